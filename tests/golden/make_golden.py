@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the *Python reference*.
+
+Runs ONLY in the build container, where /root/reference exists.  The reference (qgs) is
+imported with the three stand-in modules of oracle/refshim/ first on sys.path (numba ->
+identity njit, sparse -> dense-backed subset, pebble -> dummy), so CPython executes the
+reference's own loops statement by statement (same IEEE-754 operation order as numba).
+
+Nothing of the reference's source is copied: the outputs are DATA (inputs + expected
+outputs) written as .npz, plus gzip copies of the .ref DATA files that the reference's
+own tests compare against (model_test/*.ref).
+
+    python tests/golden/make_golden.py            # all configs (6x6 takes ~3 min)
+    python tests/golden/make_golden.py rp20 a36   # a subset
+
+Configs
+    rp20  : qgs_rp.py:77-83 parameters (Reinhold-Pierrehumbert, ndim 20)
+    a36   : model_test/test_aotensor.py:37-44 parameters (MAOOAM 2x2/2x4, ndim 36)
+    m36   : qgs_maooam.py:78-92 parameters (MAOOAM 2x2/2x4, ndim 36; BASELINE configs 2,4,5)
+    t228  : model_test/test_aotensor_6x6.py:42-47 parameters (MAOOAM 6x6/6x6, ndim 228)
+"""
+import gzip
+import json
+import os
+import shutil
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REPO, 'oracle', 'refshim'))
+
+import numpy as np  # noqa: E402
+
+from qgs.params.params import QgParams  # noqa: E402
+from qgs.functions.tendencies import create_tendencies  # noqa: E402
+from qgs.integrators.integrate import (integrate_runge_kutta, integrate_runge_kutta_tgls,  # noqa: E402
+                                       _integrate_runge_kutta_jit, _integrate_runge_kutta_tgls_jit,
+                                       _zeros_func)
+from qgs.integrators.integrator import RungeKuttaIntegrator, RungeKuttaTglsIntegrator  # noqa: E402
+
+
+def params_rp20():
+    p = QgParams({'phi0_npi': np.deg2rad(50.) / np.pi, 'hd': 0.1})
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.ground_params.set_orography(0.2, 1)
+    p.atemperature_params.set_thetas(0.2, 0)
+    return p
+
+
+def params_a36():
+    p = QgParams({'rr': 287.e0, 'sb': 5.6e-8})
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_oceanic_basin_fourier_modes(2, 4)
+    p.set_params({'kd': 0.04, 'kdp': 0.04, 'n': 1.5})
+    return p
+
+
+def params_m36():
+    p = QgParams()
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_oceanic_basin_fourier_modes(2, 4)
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'n': 1.5, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'T0': 289.3, 'hlambda': 15.06, })
+    p.gotemperature_params.set_params({'gamma': 5.6e8, 'T0': 301.46})
+    p.atemperature_params.set_insolation(103.3333, 0)
+    p.gotemperature_params.set_insolation(310., 0)
+    return p
+
+
+def params_t228():
+    p = QgParams({'rr': 287.e0, 'sb': 5.6e-8})
+    p.set_atmospheric_channel_fourier_modes(6, 6)
+    p.set_oceanic_basin_fourier_modes(6, 6)
+    p.set_params({'kd': 0.04, 'kdp': 0.04, 'n': 1.5})
+    return p
+
+
+CONFIGS = {
+    'rp20': dict(make=params_rp20, ic_scale=0.1, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
+    'a36': dict(make=params_a36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
+    'm36': dict(make=params_m36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
+    't228': dict(make=params_t228, ic_scale=0.01, n_x=8, n_jac=2, long_steps=(10,), n_traj=2),
+}
+
+RK4 = dict(c=np.array([0., 0.5, 0.5, 1.]), b=np.array([1. / 6, 1. / 3, 1. / 3, 1. / 6]),
+           a=np.array([[0., 0, 0, 0], [0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, 1., 0]]))
+# Heun's 2-stage method and Kutta's 3rd order (dense lower-triangular `a`) as non-default tableaus
+RK2 = dict(c=np.array([0., 1.]), b=np.array([0.5, 0.5]), a=np.array([[0., 0.], [1., 0.]]))
+RK3 = dict(c=np.array([0., 0.5, 1.]), b=np.array([1. / 6, 2. / 3, 1. / 6]),
+           a=np.array([[0., 0, 0], [0.5, 0, 0], [-1., 2., 0]]))
+
+
+def derived_params(p):
+    """Known-answer derived parameters, pins the host-side parameter logic."""
+    out = {}
+
+    def put(name, v):
+        if v is None:
+            return
+        out[name] = np.asarray(v, dtype=float)
+
+    put('ndim', p.ndim)
+    put('nmod', p.nmod)
+    put('variables_range', p.variables_range)
+    put('L', p.scale_params.L)
+    put('n', p.scale_params.n)
+    put('beta', p.scale_params.beta)
+    put('kd', p.atmospheric_params.kd)
+    put('kdp', p.atmospheric_params.kdp)
+    put('sig0', p.atmospheric_params.sig0)
+    put('hd', p.atemperature_params.hd if p.atemperature_params is not None else None)
+    if p.oceanic_params is not None:
+        put('oc_r', p.oceanic_params.r)
+        put('oc_d', p.oceanic_params.d)
+        put('oc_gp', p.oceanic_params.gp)
+        put('oc_h', p.oceanic_params.h)
+    for name in ('LR', 'G', 'Cpgo', 'Lpgo', 'Cpa', 'Lpa', 'sbpgo', 'sbpa', 'LSBpgo', 'LSBpa'):
+        try:
+            put(name, getattr(p, name))
+        except Exception:
+            pass
+    if p.atemperature_params is not None and p.atemperature_params.thetas is not None:
+        put('thetas', p.atemperature_params.thetas)
+    if p.ground_params is not None and p.ground_params.hk is not None:
+        put('hk', p.ground_params.hk)
+    return out
+
+
+def inner_products(aip, oip):
+    out = {}
+    if aip is not None:
+        for nm in ('a', 'u', 'c', 'b', 'g', 's', 'd'):
+            t = getattr(aip, '_' + nm, None)
+            if t is not None:
+                out['aip_' + nm] = t.todense()
+    if oip is not None:
+        for nm in ('M', 'U', 'N', 'O', 'C', 'K', 'W'):
+            t = getattr(oip, '_' + nm, None)
+            if t is not None:
+                out['oip_' + nm] = t.todense()
+    return out
+
+
+def gen(name):
+    cfg = CONFIGS[name]
+    t_start = time.time()
+    p = cfg['make']()
+    f, Df, ips, T = create_tendencies(p, return_inner_products=True, return_qgtensor=True)
+    ndim = p.ndim
+    print('[%s] tensor built in %.1fs, ndim=%d' % (name, time.time() - t_start, ndim), flush=True)
+
+    out = {}
+    coo = T.tensor.coords.T
+    val = T.tensor.data
+    jcoo = T.jacobian_tensor.coords.T
+    jval = T.jacobian_tensor.data
+    out['ndim'] = np.int64(ndim)
+    out['coo'] = coo.astype(np.int32)
+    out['val'] = val.astype(np.float64)
+    out['jcoo'] = jcoo.astype(np.int32)
+    out['jval'] = jval.astype(np.float64)
+    for k, v in derived_params(p).items():
+        out['par_' + k] = v
+    if name != 't228':      # 6x6 inner products are pinned by the gzip'ed .ref file instead
+        for k, v in inner_products(ips[0], ips[1]).items():
+            out[k] = v
+
+    # (ii) f(x), Df(x) on seeded states
+    scale = cfg['ic_scale']
+    X = np.stack([np.random.RandomState(s).rand(ndim) * scale for s in range(cfg['n_x'])])
+    out['fx_x'] = X
+    out['fx_f'] = np.stack([f(0., x) for x in X])
+    out['fx_Df'] = np.stack([Df(0., x) for x in X[:cfg['n_jac']]])
+
+    # (iii) stepper goldens
+    n_traj = cfg['n_traj']
+    rng = np.random.RandomState(21217)
+    ic = rng.rand(n_traj, ndim) * scale
+    out['rk_ic'] = ic
+    dt = 0.1
+    meta = {'rk_cases': [], 'tgls_cases': [], 'api_cases': []}
+
+    def rk_case(tag, steps, ws, forward, tab, dt=dt, t_end=None, ics=ic):
+        t0 = 0.
+        t = steps * dt if t_end is None else t_end
+        timev = np.concatenate((np.arange(t0, t, dt), np.full((1,), t)))
+        rec = _integrate_runge_kutta_jit(f, timev, ics, 1 if forward else -1, ws, tab['b'], tab['c'], tab['a'])
+        out['rk_%s_time' % tag] = timev
+        out['rk_%s_traj' % tag] = np.ascontiguousarray(rec)
+        meta['rk_cases'].append(dict(tag=tag, steps=steps, ws=ws, forward=forward, s=len(tab['b']),
+                                     dt=dt, t=t, n_traj=int(ics.shape[0])))
+        for k in 'abc':
+            out['rk_%s_%s' % (tag, k)] = tab[k]
+
+    short = (1, 10)
+    for steps in short:
+        for ws in (0, 1, 3):
+            for fwd in (True, False):
+                rk_case('s%d_w%d_%s_rk4' % (steps, ws, 'f' if fwd else 'b'), steps, ws, fwd, RK4)
+    rk_case('s10_w3_f_rk2', 10, 3, True, RK2)
+    rk_case('s10_w0_b_rk2', 10, 0, False, RK2)
+    rk_case('s10_w1_f_rk3', 10, 1, True, RK3)
+    # last step shorter than dt (t not a multiple of dt) and write_steps not dividing the step count
+    rk_case('short_last_w4_f_rk4', 10, 4, True, RK4, t_end=0.97)
+    rk_case('short_last_w4_b_rk4', 10, 4, False, RK4, t_end=0.97)
+    for steps in cfg['long_steps']:
+        rk_case('s%d_w0_f_rk4' % steps, steps, 0, True, RK4)
+    if name != 't228':
+        rk_case('s100_w7_f_rk4', 100, 7, True, RK4)
+        rk_case('s100_w10_b_rk4', 100, 10, False, RK4, ics=ic[:2])
+    print('[%s] rk goldens done at %.1fs' % (name, time.time() - t_start), flush=True)
+
+    # (iv) TGLS goldens (10 steps at 36; 3 steps at 228)
+    tg_steps = 3 if name == 't228' else 10
+    tg_ntraj = 2 if name == 't228' else 3
+    tic = ic[:tg_ntraj]
+    out['tgls_ic'] = tic
+    trng = np.random.RandomState(777)
+    n_tg = 5
+    tg_variants = {
+        'eye': np.eye(ndim)[np.newaxis].repeat(tg_ntraj, axis=0),                 # (n_traj, ndim, ndim)
+        'vec': trng.randn(tg_ntraj, ndim, 1),                                     # (n_traj, ndim, 1)
+        'few': trng.randn(tg_ntraj, ndim, n_tg),                                  # (n_traj, ndim, n_tg)
+    }
+    if name == 't228':
+        tg_variants.pop('eye')
+        tg_variants['eye8'] = np.eye(ndim)[:, :8][np.newaxis].repeat(tg_ntraj, axis=0)
+
+    def tgls_case(tag, tg_ic, ws, forward, adjoint, inverse, tab=RK4, steps=tg_steps):
+        timev = np.concatenate((np.arange(0., steps * dt, dt), np.full((1,), steps * dt)))
+        rec, fm = _integrate_runge_kutta_tgls_jit(f, Df, timev, tic, tg_ic, 1 if forward else -1, ws,
+                                                  tab['b'], tab['c'], tab['a'], adjoint, -1. if inverse else 1.,
+                                                  _zeros_func)
+        out['tgls_%s_time' % tag] = timev
+        out['tgls_%s_tgic' % tag] = tg_ic
+        out['tgls_%s_traj' % tag] = np.ascontiguousarray(rec)
+        out['tgls_%s_fm' % tag] = np.ascontiguousarray(fm)
+        for k in 'abc':
+            out['tgls_%s_%s' % (tag, k)] = tab[k]
+        meta['tgls_cases'].append(dict(tag=tag, steps=steps, ws=ws, forward=forward, adjoint=adjoint,
+                                       inverse=inverse, s=len(tab['b']), dt=dt))
+
+    for vname, tg in tg_variants.items():
+        tgls_case('%s_w0_f' % vname, tg, 0, True, False, False)
+    first = list(tg_variants)[0]
+    tgls_case('%s_w1_f' % first, tg_variants[first], 1, True, False, False)
+    tgls_case('few_w3_f', tg_variants['few'], 3, True, False, False)
+    tgls_case('few_w0_f_adj', tg_variants['few'], 0, True, True, False)
+    tgls_case('few_w1_b_adj_inv', tg_variants['few'], 1, False, True, True)
+    tgls_case('few_w3_b_inv', tg_variants['few'], 3, False, False, True)
+    tgls_case('few_w1_f_rk2', tg_variants['few'], 1, True, False, False, tab=RK2)
+    tgls_case('few_w0_f_rk3_adj', tg_variants['few'], 0, True, True, False, tab=RK3)
+    print('[%s] tgls goldens done at %.1fs' % (name, time.time() - t_start), flush=True)
+
+    # (v) API-level outputs (functional wrappers + the multiprocessing classes)
+    if name != 't228':
+        def api_rk(tag, **kw):
+            tt, tr = integrate_runge_kutta(f, **kw)
+            out['api_%s_time' % tag] = np.asarray(tt)
+            out['api_%s_traj' % tag] = np.asarray(tr)
+            kk = {k: (v if not isinstance(v, np.ndarray) else '<array>') for k, v in kw.items()}
+            meta['api_cases'].append(dict(tag=tag, kind='rk', kw=kk))
+
+        api_rk('f_w3', t0=0., t=1., dt=0.1, ic=ic, forward=True, write_steps=3)
+        api_rk('b_w3', t0=0., t=1., dt=0.1, ic=ic, forward=False, write_steps=3)
+        api_rk('f_w0', t0=0., t=1., dt=0.1, ic=ic, forward=True, write_steps=0)
+        api_rk('f_w1_single', t0=0., t=0.5, dt=0.1, ic=ic[0], forward=True, write_steps=1)
+        api_rk('f_w0_single', t0=0., t=0.5, dt=0.1, ic=ic[0], forward=True, write_steps=0)
+        api_rk('b_w2_t0', t0=1., t=2.05, dt=0.1, ic=ic[:3], forward=False, write_steps=2)
+
+        def api_tgls(tag, tg_ic, **kw):
+            tt, tr, fm = integrate_runge_kutta_tgls(f, Df, tg_ic=tg_ic, **kw)
+            out['api_%s_time' % tag] = np.asarray(tt)
+            out['api_%s_traj' % tag] = np.asarray(tr)
+            out['api_%s_fm' % tag] = np.asarray(fm)
+            if tg_ic is not None:
+                out['api_%s_tgic' % tag] = tg_ic
+            kk = {k: (v if not isinstance(v, np.ndarray) else '<array>') for k, v in kw.items()}
+            meta['api_cases'].append(dict(tag=tag, kind='tgls', kw=kk))
+
+        arng = np.random.RandomState(99)
+        api_tgls('tg_none', None, t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=1)
+        api_tgls('tg_1d', arng.randn(ndim), t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=1)
+        api_tgls('tg_2d_ntg', arng.randn(4, ndim), t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=0)
+        api_tgls('tg_2d_ntraj', arng.randn(2, ndim), t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=2)
+        api_tgls('tg_3d_swapped', arng.randn(2, 4, ndim), t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=1,
+                 adjoint=True)
+        api_tgls('tg_3d', arng.randn(2, ndim, 4), t0=0., t=0.3, dt=0.1, ic=ic[:2], write_steps=1,
+                 forward=False, inverse=True)
+        api_tgls('tg_none_single', None, t0=0., t=0.3, dt=0.1, ic=ic[0], write_steps=0)
+
+        # the multiprocessing classes themselves (reference integrator.py), 2 workers
+        integ = RungeKuttaIntegrator(num_threads=2)
+        integ.set_func(f)
+        integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=5)
+        tt, tr = integ.get_trajectories()
+        out['cls_rk_w5_time'] = np.asarray(tt)
+        out['cls_rk_w5_traj'] = np.asarray(tr)
+        integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=0, forward=False)
+        tt, tr = integ.get_trajectories()
+        out['cls_rk_w0b_time'] = np.asarray(tt)
+        out['cls_rk_w0b_traj'] = np.asarray(tr)
+        integ.terminate()
+
+        tinteg = RungeKuttaTglsIntegrator(num_threads=2)
+        tinteg.set_func(f, Df)
+        tinteg.integrate(0., 0.3, 0.1, ic=ic[:2], write_steps=1)
+        tt, tr, fm = tinteg.get_trajectories()
+        out['cls_tgls_time'] = np.asarray(tt)
+        out['cls_tgls_traj'] = np.asarray(tr)
+        out['cls_tgls_fm'] = np.asarray(fm)
+        tinteg.terminate()
+
+    out['meta_json'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('[%s] wrote %s (%.1f KB) in %.1fs' % (name, path, os.path.getsize(path) / 1024., time.time() - t_start),
+          flush=True)
+
+
+def copy_ref_data():
+    """gzip copies of the reference tests' own DATA files (model_test/*.ref)."""
+    dst = os.path.join(HERE, 'ref')
+    os.makedirs(dst, exist_ok=True)
+    for fn in ('test_aotensor.ref', 'test_aotensor_jacobian.ref', 'test_aotensor_6x6.ref',
+               'test_inprod_analytic.ref', 'test_inprod_analytic_6x6.ref'):
+        with open(os.path.join(REF, 'model_test', fn), 'rb') as fi, \
+                gzip.GzipFile(os.path.join(dst, fn + '.gz'), 'wb', mtime=0) as fo:
+            shutil.copyfileobj(fi, fo)
+
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(CONFIGS)
+    copy_ref_data()
+    for nm in names:
+        gen(nm)
