@@ -1,0 +1,140 @@
+/*
+ * qgs_hip.h -- C-ABI of libqgs_hip.so: the MI355X (gfx950) implementation of the qgs
+ * ensemble spectral-tendency + Runge-Kutta hot path.
+ *
+ * The reference (Climdyn/qgs) is pure Python and has no FFI of its own for this path; its
+ * "native" code is what numba compiles from the functions cited below.  Each entry point
+ * here replaces one of those functions for a whole ensemble at once, and is what a ctypes
+ * binding inside the reference would call.  Plain pointers and sizes
+ * only; no torch / numpy types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; qgs_last_error() gives the message
+ *     (thread-local).
+ *   - "host layout"  = the reference's NumPy layout, C-contiguous:
+ *         states      (n_traj, ndim)
+ *         trajectory  (n_traj, ndim, n_records)
+ *         tangent     (n_traj, ndim, n_tg [, n_records])
+ *   - "device layout" = mode-major ensemble, one member per wavefront lane:
+ *         states      X[mode][member]            element (d, m) at  d*ld + m
+ *         trajectory  R[record][mode][member]    element (r, d, m) at (r*ndim + d)*ld + m
+ *         tangent     F[record][mode][col][member]
+ *     `ld` (leading dimension, in members) is >= n_traj and a multiple of 64.
+ *   - tensor coordinates are the reference's: (i, j, k) with index 0 the constant slot
+ *     (eta_0 = 1), rows i in 1..ndim  (qgs/tensors/qgtensor.py:19-65).
+ *   - all floating point data is IEEE-754 binary64.
+ */
+#ifndef QGS_HIP_H
+#define QGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qgs_model qgs_model;   /* opaque: tensors staged on one device + compiled kernels */
+
+/* Error text of the last failing call on this thread ("" if none). */
+const char *qgs_last_error(void);
+
+/* Number of visible HIP devices and the gcnArchName of device 0 (e.g. "gfx950:sramecc+:xnack-").
+ * Fails (<0) when no GPU is visible: there is no CPU fallback in this library. */
+int qgs_backend_info(int *n_devices, char *arch_buf, int buflen);
+
+/* Stage a model's tensors on `device` and build its kernels.
+ *   coo/val   : qgs/functions/tendencies.py:92-93   coo = tensor.coords.T (nnz,3), val = tensor.data
+ *   jcoo/jval : qgs/functions/tendencies.py:95-96   jacobian_tensor ditto (may be NULL/0: then
+ *               qgs_jacobian and qgs_rk_tgls_integrate are unavailable)
+ * Replaces the closure capture of create_tendencies (tendencies.py:111-121). */
+int qgs_model_create(int device, int ndim,
+                     int64_t nnz, const int32_t *coo, const double *val,
+                     int64_t jnnz, const int32_t *jcoo, const double *jval,
+                     qgs_model **out);
+int qgs_model_destroy(qgs_model *m);
+
+/* Model properties: which=0 ndim, 1 nnz, 2 jnnz, 3 device, 4 specialised-kernel available (0/1). */
+int64_t qgs_model_info(const qgs_model *m, int which);
+
+/* Select the kernel family: 0 = automatic (specialised when available, else generic),
+ * 1 = force generic (tensor streamed from memory, any ndim), 2 = force specialised. */
+int qgs_model_set_kernel(qgs_model *m, int kind);
+
+/* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) -------------- */
+
+/* f(t, x) for n_traj states at once.   qgs/functions/tendencies.py:111-115 + sparse_mul.py:48-81 */
+int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx);
+
+/* Df(t, x) -> (n_traj, ndim, ndim).     qgs/functions/tendencies.py:117-121 + sparse_mul.py:13-45 */
+int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac);
+
+/* Number of records the steppers produce.  qgs/integrators/integrate.py:190-196 */
+int64_t qgs_n_records(const double *time, int64_t n_time, int64_t write_steps);
+
+/* _integrate_runge_kutta_jit(f, time, ic, time_direction, write_steps, b, c, a)
+ * qgs/integrators/integrate.py:182-223.  `time` is the undirected grid (the function reverses it
+ * for time_direction == -1 exactly like :199-202) and `traj` comes back direction-corrected (:223).
+ * traj must hold n_traj*ndim*qgs_n_records(...) doubles. */
+int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic,
+                     const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                     int s, const double *b, const double *c, const double *a,
+                     double *traj);
+
+/* _integrate_runge_kutta_tgls_jit(f, fjac, time, ic, tg_ic, time_direction, write_steps, b, c, a,
+ *                                 adjoint, inverse, boundary=_zeros_func)
+ * qgs/integrators/integrate.py:555-614.  `inverse` is the +-1.0 multiplier (integrate.py:521-523).
+ * Only the zero boundary term (the reference default, :235-237) runs on the device. */
+int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg,
+                          const double *ic, const double *tg_ic,
+                          const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                          int s, const double *b, const double *c, const double *a,
+                          int adjoint, double inverse,
+                          double *traj, double *fmatrix);
+
+/* ---- device-layout entry points (pointers are device pointers on the model's device; the work
+ *      is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT synchronised) ------ */
+
+/* (n_traj, ndim) host-layout device buffer  <->  mode-major X[ndim][ld] */
+int qgs_pack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_rows, double *d_x_modes, void *stream);
+int qgs_unpack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_modes, double *d_x_rows, void *stream);
+/* R[n_records][ndim][ld]  ->  (n_traj, ndim, n_records) */
+int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records,
+                       const double *d_rec_modes, double *d_rec_rows, void *stream);
+
+int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x, double *d_dx, void *stream);
+
+/* `time` is a HOST pointer (n_time doubles, undirected); it is small and is staged by the library.
+ * d_rec: R[n_records][ndim][ld]. */
+int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_ic,
+                            const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                            int s, const double *b, const double *c, const double *a,
+                            double *d_rec, void *stream);
+
+/* d_tg_ic: F[ndim][n_tg][ld];  d_rec_fm: F[n_records][ndim][n_tg][ld]. */
+int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg,
+                                 const double *d_ic, const double *d_tg_ic,
+                                 const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                                 int s, const double *b, const double *c, const double *a,
+                                 int adjoint, double inverse,
+                                 double *d_rec, double *d_rec_fm, void *stream);
+
+/* Name, VGPR/SGPR/LDS/scratch use of the kernel the last *_device call launched (for profiling
+ * reports).  Any pointer may be NULL. */
+int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,
+                         int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
+
+/* Compile and cache the specialised kernels of a model WITHOUT touching a device (build hosts have no
+ * GPU; the cached code objects travel with the source tree).  stage_counts lists the RK stage counts
+ * to pre-build; arch NULL = $QGS_HIP_ARCH or gfx950. */
+int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val,
+                 int64_t jnnz, const int32_t *jcoo, const double *jval,
+                 int n_stage_counts, const int *stage_counts, const char *arch);
+
+/* Generated HIP source of the specialised kernels of this model (debugging / inspection).
+ * Returns the length; copies at most buflen-1 bytes. */
+int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QGS_HIP_H */

@@ -1,0 +1,231 @@
+"""ctypes binding of libqgs_hip.so (the C-ABI of include/qgs_hip.h) and the `HipModel` handle.
+
+This is the only place where the package crosses into native code.  PyTorch is *not* needed
+here: the host-layout entry points take NumPy arrays; the device-layout entry points take raw
+device pointers (ints), which callers obtain from torch tensors (`tensor.data_ptr()`).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libqgs_hip.so')
+
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags='C_CONTIGUOUS')
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_vp = ctypes.c_void_p
+_dbl = ctypes.c_double
+
+#: every symbol include/qgs_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    'qgs_last_error': (ctypes.c_char_p, []),
+    'qgs_backend_info': (_int, [ctypes.POINTER(_int), ctypes.c_char_p, _int]),
+    'qgs_model_create': (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
+    'qgs_model_destroy': (_int, [_vp]),
+    'qgs_model_info': (_i64, [_vp, _int]),
+    'qgs_model_set_kernel': (_int, [_vp, _int]),
+    'qgs_tendencies': (_int, [_vp, _i64, _f64p, _f64p]),
+    'qgs_jacobian': (_int, [_vp, _i64, _f64p, _f64p]),
+    'qgs_n_records': (_i64, [_f64p, _i64, _i64]),
+    'qgs_rk_integrate': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p]),
+    'qgs_rk_tgls_integrate': (_int, [_vp, _i64, _i64, _f64p, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p,
+                                     _int, _dbl, _f64p, _f64p]),
+    'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_unpack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_unpack_records': (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_tendencies_device': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_rk_integrate_device': (_int, [_vp, _i64, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp, _vp]),
+    'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
+                                            _f64p, _int, _dbl, _vp, _vp, _vp]),
+    'qgs_last_kernel_info': (_int, [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
+                                    ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
+    'qgs_model_kernel_source': (_i64, [_vp, ctypes.c_char_p, _i64]),
+}
+
+_LIB = None
+
+
+class QgsHipError(RuntimeError):
+    pass
+
+
+def build_library(force=False):
+    """Compile qgs_amd/libqgs_hip.so with hipcc for gfx950 (works without a GPU)."""
+    args = ['make', '-C', os.path.join(_HERE, 'csrc'), '-s']
+    if force:
+        args.append('-B')
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    """Load libqgs_hip.so.  Raises QgsHipError if it has not been built -- there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise QgsHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C qgs_amd/csrc`.  qgs_amd has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    return lib().qgs_last_error().decode(errors='replace')
+
+
+def _check(rc):
+    if rc != 0:
+        raise QgsHipError(last_error())
+
+
+def backend_info():
+    n = _int(0)
+    buf = ctypes.create_string_buffer(256)
+    _check(lib().qgs_backend_info(ctypes.byref(n), buf, 256))
+    return n.value, buf.value.decode()
+
+
+def n_records(time, write_steps):
+    time = np.ascontiguousarray(time, dtype=np.float64)
+    return int(lib().qgs_n_records(time, len(time), int(write_steps)))
+
+
+def _c(x, dt=np.float64):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None else None
+
+
+def prebuild(ndim, coo, val, jcoo, jval, stage_counts=(4,), arch=None):
+    """Compile + cache the specialised kernels of a tensor without a GPU (see qgs_prebuild)."""
+    coo, val = _c(coo, np.int32), _c(val)
+    jcoo = _c(jcoo, np.int32) if jcoo is not None else None
+    jval = _c(jval) if jval is not None else None
+    sc = (_int * len(stage_counts))(*stage_counts)
+    _check(lib().qgs_prebuild(int(ndim), len(val), _ptr(coo), _ptr(val), 0 if jval is None else len(jval), _ptr(jcoo),
+                              _ptr(jval), len(stage_counts), sc, arch.encode() if arch else None))
+
+
+class HipModel(object):
+    """A model's tensors staged on one GPU (qgs_model handle).
+
+    coo/val, jcoo/jval are the arrays the reference's closures capture
+    (qgs/functions/tendencies.py:92-96): `tensor.coords.T`, `tensor.data`, and the same for
+    `jacobian_tensor`.
+    """
+
+    KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALISED = 0, 1, 2
+
+    def __init__(self, ndim, coo, val, jcoo=None, jval=None, device=0):
+        self.ndim = int(ndim)
+        self.device = int(device)
+        self.coo, self.val = _c(coo, np.int32), _c(val)
+        self.jcoo = _c(jcoo, np.int32) if jcoo is not None else None
+        self.jval = _c(jval) if jval is not None else None
+        h = _vp()
+        _check(lib().qgs_model_create(self.device, self.ndim, len(self.val), _ptr(self.coo), _ptr(self.val),
+                                      0 if self.jval is None else len(self.jval), _ptr(self.jcoo), _ptr(self.jval),
+                                      ctypes.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().qgs_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, kind):
+        _check(lib().qgs_model_set_kernel(self._h, int(kind)))
+
+    @property
+    def specialised_available(self):
+        return bool(lib().qgs_model_info(self._h, 4))
+
+    def last_kernel_info(self):
+        name = ctypes.create_string_buffer(128)
+        v, s, l, sc = _int(0), _int(0), _int(0), _int(0)
+        _check(lib().qgs_last_kernel_info(self._h, name, 128, ctypes.byref(v), ctypes.byref(s), ctypes.byref(l),
+                                          ctypes.byref(sc)))
+        return dict(name=name.value.decode(), vgprs=v.value, sgprs=s.value, lds_bytes=l.value, scratch_bytes=sc.value)
+
+    def kernel_source(self):
+        n = lib().qgs_model_kernel_source(self._h, None, 0)
+        buf = ctypes.create_string_buffer(int(n) + 1)
+        lib().qgs_model_kernel_source(self._h, buf, int(n) + 1)
+        return buf.value.decode()
+
+    # ---- host-layout calls (NumPy in, NumPy out) ----------------------------------------------
+    def tendencies(self, x):
+        x = _c(x)
+        xb = x.reshape(-1, self.ndim)
+        out = np.empty_like(xb)
+        _check(lib().qgs_tendencies(self._h, xb.shape[0], xb, out))
+        return out.reshape(x.shape)
+
+    def jacobian(self, x):
+        x = _c(x)
+        xb = x.reshape(-1, self.ndim)
+        out = np.empty((xb.shape[0], self.ndim, self.ndim))
+        _check(lib().qgs_jacobian(self._h, xb.shape[0], xb, out))
+        return out[0] if x.ndim == 1 else out
+
+    def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a):
+        time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
+        nrec = n_records(time, write_steps)
+        traj = np.empty((ic.shape[0], self.ndim, nrec))
+        _check(lib().qgs_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
+                                      len(b), b, c, a, traj))
+        return traj
+
+    def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse):
+        time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)
+        nrec = n_records(time, write_steps)
+        n_traj, n_tg = ic.shape[0], tg_ic.shape[2]
+        traj = np.empty((n_traj, self.ndim, nrec))
+        fm = np.empty((n_traj, self.ndim, n_tg, nrec))
+        _check(lib().qgs_rk_tgls_integrate(self._h, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
+                                           int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
+                                           traj, fm))
+        return traj, fm
+
+    # ---- device-layout calls (raw device pointers as ints; enqueue on `stream`, no sync) ---------
+    def pack_states(self, n_traj, ld, d_rows, d_modes, stream=0):
+        _check(lib().qgs_pack_states(self._h, n_traj, ld, d_rows, d_modes, stream or None))
+
+    def unpack_states(self, n_traj, ld, d_modes, d_rows, stream=0):
+        _check(lib().qgs_unpack_states(self._h, n_traj, ld, d_modes, d_rows, stream or None))
+
+    def unpack_records(self, n_traj, ld, n_inner, nrec, d_in, d_out, stream=0):
+        _check(lib().qgs_unpack_records(self._h, n_traj, ld, n_inner, nrec, d_in, d_out, stream or None))
+
+    def tendencies_device(self, n_traj, ld, d_x, d_dx, stream=0):
+        _check(lib().qgs_tendencies_device(self._h, n_traj, ld, d_x, d_dx, stream or None))
+
+    def rk_integrate_device(self, n_traj, ld, d_ic, time, time_direction, write_steps, b, c, a, d_rec, stream=0):
+        time, b, c, a = _c(time), _c(b), _c(c), _c(a)
+        _check(lib().qgs_rk_integrate_device(self._h, n_traj, ld, d_ic, time, len(time), int(time_direction),
+                                             int(write_steps), len(b), b, c, a, d_rec, stream or None))
+
+    def rk_tgls_integrate_device(self, n_traj, ld, n_tg, d_ic, d_tg_ic, time, time_direction, write_steps, b, c, a,
+                                 adjoint, inverse, d_rec, d_rec_fm, stream=0):
+        time, b, c, a = _c(time), _c(b), _c(c), _c(a)
+        _check(lib().qgs_rk_tgls_integrate_device(self._h, n_traj, ld, n_tg, d_ic, d_tg_ic, time, len(time),
+                                                  int(time_direction), int(write_steps), len(b), b, c, a,
+                                                  int(bool(adjoint)), float(inverse), d_rec, d_rec_fm, stream or None))

@@ -1,0 +1,414 @@
+// codegen.cpp -- see codegen.h.  Emits HIP C++ source; everything is straight-line fp64 code
+// with the tensor coefficients as hex-float literals, so the compiled kernels contain no
+// tensor loads at all: coefficients arrive through the scalar unit (s_mov literals) and every
+// VALU slot is a v_mul_f64 / v_fma_f64.
+#include "codegen.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <map>
+#include <sstream>
+
+namespace qgs {
+
+namespace {
+
+std::string lit(double v)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%a", v);   // exact hex-float literal (C++17)
+    return std::string(buf);
+}
+
+struct Bil { int j, k; double c; };
+struct Lin { int k; double c; };
+
+struct Row {
+    double c0 = 0.0;
+    bool has_c0 = false;
+    std::vector<Lin> lin;
+    std::vector<Bil> bil;
+};
+
+// rows[i] for i in 1..ndim from COO entries (entries are summed if duplicated)
+std::vector<Row> build_rows(int ndim, const std::vector<Term> &tensor)
+{
+    std::vector<Row> rows(ndim + 1);
+    for (const Term &t : tensor) {
+        if (t.i < 1 || t.i > ndim) continue;        // row 0 is the constant slot: res[0] = 1 (sparse_mul.py:80)
+        Row &r = rows[t.i];
+        if (t.j == 0 && t.k == 0) { r.c0 += t.v; r.has_c0 = true; }
+        else if (t.j == 0 || t.k == 0) r.lin.push_back({std::max(t.j, t.k), t.v});
+        else r.bil.push_back({t.j, t.k, t.v});
+    }
+    return rows;
+}
+
+using NameFn = std::function<std::string(int)>;
+
+// One accumulation "r": tracks whether it has been initialised to emit mul instead of fma.
+struct Acc {
+    std::ostringstream &o;
+    std::string name;
+    bool init = false;
+    const char *indent;
+    Acc(std::ostringstream &os, const std::string &n, const char *ind) : o(os), name(n), indent(ind) {}
+    void set_const(double c) { o << indent << "f64 " << name << " = " << lit(c) << ";\n"; init = true; }
+    // r += c * expr
+    void add(const std::string &c, const std::string &expr)
+    {
+        if (!init) { o << indent << "f64 " << name << " = " << c << " * " << expr << ";\n"; init = true; }
+        else o << indent << name << " = __builtin_fma(" << c << ", " << expr << ", " << name << ");\n";
+    }
+    void finish() { if (!init) { o << indent << "f64 " << name << " = 0.0;\n"; init = true; } }
+};
+
+// Emit the products of a group of (sign, left, right) factors into a temp `g`:
+//   g = l0*r0; g = fma(+-l1, r1, g); ...
+struct Prod { bool neg; std::string l, r; };
+
+void emit_group(std::ostringstream &o, const char *indent, const std::string &g, const std::vector<Prod> &ps)
+{
+    for (size_t n = 0; n < ps.size(); ++n) {
+        const Prod &p = ps[n];
+        if (n == 0)
+            o << indent << "f64 " << g << " = " << (p.neg ? "-" : "") << p.l << " * " << p.r << ";\n";
+        else
+            o << indent << g << " = __builtin_fma(" << (p.neg ? "-" : "") << p.l << ", " << p.r << ", " << g << ");\n";
+    }
+}
+
+// Group items by |coefficient| (exact equality of the doubles), keeping first-appearance order.
+template <class T>
+std::vector<std::vector<T>> group_by_abs(const std::vector<T> &items, bool enable)
+{
+    std::vector<std::vector<T>> groups;
+    if (!enable) {
+        for (const T &t : items) groups.push_back({t});
+        return groups;
+    }
+    std::map<double, size_t> where;
+    for (const T &t : items) {
+        double a = std::fabs(t.c);
+        auto it = where.find(a);
+        if (it == where.end()) { where[a] = groups.size(); groups.push_back({t}); }
+        else groups[it->second].push_back(t);
+    }
+    return groups;
+}
+
+// f_i(x): emits "f64 <res> = ...;" for row i.  X(k) names the register holding x_k.
+void emit_tend_row(std::ostringstream &o, const char *indent, const Row &row, const std::string &res,
+                   const NameFn &X, const CodegenOptions &opt, int uid)
+{
+    Acc acc(o, res, indent);
+    if (row.has_c0 && row.c0 != 0.0) acc.set_const(row.c0);
+    for (const Lin &l : row.lin) acc.add(lit(l.c), X(l.k));
+    auto groups = group_by_abs(row.bil, opt.group_coeff);
+    int gi = 0;
+    for (auto &g : groups) {
+        if (g.size() == 1) {
+            acc.add(lit(g[0].c), "(" + X(g[0].j) + " * " + X(g[0].k) + ")");
+        } else {
+            std::string gname = "g" + std::to_string(uid) + "_" + std::to_string(gi++);
+            std::vector<Prod> ps;
+            const bool ref_neg = std::signbit(g[0].c);
+            for (const Bil &b : g) ps.push_back({std::signbit(b.c) != ref_neg, X(b.j), X(b.k)});
+            emit_group(o, indent, gname, ps);
+            acc.add(lit(g[0].c), gname);
+        }
+    }
+    acc.finish();
+}
+
+// Tangent / adjoint rows are both "sum of c * w_a * x_b" lists built from the Jacobian tensor
+// Tj (reference: jacobian_tensor, qgtensor.py:700-722; J[i][j] = sum_k Tj_ijk x_k, sparse_mul.py:40-45):
+//   tangent  (J w)_i   = sum_{j,k} Tj_ijk x_k w_j      -> row i   gets {w=j, x=k}
+//   adjoint  (J^T w)_j = sum_{i,k} Tj_ijk x_k w_i      -> row j   gets {w=i, x=k}
+// (x index 0 is the constant slot: the factor x_0 = 1 is dropped.)  Because Tj holds both (i,j,k) and
+// (i,k,j) with equal value, grouping by |c| recovers c*(x_k w_j + x_j w_k) with one final FMA.
+struct WX { int w, x; double c; };
+
+std::vector<std::vector<WX>> build_wx_rows(int ndim, const std::vector<Term> &jac, bool adjoint)
+{
+    std::vector<std::vector<WX>> out(ndim + 1);
+    for (const Term &t : jac) {
+        if (t.i < 1 || t.j < 1 || t.i > ndim || t.j > ndim) continue;     // Df drops row/column 0 (tendencies.py:121)
+        if (adjoint) out[t.j].push_back({t.i, t.k, t.v});
+        else out[t.i].push_back({t.j, t.k, t.v});
+    }
+    return out;
+}
+
+void emit_wx_row(std::ostringstream &o, const char *indent, const std::vector<WX> &items,
+                 const std::string &res, const NameFn &X, const NameFn &W, const CodegenOptions &opt, int uid)
+{
+    Acc acc(o, res, indent);
+    std::vector<WX> lin, bil;
+    for (const WX &a : items) (a.x == 0 ? lin : bil).push_back(a);
+    for (const WX &a : lin) acc.add(lit(a.c), W(a.w));
+    auto groups = group_by_abs(bil, opt.group_coeff);
+    int gi = 0;
+    for (auto &g : groups) {
+        if (g.size() == 1) {
+            acc.add(lit(g[0].c), "(" + X(g[0].x) + " * " + W(g[0].w) + ")");
+        } else {
+            std::string gname = "g" + std::to_string(uid) + "_" + std::to_string(gi++);
+            std::vector<Prod> ps;
+            const bool ref_neg = std::signbit(g[0].c);
+            for (const WX &a : g) ps.push_back({std::signbit(a.c) != ref_neg, X(a.x), W(a.w)});
+            emit_group(o, indent, gname, ps);
+            acc.add(lit(g[0].c), gname);
+        }
+    }
+    acc.finish();
+}
+
+NameFn names(const std::string &prefix)
+{
+    return [prefix](int k) { return prefix + std::to_string(k); };
+}
+
+std::string decl_list(const std::string &prefix, int ndim)
+{
+    std::ostringstream o;
+    o << "f64 ";
+    for (int d = 1; d <= ndim; ++d) o << prefix << d << (d < ndim ? ", " : ";");
+    return o.str();
+}
+
+const char *PRELUDE = R"(// ---- generated by qgs_amd/csrc/codegen.cpp: tensor-specialised gfx950 kernels -------------
+#ifndef __HIPCC_RTC__
+#include <hip/hip_runtime.h>   // offline hipcc build; hiprtc predefines the HIP builtins
+#endif
+typedef double f64;
+typedef long long i64;
+#define QGS_WAVE 64
+)";
+
+// Record bookkeeping shared by the steppers (reference integrate.py:190-223): record `iw` of the directed
+// run lands at index iw (forward) or n_records-1-iw (backward, the [::-1] of :223).
+const char *RECORD_HELPERS = R"(
+__device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward)
+{
+    return backward ? (n_records - 1 - iw) : iw;
+}
+)";
+
+void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+{
+    o << "\n// f(t,x) for an ensemble: x, dx are X[mode][member] with leading dimension ld\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_tend(const f64* __restrict__ x, f64* __restrict__ dx, i64 n_traj, i64 ld)\n{\n";
+    o << "    const i64 m = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n    if (m >= n_traj) return;\n";
+    for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
+    for (int i = 1; i <= ndim; ++i) {
+        o << "    {\n";
+        emit_tend_row(o, "        ", rows[i], "r", names("x"), opt, i);
+        o << "        dx[" << (i - 1) << " * ld + m] = r;\n    }\n";
+    }
+    o << "}\n";
+}
+
+void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &jac)
+{
+    // J[i][j] = sum_k Tj_ijk x_k  (sparse_mul2, sparse_mul.py:40-45); only structural entries are
+    // stored, the caller zero-fills the output.  Output layout: Jm[(i-1)*ndim + (j-1)][member].
+    std::map<std::pair<int, int>, std::vector<Lin>> ent;
+    for (const Term &t : jac)
+        if (t.i >= 1 && t.j >= 1) ent[{t.i, t.j}].push_back({t.k, t.v});
+    o << "\n// Df(t,x) for an ensemble: only structurally non-zero entries are written\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_jac(const f64* __restrict__ x, f64* __restrict__ jm, i64 n_traj, i64 ld)\n{\n";
+    o << "    const i64 m = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n    if (m >= n_traj) return;\n";
+    for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
+    for (auto &kv : ent) {
+        o << "    {\n";
+        std::ostringstream &oo = o;
+        Acc acc(oo, "e", "        ");
+        double c0 = 0.0; bool has = false;
+        for (const Lin &l : kv.second) if (l.k == 0) { c0 += l.c; has = true; }
+        if (has) acc.set_const(c0);
+        for (const Lin &l : kv.second) if (l.k != 0) acc.add(lit(l.c), "x" + std::to_string(l.k));
+        acc.finish();
+        o << "        jm[(i64)" << ((kv.first.first - 1) * ndim + (kv.first.second - 1)) << " * ld + m] = e;\n    }\n";
+    }
+    o << "}\n";
+}
+
+// Fused S-stage explicit RK stepper for sub-diagonal tableaus, one member per lane, all state in
+// registers for the whole run.  Storage: y (step start), acc (running y + dt*sum b_i k_i),
+// xa/xb (ping-pong stage inputs).  k_i is consumed row by row as it is produced.
+void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
+                    const CodegenOptions &opt)
+{
+    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : "qgs_spec_rk_s") + std::to_string(S);
+    o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only") << "\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
+      << "    const f64* __restrict__ y_in,   // X[mode][member] state at step `step_begin`\n"
+      << "    f64* __restrict__ y_out,        // state after step `step_end-1` (may be null)\n"
+      << "    f64* __restrict__ rec,          // R[record][mode][member] (may be null when no record is due)\n"
+      << "    f64* __restrict__ stages,       // S[(step-step_begin)*" << S << "+stage][mode][member] (rkstages only)\n"
+      << "    const f64* __restrict__ dtime,  // directed time grid\n"
+      << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
+    o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+      << "    const bool live = m0 < n_traj;\n"
+      << "    const i64 m = live ? m0 : (n_traj - 1);   // tail lanes shadow the last member and never store\n";
+    o << "    " << decl_list("y", ndim) << "\n";
+    for (int d = 1; d <= ndim; ++d) o << "    y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
+    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+    o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    o << "        if (write_steps > 0 && (ti % write_steps) == 0) {\n"
+      << "            f64* p = rec + qgs_rec_index(ti / write_steps, n_records, backward) * " << ndim << " * ld + m;\n"
+      << "            if (live) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    o << "            }\n        }\n";
+    o << "        " << decl_list("acc", ndim) << "\n";
+    if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
+    if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
+    for (int st = 0; st < S; ++st) {
+        const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
+        const std::string out = (st % 2 == 0) ? "xa" : "xb";
+        const bool last = (st == S - 1);
+        o << "        {   // stage " << st << "\n";
+        o << "            const f64 hb = dt * tb" << st << ";\n";
+        if (!last) o << "            const f64 ha = dt * ta" << st << ";\n";
+        if (store_stages) {
+            o << "            if (live) {\n                f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+            for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
+            o << "            }\n";
+        }
+        for (int i = 1; i <= ndim; ++i) {
+            o << "            {\n";
+            emit_tend_row(o, "                ", rows[i], "r", names(in), opt, st * 1000 + i);
+            o << "                acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
+            if (!last) o << "                " << out << i << " = __builtin_fma(ha, r, y" << i << ");\n";
+            o << "            }\n";
+        }
+        o << "        }\n";
+    }
+    for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = acc" << d << ";\n";
+    o << "    }\n";
+    o << "    if (live) {\n";
+    o << "        if (y_out) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "            y_out[" << (d - 1) << " * ld + m] = y" << d << ";\n";
+    o << "        }\n        if (write_final) {\n"
+      << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
+    for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    o << "        }\n    }\n}\n";
+}
+
+// Tangent-linear / adjoint propagation along stored stage states.  One lane per (member, column):
+// lane l = col*ld + member; tangent arrays are F[mode][col][member] = element d*(n_tg*ld) + l.
+void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vector<WX>> &tgl,
+                     const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt)
+{
+    o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") qgs_spec_tgl_s" << S << "(\n"
+      << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
+      << "    f64* __restrict__ w_out_p,       // after step `step_end-1` (may be null)\n"
+      << "    f64* __restrict__ rec,           // F[record][mode][col][member]\n"
+      << "    const f64* __restrict__ stages,  // S[(step-step_begin)*" << S << "+stage][mode][member]\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
+      << "    int backward, int write_final, int adjoint, f64 inverse)\n{\n";
+    o << "    const i64 L = n_tg * ld;\n"
+      << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+      << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
+      << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
+      << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
+    o << "    " << decl_list("v", ndim) << "\n";
+    for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
+    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
+    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+    o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    o << "        if (write_steps > 0 && (ti % write_steps) == 0) {\n"
+      << "            f64* p = rec + qgs_rec_index(ti / write_steps, n_records, backward) * " << ndim << " * L + l;\n"
+      << "            if (live) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
+    o << "            }\n        }\n";
+    o << "        " << decl_list("acc", ndim) << "\n";
+    if (S > 1) o << "        " << decl_list("wa", ndim) << "\n";
+    if (S > 2) o << "        " << decl_list("wb", ndim) << "\n";
+    for (int st = 0; st < S; ++st) {
+        const std::string in = (st == 0) ? "v" : ((st % 2 == 1) ? "wa" : "wb");
+        const std::string out = (st % 2 == 0) ? "wa" : "wb";
+        const bool last = (st == S - 1);
+        o << "        {   // stage " << st << "\n";
+        o << "            const f64 hb = dt * tb" << st << " * inverse;\n";      // inverse = +-1: exact
+        if (!last) o << "            const f64 ha = dt * ta" << st << " * inverse;\n";
+        o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+        for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+        for (int pass = 0; pass < 2; ++pass) {
+            o << "            if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
+            for (int i = 1; i <= ndim; ++i) {
+                o << "                {\n";
+                emit_wx_row(o, "                    ", pass == 0 ? tgl[i] : adj[i], "r", names("x"), names(in), opt,
+                            pass * 100000 + st * 1000 + i);
+                o << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "v" : "acc") << i << ");\n";
+                if (!last) o << "                    " << out << i << " = __builtin_fma(ha, r, v" << i << ");\n";
+                o << "                }\n";
+            }
+            o << "            }\n";
+        }
+        o << "        }\n";
+    }
+    for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = acc" << d << ";\n";
+    o << "    }\n";
+    o << "    if (live) {\n        if (w_out_p) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "            w_out_p[" << (d - 1) << " * L + l] = v" << d << ";\n";
+    o << "        }\n        if (write_final) {\n"
+      << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
+    for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * L] = v" << d << ";\n";
+    o << "        }\n    }\n}\n";
+}
+
+}  // namespace
+
+bool tableau_is_subdiagonal(int s, const double *a)
+{
+    for (int i = 0; i < s; ++i)
+        for (int j = 0; j < s; ++j)
+            if (a[i * s + j] != 0.0 && j != i - 1) return false;
+    return true;
+}
+
+std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
+                            const std::vector<int> &stages, const CodegenOptions &opt)
+{
+    std::ostringstream o;
+    o << PRELUDE << RECORD_HELPERS;
+    o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
+    const std::vector<Row> rows = build_rows(ndim, tensor);
+    emit_tend_kernel(o, ndim, rows, opt);
+    if (!jac_tensor.empty()) emit_jac_kernel(o, ndim, jac_tensor);
+    const auto tgl = build_wx_rows(ndim, jac_tensor, false);
+    const auto adj = build_wx_rows(ndim, jac_tensor, true);
+    for (int S : stages) {
+        emit_rk_kernel(o, ndim, rows, S, false, opt);
+        if (!jac_tensor.empty()) {
+            emit_rk_kernel(o, ndim, rows, S, true, opt);
+            emit_tgl_kernel(o, ndim, tgl, adj, S, opt);
+        }
+    }
+    return o.str();
+}
+
+int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, const CodegenOptions &opt)
+{
+    const std::vector<Row> rows = build_rows(ndim, tensor);
+    int64_t n = 0;
+    for (int i = 1; i <= ndim; ++i) {
+        const Row &r = rows[i];
+        n += (int64_t)r.lin.size();
+        auto groups = group_by_abs(r.bil, opt.group_coeff);
+        for (auto &g : groups) n += (int64_t)g.size() + 1;
+    }
+    return n;
+}
+
+}  // namespace qgs

@@ -1,0 +1,46 @@
+// codegen.h -- generator of tensor-specialised HIP kernel source (host side, plain C++).
+//
+// The qgs tendencies are dx_i = sum_{j,k} T_ijk x_j x_k with x_0 = 1
+// (reference: qgs/functions/sparse_mul.py:48-81, qgs/functions/tendencies.py:111-115).
+// On a CDNA4 wavefront with one ensemble member per lane the state must live in VGPRs, which
+// cannot be indexed by the run-time (j,k) of a COO entry.  So for register-resident sizes the
+// library turns the COO tensor into straight-line fp64 FMA code once per model (the same idea as
+// the reference's own symbolic code export, but targeting gfx950 ISA through hiprtc) and
+// compiles it when the model is created.  See DESIGN.md section 3.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace qgs {
+
+struct Term {          // one COO entry (i, j, k, value); index 0 is the constant slot
+    int i, j, k;
+    double v;
+};
+
+struct CodegenOptions {
+    bool group_coeff = true;   // factor equal-|coefficient| bilinear terms of a row: c*(m1 +- m2 ...)
+    int min_waves_per_simd = 1;
+};
+
+// Classification of a Butcher tableau (reference: integrate.py:214-219 uses the full matrix `a`).
+// The register-resident kernels need a[i][j] != 0 only for j == i-1 (RK4, Heun, midpoint, Euler ...).
+bool tableau_is_subdiagonal(int s, const double *a);
+
+// Source of all specialised kernels of one model:
+//   qgs_spec_tend            f(x) for an ensemble                       (tendencies.py:111-115)
+//   qgs_spec_jac             Df(x) for an ensemble                      (tendencies.py:117-121)
+//   qgs_spec_rk_s<S>         fused S-stage RK trajectory stepper        (integrate.py:182-223)
+//   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
+//   qgs_spec_tgl_s<S>        tangent / adjoint propagation, one lane per (member, column)
+//                                                                       (integrate.py:226-231, 555-614)
+// `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
+std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
+                            const std::vector<int> &stages, const CodegenOptions &opt);
+
+// Rough count of fp64 VALU instructions of one tendency evaluation in the generated code
+// (used for the roofline note in the bench output and DESIGN.md).
+int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, const CodegenOptions &opt);
+
+}  // namespace qgs

@@ -1,0 +1,62 @@
+// generic_kernels.h -- tensor-streaming ("generic") HIP kernels: any ndim, any explicit tableau.
+//
+// These kernels read the COO tensor from memory at run time (row-grouped, i.e. CSR over the
+// output index i) instead of having it compiled in.  They serve models whose state does not fit
+// the register file (ndim > QGS_SPEC_MAX_NDIM, e.g. MAOOAM 6x6 with ndim 228), tableaus with a
+// dense `a` matrix, and as an independent second implementation in the parity tests.
+//
+// Layout is the library's device layout: one ensemble member per lane, X[mode][member].
+// The tensor entry (j,k,val) of a row is wave-uniform, so it is fetched through the scalar unit /
+// broadcast, while x_j, x_k are coalesced 512-byte wavefront loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace qgs {
+
+// Row-grouped tensor on the device: entries e in [rowptr[i], rowptr[i+1]) belong to output row i
+// (i in 0..ndim, row 0 unused).  idx packs the two remaining coordinates: (a << 16) | b.
+struct DevTensor {
+    const int32_t *rowptr;   // ndim + 2
+    const uint32_t *idx;     // nnz
+    const double *val;       // nnz
+};
+
+struct RkArgs {
+    int ndim, s;
+    int64_t n_traj, ld;
+    int64_t step_begin, step_end, write_steps, n_records;
+    int backward, write_final;
+};
+
+// f(x) -> dx
+void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, const double *x, double *dx, hipStream_t st);
+// Df(x) -> jm[(i-1)*ndim + (j-1)][member]   (output must be zero-filled by the caller)
+void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, const double *x, double *jm, hipStream_t st);
+
+// Explicit s-stage RK with the full `a` matrix (integrate.py:204-221).
+//   work: (s + 2) * ndim * ld doubles of scratch;  stages: optional S[(step-step_begin)*s+stage][mode][member]
+//   tab_full: device array  b[s], a[s*s]
+void launch_gen_rk(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
+                   double *work, const double *dtime, const double *tab_full, hipStream_t st);
+
+// Tangent / adjoint propagation along stored stage states, one lane per (member, column)
+// (integrate.py:226-231, 593-609).  Jrow is the Jacobian tensor grouped by output row
+// (by i for the tangent model, by j for the adjoint), idx = (w index << 16) | x index.
+//   work: (s + 2) * ndim * n_tg * ld doubles of scratch
+void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double inverse,
+                    const double *w_in, double *w_out, double *rec, const double *stages,
+                    double *work, const double *dtime, const double *tab_full, hipStream_t st);
+
+// Layout conversion kernels (host layout <-> device layout), see include/qgs_hip.h
+void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);
+void launch_unpack_states(int ndim, int64_t n_traj, int64_t ld, const double *modes, double *rows, hipStream_t st);
+// in: R[n_records][n_inner][ld]  ->  out: (n_traj, n_inner, n_records)
+void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t n_records, const double *in, double *out,
+                           hipStream_t st);
+// tangent IC: host (n_traj, ndim, n_tg) -> F[ndim][n_tg][ld]
+void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);
+// tangent records: F[n_records][ndim][n_tg][ld] -> (n_traj, ndim, n_tg, n_records): same as unpack_records with
+// n_inner = ndim * n_tg.
+
+}  // namespace qgs

@@ -1,0 +1,269 @@
+// generic_kernels.hip -- see generic_kernels.h.  gfx950 only.
+#include "generic_kernels.h"
+
+namespace qgs {
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// One tendency row: r = sum_e val_e * x_a * x_b  with x_0 = 1 (sparse_mul.py:76-80; the row loop
+// is the COO loop restricted to coo[n,0] == i, entries kept in the reference's (j,k) order).
+__device__ __forceinline__ double row_dot2(const DevTensor &T, int i, const double *__restrict__ x, int64_t ld, int64_t m)
+{
+    double r = 0.0;
+    const int e1 = T.rowptr[i + 1];
+    for (int e = T.rowptr[i]; e < e1; ++e) {
+        const uint32_t jk = T.idx[e];
+        const uint32_t j = jk >> 16, k = jk & 0xffffu;
+        const double xj = j ? x[(int64_t)(j - 1) * ld + m] : 1.0;
+        const double xk = k ? x[(int64_t)(k - 1) * ld + m] : 1.0;
+        r = __builtin_fma(xj * xk, T.val[e], r);
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(WAVE) gen_tend_kernel(DevTensor T, int ndim, int64_t n_traj, int64_t ld,
+                                                        const double *__restrict__ x, double *__restrict__ dx)
+{
+    const int64_t m = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (m >= n_traj) return;
+    for (int i = 1; i <= ndim; ++i) dx[(int64_t)(i - 1) * ld + m] = row_dot2(T, i, x, ld, m);
+}
+
+// Jacobian rows: entries of row i carry idx = (j << 16) | k and contribute val * x_k to J[i][j]
+// (sparse_mul.py:40-45).
+__global__ void __launch_bounds__(WAVE) gen_jac_kernel(DevTensor Jt, int ndim, int64_t n_traj, int64_t ld,
+                                                       const double *__restrict__ x, double *__restrict__ jm)
+{
+    const int64_t m = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (m >= n_traj) return;
+    for (int i = 1; i <= ndim; ++i) {
+        const int e1 = Jt.rowptr[i + 1];
+        for (int e = Jt.rowptr[i]; e < e1; ++e) {
+            const uint32_t jk = Jt.idx[e];
+            const uint32_t j = jk >> 16, k = jk & 0xffffu;
+            if (j == 0) continue;                                   // column 0 is dropped (tendencies.py:121)
+            const double xk = k ? x[(int64_t)(k - 1) * ld + m] : 1.0;
+            double *p = jm + ((int64_t)(i - 1) * ndim + (j - 1)) * ld + m;
+            *p = __builtin_fma(xk, Jt.val[e], *p);
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t rec_index(int64_t iw, int64_t n_records, int backward)
+{
+    return backward ? (n_records - 1 - iw) : iw;
+}
+
+__global__ void __launch_bounds__(WAVE) gen_rk_kernel(DevTensor T, RkArgs p, const double *__restrict__ y_in,
+                                                      double *__restrict__ y_out, double *__restrict__ rec,
+                                                      double *__restrict__ stages, double *__restrict__ work,
+                                                      const double *__restrict__ dtime, const double *__restrict__ tab)
+{
+    const int64_t m = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (m >= p.n_traj) return;
+    const int ndim = p.ndim, s = p.s;
+    const int64_t ld = p.ld, A = (int64_t)ndim * ld;
+    double *y = work, *ys = work + A, *k = work + 2 * A;
+    const double *b = tab, *a = tab + s;
+    for (int d = 0; d < ndim; ++d) y[d * ld + m] = y_in[d * ld + m];
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (p.write_steps > 0 && (ti % p.write_steps) == 0) {
+            double *r = rec + rec_index(ti / p.write_steps, p.n_records, p.backward) * A + m;
+            for (int d = 0; d < ndim; ++d) r[d * ld] = y[d * ld + m];
+        }
+        for (int i = 0; i < s; ++i) {
+            for (int d = 0; d < ndim; ++d) {                              // y_s = y + (dt*a[i]) @ k
+                double acc = 0.0;
+                for (int j = 0; j < i; ++j) acc = __builtin_fma(dt * a[i * s + j], k[j * A + d * ld + m], acc);
+                ys[d * ld + m] = y[d * ld + m] + acc;
+            }
+            if (stages) {
+                double *sp = stages + ((ti - p.step_begin) * s + i) * A + m;
+                for (int d = 0; d < ndim; ++d) sp[d * ld] = ys[d * ld + m];
+            }
+            double *ki = k + i * A;
+            for (int r = 1; r <= ndim; ++r) ki[(int64_t)(r - 1) * ld + m] = row_dot2(T, r, ys, ld, m);
+        }
+        for (int d = 0; d < ndim; ++d) {                                  // y = y + (dt*b) @ k
+            double acc = 0.0;
+            for (int j = 0; j < s; ++j) acc = __builtin_fma(dt * b[j], k[j * A + d * ld + m], acc);
+            y[d * ld + m] += acc;
+        }
+    }
+    if (y_out) for (int d = 0; d < ndim; ++d) y_out[d * ld + m] = y[d * ld + m];
+    if (p.write_final) {
+        double *r = rec + rec_index(p.n_records - 1, p.n_records, p.backward) * A + m;
+        for (int d = 0; d < ndim; ++d) r[d * ld] = y[d * ld + m];
+    }
+}
+
+__global__ void __launch_bounds__(WAVE) gen_tgl_kernel(DevTensor Jr, RkArgs p, int64_t n_tg, double inverse,
+                                                       const double *__restrict__ w_in, double *__restrict__ w_out,
+                                                       double *__restrict__ rec, const double *__restrict__ stages,
+                                                       double *__restrict__ work, const double *__restrict__ dtime,
+                                                       const double *__restrict__ tab)
+{
+    const int64_t L = n_tg * p.ld;
+    const int64_t l = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (l >= L) return;
+    const int64_t m = l % p.ld;
+    if (m >= p.n_traj) return;
+    const int ndim = p.ndim, s = p.s;
+    const int64_t ld = p.ld, A = (int64_t)ndim * L, AS = (int64_t)ndim * ld;
+    double *v = work, *ws = work + A, *km = work + 2 * A;
+    const double *b = tab, *a = tab + s;
+    for (int d = 0; d < ndim; ++d) v[d * L + l] = w_in[d * L + l];
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (p.write_steps > 0 && (ti % p.write_steps) == 0) {
+            double *r = rec + rec_index(ti / p.write_steps, p.n_records, p.backward) * A + l;
+            for (int d = 0; d < ndim; ++d) r[d * L] = v[d * L + l];
+        }
+        for (int i = 0; i < s; ++i) {
+            for (int d = 0; d < ndim; ++d) {                              // km_s = fm + sum_j dt*a[i,j]*km[j]
+                double acc = v[d * L + l];
+                for (int j = 0; j < i; ++j) acc = __builtin_fma(dt * a[i * s + j], km[j * A + d * L + l], acc);
+                ws[d * L + l] = acc;
+            }
+            const double *x = stages + ((ti - p.step_begin) * s + i) * AS;
+            double *kmi = km + i * A;
+            for (int r = 1; r <= ndim; ++r) {                             // hom = inverse * (J or J^T) @ km_s
+                double acc = 0.0;
+                const int e1 = Jr.rowptr[r + 1];
+                for (int e = Jr.rowptr[r]; e < e1; ++e) {
+                    const uint32_t wx = Jr.idx[e];
+                    const uint32_t wi = wx >> 16, xi = wx & 0xffffu;
+                    const double xv = xi ? x[(int64_t)(xi - 1) * ld + m] : 1.0;
+                    acc = __builtin_fma(xv * ws[(int64_t)(wi - 1) * L + l], Jr.val[e], acc);
+                }
+                kmi[(int64_t)(r - 1) * L + l] = inverse * acc;
+            }
+        }
+        for (int d = 0; d < ndim; ++d) {                                  // fm += sum_j dt*b[j]*km[j]
+            double acc = v[d * L + l];
+            for (int j = 0; j < s; ++j) acc = __builtin_fma(dt * b[j], km[j * A + d * L + l], acc);
+            v[d * L + l] = acc;
+        }
+    }
+    if (w_out) for (int d = 0; d < ndim; ++d) w_out[d * L + l] = v[d * L + l];
+    if (p.write_final) {
+        double *r = rec + rec_index(p.n_records - 1, p.n_records, p.backward) * A + l;
+        for (int d = 0; d < ndim; ++d) r[d * L] = v[d * L + l];
+    }
+}
+
+// ---- layout conversion ----------------------------------------------------------------------
+// 64 members x 64 inner elements per block through an LDS tile so that both sides are coalesced.
+constexpr int TILE = 64;
+
+__global__ void __launch_bounds__(256) pack_kernel(int64_t n_inner, int64_t n_traj, int64_t ld,
+                                                   const double *__restrict__ rows, double *__restrict__ modes)
+{
+    __shared__ double tile[TILE][TILE + 1];
+    const int64_t m0 = (int64_t)blockIdx.x * TILE, q0 = (int64_t)blockIdx.y * TILE;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;           // 64 x 4
+    for (int r = ty; r < TILE; r += 4) {                              // read rows[m][q]: q fastest
+        const int64_t m = m0 + r, q = q0 + tx;
+        if (m < n_traj && q < n_inner) tile[r][tx] = rows[m * n_inner + q];
+    }
+    __syncthreads();
+    for (int r = ty; r < TILE; r += 4) {                              // write modes[q][m]: m fastest
+        const int64_t q = q0 + r, m = m0 + tx;
+        if (m < n_traj && q < n_inner) modes[q * ld + m] = tile[tx][r];
+    }
+}
+
+__global__ void __launch_bounds__(256) unpack_kernel(int64_t n_inner, int64_t n_traj, int64_t ld,
+                                                     const double *__restrict__ modes, double *__restrict__ rows)
+{
+    __shared__ double tile[TILE][TILE + 1];
+    const int64_t m0 = (int64_t)blockIdx.x * TILE, q0 = (int64_t)blockIdx.y * TILE;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < TILE; r += 4) {
+        const int64_t q = q0 + r, m = m0 + tx;
+        if (m < n_traj && q < n_inner) tile[r][tx] = modes[q * ld + m];
+    }
+    __syncthreads();
+    for (int r = ty; r < TILE; r += 4) {
+        const int64_t m = m0 + r, q = q0 + tx;
+        if (m < n_traj && q < n_inner) rows[m * n_inner + q] = tile[tx][r];
+    }
+}
+
+// in: R[n_records][n_inner][ld] -> out (n_traj, n_inner, n_records).  One thread per (member, q);
+// the record axis is innermost in the output, so each thread writes a contiguous run.
+__global__ void __launch_bounds__(256) unpack_records_kernel(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t n_records,
+                                                             const double *__restrict__ in, double *__restrict__ out)
+{
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y;
+    if (m >= n_traj) return;
+    double *o = out + (m * n_inner + q) * n_records;
+    const double *i = in + q * ld + m;
+    for (int64_t r = 0; r < n_records; ++r) o[r] = i[r * n_inner * ld];
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, const double *x, double *dx, hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_tend_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, T, ndim, n_traj, ld, x, dx);
+}
+
+void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, const double *x, double *jm, hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_jac_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, Jt, ndim, n_traj, ld, x, jm);
+}
+
+void launch_gen_rk(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
+                   double *work, const double *dtime, const double *tab_full, hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_rk_kernel, dim3(blocks_for(p.n_traj, WAVE)), dim3(WAVE), 0, st, T, p, y_in, y_out, rec, stages,
+                       work, dtime, tab_full);
+}
+
+void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double inverse, const double *w_in, double *w_out,
+                    double *rec, const double *stages, double *work, const double *dtime, const double *tab_full,
+                    hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_tgl_kernel, dim3(blocks_for(n_tg * p.ld, WAVE)), dim3(WAVE), 0, st, Jrow, p, n_tg, inverse, w_in,
+                       w_out, rec, stages, work, dtime, tab_full);
+}
+
+void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(ndim, TILE)), dim3(256), 0, st,
+                       (int64_t)ndim, n_traj, ld, rows, modes);
+}
+
+void launch_unpack_states(int ndim, int64_t n_traj, int64_t ld, const double *modes, double *rows, hipStream_t st)
+{
+    hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(ndim, TILE)), dim3(256), 0, st,
+                       (int64_t)ndim, n_traj, ld, modes, rows);
+}
+
+void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t n_records, const double *in, double *out,
+                           hipStream_t st)
+{
+    if (n_records == 1) {   // plain 2-D transpose
+        hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(n_inner, TILE)), dim3(256), 0, st,
+                           n_inner, n_traj, ld, in, out);
+        return;
+    }
+    hipLaunchKernelGGL(unpack_records_kernel, dim3(blocks_for(n_traj, 256), (unsigned)n_inner), dim3(256), 0, st, n_inner,
+                       n_traj, ld, n_records, in, out);
+}
+
+void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)
+{
+    const int64_t n_inner = (int64_t)ndim * n_tg;
+    hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(n_inner, TILE)), dim3(256), 0, st, n_inner,
+                       n_traj, ld, rows, modes);
+}
+
+}  // namespace qgs

@@ -1,0 +1,766 @@
+// qgs_hip_api.hip -- implementation of the C-ABI declared in include/qgs_hip.h.  gfx950 only.
+//
+// Host side of the MI355X path: stages the model tensors on the device, generates and compiles the
+// tensor-specialised kernels (codegen.cpp + hiprtc, cached on disk), owns the scratch buffers and
+// launches either the specialised or the generic kernels.  No CPU compute path exists here: every
+// entry point fails if no GPU is visible.
+#include "../../include/qgs_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "codegen.h"
+#include "generic_kernels.h"
+
+#ifndef QGS_SPEC_MAX_NDIM
+#define QGS_SPEC_MAX_NDIM 64      // register-resident specialised kernels up to this many variables
+#endif
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &msg)
+{
+    g_err = msg;
+    return -1;
+}
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess) {                                                                       \
+            std::ostringstream os__;                                                                   \
+            os__ << #expr << " failed: " << hipGetErrorString(e__) << " (" << __FILE__ << ":" << __LINE__ << ")"; \
+            return fail(os__.str());                                                                   \
+        }                                                                                              \
+    } while (0)
+
+uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull)
+{
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string lib_dir()
+{
+    Dl_info info;
+    if (dladdr((void *)&fnv1a, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t k = p.find_last_of('/');
+        return k == std::string::npos ? std::string(".") : p.substr(0, k);
+    }
+    return ".";
+}
+
+std::string cache_dir()
+{
+    const char *e = std::getenv("QGS_HIP_CACHE_DIR");
+    std::string d = e && *e ? std::string(e) : lib_dir() + "/kcache";
+    ::mkdir(d.c_str(), 0777);
+    return d;
+}
+
+std::string target_arch(int device)
+{
+    const char *e = std::getenv("QGS_HIP_ARCH");
+    if (e && *e) return e;
+    if (device >= 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+            std::string a(prop.gcnArchName);
+            size_t c = a.find(':');
+            return c == std::string::npos ? a : a.substr(0, c);
+        }
+    }
+    return "gfx950";
+}
+
+// source -> code object (hsaco), through the on-disk cache
+int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+{
+    std::string opts_key = arch + "|O3|c++17|v1";
+    char name[64];
+    std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
+    const std::string path = cache_dir() + "/" + name + ".hsaco";
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (f) {
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code.empty()) { if (from_cache) *from_cache = true; return 0; }
+        }
+    }
+    if (from_cache) *from_cache = false;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "qgs_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
+        return fail("hiprtcCreateProgram failed");
+    const std::string archopt = "--offload-arch=" + arch;
+    const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
+    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(std::string("hiprtc compile failed: ") + hiprtcGetErrorString(r) + "\n" + log.substr(0, 4000));
+    }
+    size_t n = 0;
+    hiprtcGetCodeSize(prog, &n);
+    code.resize(n);
+    hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    {   // atomic publish into the cache
+        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+        std::ofstream f(tmp, std::ios::binary);
+        if (f) {
+            f.write(code.data(), (std::streamsize)code.size());
+            f.close();
+            std::rename(tmp.c_str(), path.c_str());
+        }
+    }
+    return 0;
+}
+
+struct HostCsr {          // row-grouped tensor on the host, see generic_kernels.h DevTensor
+    std::vector<int32_t> rowptr;
+    std::vector<uint32_t> idx;
+    std::vector<double> val;
+};
+
+// group entries by `row(t)`, keep the incoming (reference) order inside a row
+template <class RowFn, class IdxFn>
+HostCsr build_csr(int ndim, const std::vector<qgs::Term> &ts, RowFn row, IdxFn idx)
+{
+    HostCsr c;
+    c.rowptr.assign(ndim + 2, 0);
+    for (const auto &t : ts) c.rowptr[row(t) + 1]++;
+    for (int i = 0; i <= ndim; ++i) c.rowptr[i + 1] += c.rowptr[i];
+    c.idx.resize(ts.size());
+    c.val.resize(ts.size());
+    std::vector<int32_t> pos(c.rowptr.begin(), c.rowptr.end() - 1);
+    for (const auto &t : ts) {
+        int p = pos[row(t)]++;
+        c.idx[p] = idx(t);
+        c.val[p] = t.v;
+    }
+    return c;
+}
+
+struct DevCsr {
+    int32_t *rowptr = nullptr;
+    uint32_t *idx = nullptr;
+    double *val = nullptr;
+    qgs::DevTensor view() const { return qgs::DevTensor{rowptr, idx, val}; }
+};
+
+struct Buffer {           // grow-only device scratch
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) return fail("hipMalloc of " + std::to_string(bytes) + " bytes failed");
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    double *f64() const { return (double *)p; }
+};
+
+struct KernelInfo {
+    std::string name;
+    int vgprs = 0, sgprs = 0, lds = 0, scratch = 0;
+};
+
+}  // namespace
+
+struct qgs_model {
+    int device = 0;
+    int ndim = 0;
+    std::string arch;
+    std::vector<qgs::Term> T, J;
+    DevCsr dT, dJ_by_i, dJ_by_j;
+    int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
+    bool spec_possible = false;
+    qgs::CodegenOptions cg;
+    // compiled specialised modules: key 0 = base (tend, jac), key S = S-stage steppers
+    std::map<int, hipModule_t> modules;
+    std::map<std::string, hipFunction_t> functions;
+    std::string source_all;
+    // staged time grid / tableau
+    Buffer d_time, d_tab;
+    std::vector<double> h_time, h_tab;
+    // scratch
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2;
+    KernelInfo last;
+};
+
+namespace {
+
+int upload_csr(const HostCsr &h, DevCsr &d)
+{
+    HIPCHK(hipMalloc((void **)&d.rowptr, sizeof(int32_t) * h.rowptr.size()));
+    HIPCHK(hipMalloc((void **)&d.idx, sizeof(uint32_t) * std::max<size_t>(1, h.idx.size())));
+    HIPCHK(hipMalloc((void **)&d.val, sizeof(double) * std::max<size_t>(1, h.val.size())));
+    HIPCHK(hipMemcpy(d.rowptr, h.rowptr.data(), sizeof(int32_t) * h.rowptr.size(), hipMemcpyHostToDevice));
+    if (!h.idx.empty()) {
+        HIPCHK(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+void free_csr(DevCsr &d)
+{
+    if (d.rowptr) (void)hipFree(d.rowptr);
+    if (d.idx) (void)hipFree(d.idx);
+    if (d.val) (void)hipFree(d.val);
+    d = DevCsr();
+}
+
+std::string module_source(const qgs_model *m, int S)
+{
+    // S == 0: tendencies + Jacobian; S > 0: the S-stage steppers
+    std::vector<int> stages;
+    if (S > 0) stages.push_back(S);
+    return qgs::generate_source(m->ndim, S == 0 ? m->T : m->T, m->J, stages, m->cg);
+}
+
+// Make sure the module holding `fname` (for S stages, 0 = base) is compiled and loaded.
+int get_function(qgs_model *m, int S, const std::string &fname, hipFunction_t *fn)
+{
+    auto it = m->functions.find(fname);
+    if (it != m->functions.end()) { *fn = it->second; return 0; }
+    if (!m->modules.count(S)) {
+        std::string src = module_source(m, S);
+        if (S > 0) {   // the stepper modules do not need another copy of tend/jac: strip them by regenerating
+            // (generate_source always emits tend/jac first; they are small, keep them: simpler and harmless)
+        }
+        std::vector<char> code;
+        bool cached = false;
+        if (compile_source(src, m->arch, code, &cached)) return -1;
+        hipModule_t mod;
+        HIPCHK(hipModuleLoadData(&mod, code.data()));
+        m->modules[S] = mod;
+        m->source_all += src;
+    }
+    hipFunction_t f;
+    hipError_t e = hipModuleGetFunction(&f, m->modules[S], fname.c_str());
+    if (e != hipSuccess) return fail("kernel " + fname + " not found in the specialised module: " + hipGetErrorString(e));
+    m->functions[fname] = f;
+    *fn = f;
+    return 0;
+}
+
+void note_kernel(qgs_model *m, const std::string &name, hipFunction_t f)
+{
+    m->last.name = name;
+    if (f) {
+        int v = 0;
+        if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, f) == hipSuccess) m->last.vgprs = v;
+        if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f) == hipSuccess) m->last.lds = v;
+        if (hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, f) == hipSuccess) m->last.scratch = v;
+        m->last.sgprs = 0;
+    } else {
+        m->last.vgprs = m->last.sgprs = m->last.lds = m->last.scratch = 0;
+    }
+}
+
+int launch(hipFunction_t f, int64_t lanes, hipStream_t st, void **args)
+{
+    const unsigned blocks = (unsigned)((lanes + 63) / 64);
+    HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    return 0;
+}
+
+// Stage the directed time grid (integrate.py:199-202) and the tableau on the device; both are cached.
+//   tab layout: [ b[s], a_sub[s-1] | b[s], a[s*s] ]   (specialised part first, generic part after it)
+int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int direction, int s, const double *b,
+                   const double *a, hipStream_t st, const double **d_time, const double **d_tab_spec,
+                   const double **d_tab_full)
+{
+    std::vector<double> dt(time, time + n_time);
+    if (direction == -1) std::reverse(dt.begin(), dt.end());
+    if (dt != m->h_time) {
+        if (m->d_time.ensure(sizeof(double) * (size_t)n_time)) return -1;
+        HIPCHK(hipMemcpyAsync(m->d_time.p, dt.data(), sizeof(double) * (size_t)n_time, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        m->h_time.swap(dt);
+    }
+    std::vector<double> tab;
+    tab.insert(tab.end(), b, b + s);
+    for (int i = 1; i < s; ++i) tab.push_back(a[i * s + (i - 1)]);
+    tab.insert(tab.end(), b, b + s);
+    tab.insert(tab.end(), a, a + (size_t)s * s);
+    if (tab != m->h_tab) {
+        if (m->d_tab.ensure(sizeof(double) * tab.size())) return -1;
+        HIPCHK(hipMemcpyAsync(m->d_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        m->h_tab.swap(tab);
+    }
+    *d_time = m->d_time.f64();
+    *d_tab_spec = m->d_tab.f64();
+    *d_tab_full = m->d_tab.f64() + (2 * s - 1);
+    return 0;
+}
+
+bool use_spec(const qgs_model *m, int s, const double *a)
+{
+    if (m->kernel_kind == 1) return false;
+    if (!m->spec_possible) return false;
+    if (s < 1 || s > 8) return false;
+    return a == nullptr || qgs::tableau_is_subdiagonal(s, a);
+}
+
+int check_common(const qgs_model *m, int64_t n_traj, int64_t ld)
+{
+    if (!m) return fail("null model");
+    if (n_traj < 1) return fail("n_traj must be >= 1");
+    if (ld < n_traj || (ld % 64) != 0) return fail("ld must be >= n_traj and a multiple of 64");
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *qgs_last_error(void) { return g_err.c_str(); }
+
+int qgs_backend_info(int *n_devices, char *arch_buf, int buflen)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n < 1) {
+        if (n_devices) *n_devices = 0;
+        return fail(std::string("no HIP device visible (") + (e == hipSuccess ? "count 0" : hipGetErrorString(e)) +
+                    "); libqgs_hip has no CPU path");
+    }
+    if (n_devices) *n_devices = n;
+    if (arch_buf && buflen > 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, 0));
+        std::snprintf(arch_buf, (size_t)buflen, "%s", prop.gcnArchName);
+    }
+    return 0;
+}
+
+int64_t qgs_n_records(const double *time, int64_t n_time, int64_t write_steps)
+{
+    if (write_steps == 0 || n_time < 1) return 1;                 // integrate.py:190-191
+    int64_t n = (n_time + write_steps - 1) / write_steps;         // len(time[::write_steps])
+    if (time[(n - 1) * write_steps] != time[n_time - 1]) n += 1;  // :195-196
+    return n;
+}
+
+int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz,
+                     const int32_t *jcoo, const double *jval, qgs_model **out)
+{
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (ndim < 1 || ndim > 65534) return fail("ndim out of range");
+    if (nnz < 0 || (nnz > 0 && (!coo || !val))) return fail("bad tensor arguments");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail("no HIP device visible; libqgs_hip has no CPU path");
+    if (device < 0 || device >= n) return fail("device index out of range");
+    HIPCHK(hipSetDevice(device));
+    qgs_model *m = new qgs_model();
+    m->device = device;
+    m->ndim = ndim;
+    m->arch = target_arch(device);
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int i = coo[3 * e], j = coo[3 * e + 1], k = coo[3 * e + 2];
+        if (i < 0 || j < 0 || k < 0 || i > ndim || j > ndim || k > ndim) { delete m; return fail("tensor coordinate out of range"); }
+        m->T.push_back({i, j, k, val[e]});
+    }
+    for (int64_t e = 0; e < jnnz; ++e) {
+        const int i = jcoo[3 * e], j = jcoo[3 * e + 1], k = jcoo[3 * e + 2];
+        if (i < 0 || j < 0 || k < 0 || i > ndim || j > ndim || k > ndim) { delete m; return fail("jacobian coordinate out of range"); }
+        m->J.push_back({i, j, k, jval[e]});
+    }
+    // generic-kernel tensors (row 0 entries are kept out: res[0] = 1 is the constant slot)
+    std::vector<qgs::Term> Tr, Jr;
+    for (const auto &t : m->T) if (t.i >= 1) Tr.push_back(t);
+    for (const auto &t : m->J) if (t.i >= 1 && t.j >= 1) Jr.push_back(t);
+    auto pack = [](int a, int b) { return ((uint32_t)a << 16) | (uint32_t)b; };
+    HostCsr hT = build_csr(ndim, Tr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
+    // Jacobian kernel wants (j,k) per row i; tangent model wants (w=j, x=k) per row i; adjoint (w=i, x=k) per row j
+    HostCsr hJi = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
+    HostCsr hJj = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.j; }, [&](const qgs::Term &t) { return pack(t.i, t.k); });
+    if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
+    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM);
+    const char *nogroup = std::getenv("QGS_HIP_NO_GROUP");
+    if (nogroup && *nogroup == '1') m->cg.group_coeff = false;
+    *out = m;
+    return 0;
+}
+
+int qgs_model_destroy(qgs_model *m)
+{
+    if (!m) return 0;
+    (void)hipSetDevice(m->device);
+    for (auto &kv : m->modules) (void)hipModuleUnload(kv.second);
+    free_csr(m->dT); free_csr(m->dJ_by_i); free_csr(m->dJ_by_j);
+    for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2})
+        b->release();
+    delete m;
+    return 0;
+}
+
+int64_t qgs_model_info(const qgs_model *m, int which)
+{
+    if (!m) return -1;
+    switch (which) {
+    case 0: return m->ndim;
+    case 1: return (int64_t)m->T.size();
+    case 2: return (int64_t)m->J.size();
+    case 3: return m->device;
+    case 4: return m->spec_possible ? 1 : 0;
+    default: return -1;
+    }
+}
+
+int qgs_model_set_kernel(qgs_model *m, int kind)
+{
+    if (!m) return fail("null model");
+    if (kind < 0 || kind > 2) return fail("kind must be 0, 1 or 2");
+    if (kind == 2 && !m->spec_possible) return fail("specialised kernels are not available for this ndim");
+    m->kernel_kind = kind;
+    return 0;
+}
+
+int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen, int *vgprs, int *sgprs, int *lds_bytes,
+                         int *scratch_bytes)
+{
+    if (!m) return fail("null model");
+    if (name_buf && buflen > 0) std::snprintf(name_buf, (size_t)buflen, "%s", m->last.name.c_str());
+    if (vgprs) *vgprs = m->last.vgprs;
+    if (sgprs) *sgprs = m->last.sgprs;
+    if (lds_bytes) *lds_bytes = m->last.lds;
+    if (scratch_bytes) *scratch_bytes = m->last.scratch;
+    return 0;
+}
+
+int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen)
+{
+    if (!m) return -1;
+    std::string src = m->source_all;
+    if (src.empty() && m->spec_possible) src = module_source(m, 0);
+    if (buf && buflen > 0) {
+        const size_t n = std::min<size_t>(src.size(), (size_t)buflen - 1);
+        std::memcpy(buf, src.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)src.size();
+}
+
+// ---- device-layout entry points ---------------------------------------------------------------
+
+int qgs_pack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_rows, double *d_modes, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_pack_states(m->ndim, n_traj, ld, d_rows, d_modes, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_unpack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_modes, double *d_rows, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_unpack_states(m->ndim, n_traj, ld, d_modes, d_rows, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records, const double *d_in,
+                       double *d_out, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_inner < 1 || n_inner > 65535 || n_records < 1) return fail("bad n_inner / n_records");
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_unpack_records(n_inner, n_traj, ld, n_records, d_in, d_out, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x, double *d_dx, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (use_spec(m, 1, nullptr)) {
+        hipFunction_t f;
+        if (get_function(m, 0, "qgs_spec_tend", &f)) return -1;
+        long long nt = n_traj, l = ld;
+        void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
+        note_kernel(m, "qgs_spec_tend", f);
+        return launch(f, n_traj, st, args);
+    }
+    qgs::launch_gen_tend(m->dT.view(), m->ndim, n_traj, ld, d_x, d_dx, st);
+    note_kernel(m, "gen_tend_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+static int jacobian_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x, double *d_jm, hipStream_t st)
+{
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    HIPCHK(hipMemsetAsync(d_jm, 0, sizeof(double) * (size_t)m->ndim * m->ndim * ld, st));
+    if (use_spec(m, 1, nullptr)) {
+        hipFunction_t f;
+        if (get_function(m, 0, "qgs_spec_jac", &f)) return -1;
+        long long nt = n_traj, l = ld;
+        void *args[] = {(void *)&d_x, (void *)&d_jm, &nt, &l};
+        note_kernel(m, "qgs_spec_jac", f);
+        return launch(f, n_traj, st, args);
+    }
+    qgs::launch_gen_jac(m->dJ_by_i.view(), m->ndim, n_traj, ld, d_x, d_jm, st);
+    note_kernel(m, "gen_jac_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_ic, const double *time,
+                            int64_t n_time, int time_direction, int64_t write_steps, int s, const double *b,
+                            const double *c, const double *a, double *d_rec, void *stream)
+{
+    (void)c;   // autonomous system: f ignores t (tendencies.py:112)
+    if (check_common(m, n_traj, ld)) return -1;
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const int backward = time_direction == -1;
+    if (use_spec(m, s, a)) {
+        hipFunction_t f;
+        const std::string name = "qgs_spec_rk_s" + std::to_string(s);
+        if (get_function(m, s, name, &f)) return -1;
+        double *y_out = nullptr, *stg = nullptr;
+        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
+        int bw = backward, wf = 1;
+        void *args[] = {(void *)&d_ic, &y_out, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_spec,
+                        &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+        note_kernel(m, name, f);
+        return launch(f, n_traj, st, args);
+    }
+    if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * ld)) return -1;
+    qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
+    qgs::launch_gen_rk(m->dT.view(), p, d_ic, nullptr, d_rec, nullptr, m->work.f64(), d_time, d_tab_full, st);
+    note_kernel(m, "gen_rk_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_ic,
+                                 const double *d_tg_ic, const double *time, int64_t n_time, int time_direction,
+                                 int64_t write_steps, int s, const double *b, const double *c, const double *a,
+                                 int adjoint, double inverse, double *d_rec, double *d_rec_fm, void *stream)
+{
+    (void)c;
+    if (check_common(m, n_traj, ld)) return -1;
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    if (n_tg < 1) return fail("n_tg must be >= 1");
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const int backward = time_direction == -1;
+    const int64_t n_steps = n_time - 1;
+    const int64_t A = (int64_t)m->ndim * ld, L = n_tg * ld;
+    const bool spec = use_spec(m, s, a);
+
+    // The reference pre-writes record 0 with the initial conditions (integrate.py:581-582); with at least
+    // one step that record is rewritten by the loop, with zero steps the final record covers it.
+    // Steps are processed in chunks: trajectory kernel (stores every stage state) -> tangent kernel.
+    const size_t stage_bytes_per_step = sizeof(double) * (size_t)s * A;
+    int64_t chunk = std::max<int64_t>(1, (int64_t)((size_t)768 << 20) / (int64_t)stage_bytes_per_step);
+    if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(e));
+    chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, n_steps));
+    if (m->stages.ensure(stage_bytes_per_step * (size_t)chunk)) return -1;
+    if (m->b_state2.ensure(sizeof(double) * (size_t)A)) return -1;
+    if (m->b_tg2.ensure(sizeof(double) * (size_t)m->ndim * L)) return -1;
+    if (!spec) {
+        if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * std::max<int64_t>(ld, L))) return -1;
+    }
+    double *y_state = m->b_state2.f64();
+    double *w_state = m->b_tg2.f64();
+    double *stages = m->stages.f64();
+    const qgs::DevTensor Jrow = adjoint ? m->dJ_by_j.view() : m->dJ_by_i.view();
+
+    int64_t begin = 0;
+    bool first = true;
+    do {
+        const int64_t end = std::min(n_steps, begin + chunk);
+        const int final_chunk = (end == n_steps);
+        const double *y_src = first ? d_ic : y_state;
+        const double *w_src = first ? d_tg_ic : w_state;
+        if (spec) {
+            hipFunction_t f1, f2;
+            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s), n2 = "qgs_spec_tgl_s" + std::to_string(s);
+            if (get_function(m, s, n1, &f1) || get_function(m, s, n2, &f2)) return -1;
+            long long nt = n_traj, l = ld, sb = begin, se = end, ws = write_steps, nr = n_records, ntg = n_tg;
+            int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
+            double inv = inverse;
+            void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
+                          &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+            if (launch(f1, n_traj, st, a1)) return -1;
+            void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
+                          &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
+            note_kernel(m, n2, f2);
+            if (launch(f2, L, st, a2)) return -1;
+        } else {
+            qgs::RkArgs p{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
+            qgs::launch_gen_rk(m->dT.view(), p, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
+            qgs::launch_gen_tgl(Jrow, p, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);
+            note_kernel(m, "gen_tgl_kernel", nullptr);
+            HIPCHK(hipGetLastError());
+        }
+        begin = end;
+        first = false;
+    } while (begin < n_steps);
+    return 0;
+}
+
+// ---- host-layout entry points -------------------------------------------------------------------
+
+static int64_t round_ld(int64_t n) { return (n + 63) / 64 * 64; }
+
+int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx)
+{
+    if (!m || !x || !dx || n_traj < 1) return fail("bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    const int64_t ld = round_ld(n_traj);
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b)) return -1;
+    HIPCHK(hipMemcpy(m->b_in_rows.p, x, rows_b, hipMemcpyHostToDevice));
+    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
+    if (qgs_tendencies_device(m, n_traj, ld, m->b_in_modes.f64(), m->b_rec_modes.f64(), nullptr)) return -1;
+    if (qgs_unpack_states(m, n_traj, ld, m->b_rec_modes.f64(), m->b_in_rows.f64(), nullptr)) return -1;
+    HIPCHK(hipMemcpy(dx, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac)
+{
+    if (!m || !x || !jac || n_traj < 1) return fail("bad arguments");
+    HIPCHK(hipSetDevice(m->device));
+    const int64_t ld = round_ld(n_traj), nn = (int64_t)m->ndim * m->ndim;
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    const size_t jm_b = sizeof(double) * (size_t)ld * nn, jr_b = sizeof(double) * (size_t)n_traj * nn;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_fm_modes.ensure(jm_b) || m->b_fm_rows.ensure(jr_b)) return -1;
+    HIPCHK(hipMemcpy(m->b_in_rows.p, x, rows_b, hipMemcpyHostToDevice));
+    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
+    if (jacobian_device(m, n_traj, ld, m->b_in_modes.f64(), m->b_fm_modes.f64(), nullptr)) return -1;
+    qgs::launch_unpack_records(nn, n_traj, ld, 1, m->b_fm_modes.f64(), m->b_fm_rows.f64(), nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(jac, m->b_fm_rows.p, jr_b, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
+                     int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
+                     double *traj)
+{
+    if (!m || !ic || !traj || n_traj < 1) return fail("bad arguments");
+    if (!time || n_time < 1) return fail("bad time grid");
+    HIPCHK(hipSetDevice(m->device));
+    const int64_t ld = round_ld(n_traj);
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
+        m->b_rec_rows.ensure(rows_b * (size_t)n_records)) return -1;
+    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
+    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
+    if (qgs_rk_integrate_device(m, n_traj, ld, m->b_in_modes.f64(), time, n_time, time_direction, write_steps, s, b, c, a,
+                                m->b_rec_modes.f64(), nullptr)) return -1;
+    if (qgs_unpack_records(m, n_traj, ld, m->ndim, n_records, m->b_rec_modes.f64(), m->b_rec_rows.f64(), nullptr)) return -1;
+    HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                          const double *time, int64_t n_time, int time_direction, int64_t write_steps, int s,
+                          const double *b, const double *c, const double *a, int adjoint, double inverse, double *traj,
+                          double *fmatrix)
+{
+    if (!m || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
+    if (!time || n_time < 1) return fail("bad time grid");
+    if ((int64_t)m->ndim * n_tg > 65535) return fail("ndim * n_tg > 65535 is not supported by the record unpack kernel");
+    HIPCHK(hipSetDevice(m->device));
+    const int64_t ld = round_ld(n_traj);
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    const size_t tg_rows_b = rows_b * (size_t)n_tg, tg_modes_b = modes_b * (size_t)n_tg;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
+        m->b_rec_rows.ensure(rows_b * (size_t)n_records) || m->b_tg_rows.ensure(tg_rows_b) || m->b_tg_modes.ensure(tg_modes_b) ||
+        m->b_fm_modes.ensure(tg_modes_b * (size_t)n_records) || m->b_fm_rows.ensure(tg_rows_b * (size_t)n_records)) return -1;
+    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->b_tg_rows.p, tg_ic, tg_rows_b, hipMemcpyHostToDevice));
+    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
+    qgs::launch_pack_tangent(m->ndim, n_tg, n_traj, ld, m->b_tg_rows.f64(), m->b_tg_modes.f64(), nullptr);
+    HIPCHK(hipGetLastError());
+    // padding lanes of the tangent state are read (never stored) by the specialised kernel: define them
+    if (qgs_rk_tgls_integrate_device(m, n_traj, ld, n_tg, m->b_in_modes.f64(), m->b_tg_modes.f64(), time, n_time,
+                                     time_direction, write_steps, s, b, c, a, adjoint, inverse, m->b_rec_modes.f64(),
+                                     m->b_fm_modes.f64(), nullptr)) return -1;
+    if (qgs_unpack_records(m, n_traj, ld, m->ndim, n_records, m->b_rec_modes.f64(), m->b_rec_rows.f64(), nullptr)) return -1;
+    if (qgs_unpack_records(m, n_traj, ld, (int64_t)m->ndim * n_tg, n_records, m->b_fm_modes.f64(), m->b_fm_rows.f64(), nullptr)) return -1;
+    HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fmatrix, m->b_fm_rows.p, tg_rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Compile (and cache) the specialised kernels of a model without touching a device: used by
+// __graft_entry__.build() on the GPU-less build host so that the code objects travel with the tree.
+int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
+                 const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
+{
+    if (ndim > QGS_SPEC_MAX_NDIM) return 0;
+    qgs_model m;
+    m.ndim = ndim;
+    m.arch = (arch && *arch) ? arch : target_arch(-1);
+    for (int64_t e = 0; e < nnz; ++e) m.T.push_back({coo[3 * e], coo[3 * e + 1], coo[3 * e + 2], val[e]});
+    for (int64_t e = 0; e < jnnz; ++e) m.J.push_back({jcoo[3 * e], jcoo[3 * e + 1], jcoo[3 * e + 2], jval[e]});
+    const char *nogroup = std::getenv("QGS_HIP_NO_GROUP");
+    if (nogroup && *nogroup == '1') m.cg.group_coeff = false;
+    std::vector<int> all = {0};
+    for (int i = 0; i < n_stage_counts; ++i) all.push_back(stage_counts[i]);
+    for (int S : all) {
+        std::vector<char> code;
+        bool cached;
+        if (compile_source(module_source(&m, S), m.arch, code, &cached)) return -1;
+    }
+    return 0;
+}
+
+}  // extern "C"
