@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/qgs_hip.h declares, and the
+ctypes table in qgs_amd/_lib.py names exactly those symbols.  No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+
+def _header_symbols():
+    src = open(os.path.join(REPO, 'include', 'qgs_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(qgs_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_header_declares_something():
+    syms = _header_symbols()
+    assert 'qgs_rk_integrate' in syms and 'qgs_tendencies' in syms and len(syms) >= 15
+
+
+def test_library_exports_every_header_symbol():
+    from qgs_amd import _lib
+    _lib.build_library()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for s in _header_symbols():
+        assert hasattr(L, s), 'libqgs_hip.so does not export ' + s
+
+
+def test_ctypes_table_matches_header():
+    from qgs_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _header_symbols()
+
+
+def test_n_records_host_helper():
+    from qgs_amd import _lib
+    t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
+    assert _lib.n_records(t, 0) == 1
+    assert _lib.n_records(t, 1) == 11
+    assert _lib.n_records(t, 3) == 5
+    assert _lib.n_records(t, 5) == 3
+    assert _lib.n_records(t[:1], 1) == 1
+
+
+def test_fails_loudly_without_gpu():
+    """On a GPU-less host every numerical entry point must raise, never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    from qgs_amd import _lib
+    with pytest.raises(_lib.QgsHipError):
+        _lib.backend_info()
+    with pytest.raises(_lib.QgsHipError):
+        _lib.HipModel(2, np.array([[1, 0, 1]], dtype=np.int32), np.array([1.0]))
+
+
+def test_prebuild_generates_code_objects(tmp_path, monkeypatch):
+    """hiprtc cross-compiles the tensor-specialised kernels for gfx950 without a GPU."""
+    from qgs_amd import _lib
+    monkeypatch.setenv('QGS_HIP_CACHE_DIR', str(tmp_path))
+    coo = np.array([[1, 0, 1], [1, 1, 2], [2, 0, 0], [2, 1, 1]], dtype=np.int32)
+    val = np.array([-0.5, 2.0, 0.25, -1.0])
+    jcoo = np.array([[1, 1, 0], [1, 1, 2], [1, 2, 1], [2, 1, 1]], dtype=np.int32)
+    jval = np.array([-0.5, 2.0, 2.0, -2.0])
+    _lib.prebuild(2, coo, val, jcoo, jval, stage_counts=(2,))
+    objs = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
+    assert len(objs) == 2          # base module (f, Df) + the 2-stage stepper module
+    assert all(os.path.getsize(os.path.join(tmp_path, f)) > 1000 for f in objs)
+
+
+def test_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under qgs_amd/ may import, load or reference it."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, 'qgs_amd')):
+        for fn in files:
+            if fn.endswith(('.py', '.cpp', '.hip', '.h')):
+                txt = open(os.path.join(root, fn), errors='replace').read()
+                if re.search(r'(^|\W)(import\s+oracle|from\s+oracle|libqgs_oracle|oracle/)', txt):
+                    bad.append(os.path.join(root, fn))
+    assert not bad, bad

@@ -1,0 +1,178 @@
+"""GPU: parity of the HIP path (through the C-ABI) against the goldens captured from the Python
+reference and against the CPU oracle on seeded inputs.
+
+Tolerances (fp64; the HIP kernels use FMA and a different summation order than the reference):
+  f, Df                      |d| <= 1e-14 * max|ref|
+  trajectories <= 100 steps  1e-12 relative
+  trajectories 1000 steps    1e-10 relative (weakly chaotic amplification of rounding differences)
+  tangent / adjoint 10 steps 1e-11 relative
+"""
+import numpy as np
+import pytest
+
+from conftest import RK4, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+KINDS = {'generic': 1, 'specialised': 2}
+
+
+@pytest.fixture(scope='module')
+def models():
+    from qgs_amd import _lib
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            g = load_golden(name)
+            cache[name] = _lib.HipModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+        return cache[name]
+    yield get
+    for m in cache.values():
+        m.close()
+
+
+def _kinds(model):
+    return [k for k in KINDS if k == 'generic' or model.specialised_available]
+
+
+def test_backend_is_gfx950():
+    from qgs_amd import _lib
+    n, arch = _lib.backend_info()
+    assert n >= 1 and arch.startswith('gfx950'), arch
+
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228'])
+def test_f_and_Df_vs_golden(models, name):
+    g, m = load_golden(name), models(name)
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        assert rel_err(m.tendencies(g['fx_x']), g['fx_f']) < 1e-14, kind
+        n = g['fx_Df'].shape[0]
+        assert rel_err(m.jacobian(g['fx_x'][:n]), g['fx_Df']) < 1e-14, kind
+        # single-state call keeps the reference's shapes
+        assert m.tendencies(g['fx_x'][0]).shape == (g.ndim,)
+        assert m.jacobian(g['fx_x'][0]).shape == (g.ndim, g.ndim)
+
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228'])
+def test_rk_cases_vs_golden(models, name):
+    g, m = load_golden(name), models(name)
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        for cs in g.meta['rk_cases']:
+            t = cs['tag']
+            ic = g['rk_ic'][:cs['n_traj']]
+            rec = m.rk_integrate(g['rk_%s_time' % t], ic, 1 if cs['forward'] else -1, cs['ws'], g['rk_%s_b' % t],
+                                 g['rk_%s_c' % t], g['rk_%s_a' % t])
+            tol = 1e-10 if cs['steps'] >= 1000 else 1e-12
+            assert rel_err(rec, g['rk_%s_traj' % t]) < tol, (kind, t)
+
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228'])
+def test_tgls_cases_vs_golden(models, name):
+    g, m = load_golden(name), models(name)
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        for cs in g.meta['tgls_cases']:
+            t = cs['tag']
+            rec, fm = m.rk_tgls_integrate(g['tgls_%s_time' % t], g['tgls_ic'], g['tgls_%s_tgic' % t],
+                                          1 if cs['forward'] else -1, cs['ws'], g['tgls_%s_b' % t], g['tgls_%s_c' % t],
+                                          g['tgls_%s_a' % t], cs['adjoint'], -1. if cs['inverse'] else 1.)
+            assert rel_err(rec, g['tgls_%s_traj' % t]) < 1e-11, (kind, t)
+            assert rel_err(fm, g['tgls_%s_fm' % t]) < 1e-11, (kind, t)
+
+
+@pytest.mark.parametrize('n_traj', [1, 63, 64, 65, 1000])
+def test_ragged_ensemble_sizes_vs_oracle(models, n_traj):
+    """Wavefront tails: member counts around the 64-lane boundary."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden('m36'), models('m36')
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = np.random.RandomState(n_traj).rand(n_traj, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 2.0, 0.1), [2.0]))
+    ref = ora.integrate_runge_kutta_jit(t, ic, 1, 7, RK4['b'], RK4['c'], RK4['a'], threads=4)
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14
+        assert rel_err(m.rk_integrate(t, ic, 1, 7, RK4['b'], RK4['c'], RK4['a']), ref) < 1e-12, kind
+
+
+def test_zero_steps_and_single_step(models):
+    """n_time == 1 (no step): the only record is the initial condition (integrate.py:221)."""
+    g, m = load_golden('a36'), models('a36')
+    ic = g['rk_ic']
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        for ws in (0, 1, 4):
+            rec = m.rk_integrate(np.array([0.]), ic, 1, ws, RK4['b'], RK4['c'], RK4['a'])
+            assert rec.shape == (ic.shape[0], g.ndim, 1) and np.array_equal(rec[:, :, 0], ic)
+
+
+def test_tgls_chunked_equals_unchunked(models, monkeypatch):
+    """The stage-state buffer is processed in chunks of steps; chunking must not change the result."""
+    g, m = load_golden('m36'), models('m36')
+    ic = g['rk_ic'][:5]
+    tg = np.random.RandomState(3).randn(5, g.ndim, 3)
+    t = np.concatenate((np.arange(0., 2.3, 0.1), [2.3]))
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        monkeypatch.delenv('QGS_HIP_TGLS_CHUNK', raising=False)
+        a_tr, a_fm = m.rk_tgls_integrate(t, ic, tg, 1, 4, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        monkeypatch.setenv('QGS_HIP_TGLS_CHUNK', '5')
+        b_tr, b_fm = m.rk_tgls_integrate(t, ic, tg, 1, 4, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        assert np.array_equal(a_tr, b_tr) and np.array_equal(a_fm, b_fm), kind
+
+
+def test_specialised_equals_generic_long_run(models):
+    """Two independent HIP implementations agree on a 2000-step run of 4096 members."""
+    g, m = load_golden('m36'), models('m36')
+    ic = np.random.RandomState(5).rand(4096, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 200.0, 0.1), [200.0]))[:2001]
+    m.set_kernel(1)
+    a = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])
+    m.set_kernel(2)
+    b = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])
+    assert rel_err(a, b) < 1e-9
+
+
+def test_full_size_properties(models):
+    """BASELINE config 2 size (65 536 members): size-independent properties.
+
+    (1) the ensemble result is independent of the batch composition: any member integrated alone or inside
+        the full batch gives bitwise the same answer (members never interact);
+    (2) time reversal: integrating forward then backward over the same grid returns to the initial state
+        to O(dt^4) truncation, well inside 1e-6 for 50 steps;
+    (3) a sample of members agrees with the CPU oracle.
+    """
+    from oracle.oracle import OracleModel
+    g, m = load_golden('m36'), models('m36')
+    m.set_kernel(0)
+    n = 65536
+    ic = np.random.RandomState(21217).rand(n, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 5.0, 0.1), [5.0]))
+    full = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert np.isfinite(full).all()
+    pick = np.array([0, 1, 63, 64, 4097, 32768, 65535])
+    alone = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert np.array_equal(alone, full[pick])
+    back = m.rk_integrate(t, full, -1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert np.abs(back - ic).max() < 1e-6
+    ora = OracleModel(g.ndim, g['coo'], g['val'])
+    ref = ora.integrate_runge_kutta_jit(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert rel_err(alone, ref) < 1e-12
+
+
+def test_linearity_of_tangent_model(models):
+    """TL(a*u + b*v) = a*TL(u) + b*TL(v) along the same trajectory (columns are independent lanes)."""
+    g, m = load_golden('m36'), models('m36')
+    rng = np.random.RandomState(11)
+    ic = g['rk_ic'][:4]
+    u, v = rng.randn(4, g.ndim, 1), rng.randn(4, g.ndim, 1)
+    tg = np.concatenate((u, v, 2.0 * u - 3.0 * v), axis=2)
+    t = np.concatenate((np.arange(0., 1.0, 0.1), [1.0]))
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        _, fm = m.rk_tgls_integrate(t, ic, tg, 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        fm = fm[..., 0]
+        assert rel_err(fm[:, :, 2], 2.0 * fm[:, :, 0] - 3.0 * fm[:, :, 1]) < 1e-13, kind
