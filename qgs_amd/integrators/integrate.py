@@ -1,0 +1,141 @@
+"""Functional integration API (reference: qgs/integrators/integrate.py).
+
+`integrate_runge_kutta` / `integrate_runge_kutta_tgls` keep the reference's signatures and output
+conventions (integrate.py:29-179, 240-552); the stepping itself (the reference's
+`_integrate_runge_kutta_jit` / `_integrate_runge_kutta_tgls_jit`, integrate.py:182-223, 555-614) runs on
+the GPU through `qgs_rk_integrate` / `qgs_rk_tgls_integrate` for the whole ensemble at once.
+"""
+import numpy as np
+
+from qgs_amd.functions.util import reverse
+
+
+def default_tableau():
+    """Classic RK4 (integrate.py:149-155)."""
+    c = np.array([0., 0.5, 0.5, 1.])
+    b = np.array([1. / 6, 1. / 3, 1. / 3, 1. / 6])
+    a = np.zeros((len(c), len(b)))
+    a[1, 0] = 0.5
+    a[2, 1] = 0.5
+    a[3, 2] = 1.
+    return b, c, a
+
+
+def resolve_tableau(b, c, a):
+    if a is None and b is None and c is None:
+        return default_tableau()
+    return b, c, a
+
+
+def time_grid(t0, t, dt):
+    """`np.concatenate((np.arange(t0, t, dt), [t]))` (integrate.py:162): the last step may be shorter than dt."""
+    return np.concatenate((np.arange(t0, t, dt), np.full((1,), t)))
+
+
+def record_times(time, write_steps, forward):
+    """Time axis of the records (integrate.py:166-179 / integrator.py:409-424)."""
+    if write_steps > 0:
+        if forward:
+            kept = time[::write_steps]
+            if kept[-1] == time[-1]:
+                return kept
+            return np.concatenate((kept, np.full((1,), time[-1])))
+        rtime = reverse(time[::-write_steps])
+        if rtime[0] == time[0]:
+            return rtime
+        return np.concatenate((np.full((1,), time[0]), rtime))
+    return time[-1]
+
+
+def hip_model_of(func, what='f'):
+    """The GPU handle behind a tendencies callable; arbitrary Python callables cannot run on the device."""
+    get = getattr(func, 'hip_model', None)
+    if get is None:
+        raise TypeError("%s must come from qgs_amd.functions.tendencies (create_tendencies / tendencies_from_tensor): "
+                        "a plain Python callable carries no tensor to stage on the GPU, and qgs_amd has no CPU "
+                        "integration path" % what)
+    return get()
+
+
+def dimension_of(func):
+    nd = getattr(func, 'ndim', None)
+    if nd is None:
+        raise TypeError('cannot determine the system dimension: the callable carries no tensor')
+    return int(nd)
+
+
+def normalise_ic(ic, n_dim):
+    if ic is None:
+        ic = np.zeros(n_dim)
+    ic = np.asarray(ic, dtype=np.float64)
+    if ic.ndim == 1:
+        ic = ic.reshape((1, -1))
+    return ic
+
+
+def normalise_tg_ic(tg_ic, n_traj, n_dim):
+    """Bring the tangent initial conditions to (n_traj, n_dim, n_tg) (integrate.py:472-497)."""
+    if tg_ic is None:
+        tg_ic = np.eye(n_dim)
+    tg_ic = np.asarray(tg_ic, dtype=np.float64)
+    if tg_ic.ndim == 1:                                   # one vector, shared by all trajectories
+        out = np.repeat(tg_ic.reshape((1, -1, 1)), n_traj, axis=0)
+    elif tg_ic.ndim == 2:
+        if tg_ic.shape[0] == n_traj:                      # one vector per trajectory
+            out = tg_ic[..., np.newaxis]
+        else:                                             # (n_tg, n_dim) shared by all trajectories
+            out = np.repeat(np.swapaxes(tg_ic[np.newaxis, ...], 1, 2), n_traj, axis=0)
+    elif tg_ic.ndim == 3:
+        out = np.swapaxes(tg_ic, 1, 2) if tg_ic.shape[1] != n_dim else tg_ic
+    else:
+        raise ValueError('tg_ic must be 1-D, 2-D or 3-D')
+    return np.ascontiguousarray(out)
+
+
+def restore_fmatrix_axes(recorded_fmatrix, tg_ic_user, n_dim):
+    """Undo the axis swap for user-side shapes (integrate.py:527-534 / integrator.py:998-1005)."""
+    if tg_ic_user.ndim == 2:
+        if recorded_fmatrix.shape[1:3] != tg_ic_user.shape:
+            recorded_fmatrix = np.swapaxes(recorded_fmatrix, 1, 2)
+    elif tg_ic_user.ndim == 3:
+        if tg_ic_user.shape[1] != n_dim:
+            if recorded_fmatrix.shape[:3] != tg_ic_user.shape:
+                recorded_fmatrix = np.swapaxes(recorded_fmatrix, 1, 2)
+    return recorded_fmatrix
+
+
+def check_boundary(boundary):
+    if boundary is not None:
+        raise NotImplementedError('only the zero boundary term (the default, integrate.py:235-237) runs on the device')
+
+
+def integrate_runge_kutta(f, t0, t, dt, ic=None, forward=True, write_steps=1, b=None, c=None, a=None):
+    """Integrate dx/dt = f(t, x) for one state or an ensemble of states; returns ``(time, traj)`` with the
+    reference's conventions: traj is ``np.squeeze`` of (n_traj, n_dim, n_records); time is a scalar when
+    ``write_steps == 0``."""
+    model = hip_model_of(f)
+    ic = normalise_ic(ic, dimension_of(f))
+    b, c, a = resolve_tableau(b, c, a)
+    time = time_grid(t0, t, dt)
+    recorded = model.rk_integrate(time, ic, 1 if forward else -1, write_steps, b, c, a)
+    return record_times(time, write_steps, forward), np.squeeze(recorded)
+
+
+def integrate_runge_kutta_tgls(f, fjac, t0, t, dt, ic=None, tg_ic=None, forward=True, adjoint=False, inverse=False,
+                               boundary=None, write_steps=1, b=None, c=None, a=None):
+    """Integrate the trajectory together with its tangent linear (or adjoint) model; returns
+    ``(time, traj, fmatrix)`` like integrate.py:240-552."""
+    check_boundary(boundary)
+    model = hip_model_of(f)
+    if fjac is None or hip_model_of(fjac, 'fjac') is not model:
+        raise TypeError('f and fjac must come from the same create_tendencies() call')
+    n_dim = dimension_of(f)
+    ic = normalise_ic(ic, n_dim)
+    tg_user = np.eye(n_dim) if tg_ic is None else np.asarray(tg_ic, dtype=np.float64)
+    tg = normalise_tg_ic(tg_user, ic.shape[0], n_dim)
+    b, c, a = resolve_tableau(b, c, a)
+    time = time_grid(t0, t, dt)
+    traj, fm = model.rk_tgls_integrate(time, ic, tg, 1 if forward else -1, write_steps, b, c, a, adjoint,
+                                       -1. if inverse else 1.)
+    fm = restore_fmatrix_axes(fm, tg_user, n_dim)
+    return record_times(time, write_steps, forward), np.squeeze(traj), np.squeeze(fm)

@@ -1,0 +1,132 @@
+"""GPU: the drop-in Python API (create_tendencies objects, functional integrators, integrator classes)
+against API-level goldens captured from the reference (shapes, time axes, squeezing, tg_ic conventions)."""
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module', params=['rp20', 'a36', 'm36'])
+def setup(request):
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    g = load_golden(request.param)
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    yield g, f, Df
+    f.operands.release()
+
+
+def _kw(g, case):
+    kw = dict(case['kw'])
+    return kw
+
+
+def test_f_and_Df_callables(setup):
+    g, f, Df = setup
+    x = g['fx_x'][3]
+    assert f(0., x).shape == (g.ndim,) and rel_err(f(0., x), g['fx_f'][3]) < 1e-14
+    assert Df(0., x).shape == (g.ndim, g.ndim) and rel_err(Df(0., x), g['fx_Df'][3]) < 1e-14
+    assert f.coo.shape[1] == 3 and len(f.val) == f.coo.shape[0] and f.ndim == g.ndim
+    f2 = pickle.loads(pickle.dumps(f))                       # picklable like the reference's f
+    assert rel_err(f2(0., x), g['fx_f'][3]) < 1e-14
+    f2.operands.release()
+
+
+def test_functional_rk_api(setup):
+    from qgs_amd.integrators.integrate import integrate_runge_kutta
+    g, f, _ = setup
+    ic = g['rk_ic']
+    cases = {
+        'f_w3': dict(t0=0., t=1., dt=0.1, ic=ic, forward=True, write_steps=3),
+        'b_w3': dict(t0=0., t=1., dt=0.1, ic=ic, forward=False, write_steps=3),
+        'f_w0': dict(t0=0., t=1., dt=0.1, ic=ic, forward=True, write_steps=0),
+        'f_w1_single': dict(t0=0., t=0.5, dt=0.1, ic=ic[0], forward=True, write_steps=1),
+        'f_w0_single': dict(t0=0., t=0.5, dt=0.1, ic=ic[0], forward=True, write_steps=0),
+        'b_w2_t0': dict(t0=1., t=2.05, dt=0.1, ic=ic[:3], forward=False, write_steps=2),
+    }
+    for tag, kw in cases.items():
+        tt, tr = integrate_runge_kutta(f, **kw)
+        assert np.shape(tt) == g['api_%s_time' % tag].shape, tag
+        assert np.array_equal(np.asarray(tt), g['api_%s_time' % tag]), tag
+        assert rel_err(tr, g['api_%s_traj' % tag]) < 1e-12, tag
+
+
+def test_functional_tgls_api(setup):
+    from qgs_amd.integrators.integrate import integrate_runge_kutta_tgls
+    g, f, Df = setup
+    ic = g['rk_ic']
+    common = dict(t0=0., t=0.3, dt=0.1)
+    cases = {
+        'tg_none': (None, dict(ic=ic[:2], write_steps=1)),
+        'tg_1d': ('arr', dict(ic=ic[:2], write_steps=1)),
+        'tg_2d_ntg': ('arr', dict(ic=ic[:2], write_steps=0)),
+        'tg_2d_ntraj': ('arr', dict(ic=ic[:2], write_steps=2)),
+        'tg_3d_swapped': ('arr', dict(ic=ic[:2], write_steps=1, adjoint=True)),
+        'tg_3d': ('arr', dict(ic=ic[:2], write_steps=1, forward=False, inverse=True)),
+        'tg_none_single': (None, dict(ic=ic[0], write_steps=0)),
+    }
+    for tag, (kind, kw) in cases.items():
+        tg = None if kind is None else g['api_%s_tgic' % tag]
+        tt, tr, fm = integrate_runge_kutta_tgls(f, Df, tg_ic=tg, **common, **kw)
+        assert np.array_equal(np.asarray(tt), g['api_%s_time' % tag]), tag
+        assert rel_err(tr, g['api_%s_traj' % tag]) < 1e-12, tag
+        assert rel_err(fm, g['api_%s_fm' % tag]) < 1e-11, tag
+
+
+def test_integrator_classes_vs_reference_classes(setup):
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator, RungeKuttaTglsIntegrator
+    g, f, Df = setup
+    ic = g['rk_ic']
+    integ = RungeKuttaIntegrator(num_threads=2)
+    assert integ.integrate(0., 1., 0.1, ic=ic[:4]) == 0          # no function set: prints and returns 0
+    integ.set_func(f)
+    integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=5)
+    tt, tr = integ.get_trajectories()
+    assert np.array_equal(tt, g['cls_rk_w5_time']) and rel_err(tr, g['cls_rk_w5_traj']) < 1e-12
+    assert (integ.n_traj, integ.n_dim, integ.n_records) == (4, g.ndim, 3)
+    assert integ.get_ic() is integ.ic and integ.ic.shape == (4, g.ndim)
+    integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=0, forward=False)
+    tt, tr = integ.get_trajectories()
+    assert np.ndim(tt) == 0 and tt == g['cls_rk_w0b_time'] and rel_err(tr, g['cls_rk_w0b_traj']) < 1e-12
+    integ.terminate()
+
+    tinteg = RungeKuttaTglsIntegrator(num_threads=2)
+    tinteg.set_func(f, Df)
+    tinteg.integrate(0., 0.3, 0.1, ic=ic[:2], write_steps=1)
+    tt, tr, fm = tinteg.get_trajectories()
+    assert np.array_equal(tt, g['cls_tgls_time'])
+    assert rel_err(tr, g['cls_tgls_traj']) < 1e-12 and rel_err(fm, g['cls_tgls_fm']) < 1e-11
+    assert tinteg.get_tg_ic().shape == (2, g.ndim, g.ndim)
+    tinteg.terminate()
+
+
+def test_initialize_draw_order_and_resume(setup):
+    """`initialize` consumes np.random in num_threads-sized batches (integrator.py:257-291) and leaves
+    (number_of_trajectories, n_dim) states in `ic`; feeding the last state back resumes a run."""
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+    g, f, _ = setup
+    scale = 0.05
+    integ = RungeKuttaIntegrator(num_threads=3)
+    integ.set_func(f)
+    np.random.seed(4)
+    integ.initialize(2.0, 0.1, ic=np.random.rand(5, g.ndim) * scale)
+    assert integ.get_ic().shape == (5, g.ndim) and np.isfinite(integ.get_ic()).all()
+    # resume: 20 steps in one go == 10 + 10 steps fed back (qgs_rp.py:106-108 idiom)
+    ic = g['rk_ic'][:3]
+    integ.integrate(0., 2.0, 0.1, ic=ic, write_steps=0)
+    _, whole = integ.get_trajectories()
+    integ.integrate(0., 1.0, 0.1, ic=ic, write_steps=0)
+    _, half = integ.get_trajectories()
+    integ.integrate(0., 1.0, 0.1, ic=half, write_steps=0)
+    _, two = integ.get_trajectories()
+    assert rel_err(two, whole) < 1e-13
+
+
+def test_plain_python_callable_is_rejected_loudly():
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+    integ = RungeKuttaIntegrator(num_threads=1)
+    with pytest.raises(TypeError):
+        integ.set_func(lambda t, x: -x)
