@@ -195,6 +195,10 @@ __device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward
 {
     return backward ? (n_records - 1 - iw) : iw;
 }
+// step `ti` is recorded (as record iw = ti / write_steps) when ti % write_steps == 0: keep the next such
+// step in a counter instead of dividing every step
+#define QGS_REC_INIT i64 iw = 0, next_rec = -1; \
+    if (write_steps > 0) { iw = (step_begin + write_steps - 1) / write_steps; next_rec = iw * write_steps; }
 )";
 
 void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
@@ -259,10 +263,12 @@ void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &row
     for (int d = 1; d <= ndim; ++d) o << "    y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    o << "    QGS_REC_INIT\n";
     o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
     o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
-    o << "        if (write_steps > 0 && (ti % write_steps) == 0) {\n"
-      << "            f64* p = rec + qgs_rec_index(ti / write_steps, n_records, backward) * " << ndim << " * ld + m;\n"
+    o << "        if (ti == next_rec) {\n"
+      << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
+      << "            ++iw; next_rec += write_steps;\n"
       << "            if (live) {\n";
     for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
     o << "            }\n        }\n";
@@ -301,6 +307,113 @@ void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &row
     o << "        }\n    }\n}\n";
 }
 
+// Row-split variant of the fused stepper: a workgroup of R wavefronts shares 64 members; wave w evaluates
+// only the rows of its partition and the R partitions exchange the new stage state through LDS once per
+// stage.  With n_traj/64 wavefronts of work a 1024-SIMD MI355X gets only ONE wave per SIMD from a
+// 65 536-member ensemble, and a lone wave cannot issue fp64 FMAs back to back (measured: 5.6 cycles per
+// independent v_fma_f64 against 4 with a second wave).  Splitting rows doubles the wave count for the
+// same ensemble and shrinks the per-wave register footprint (own rows of y/acc/x_out + the full x_in).
+std::vector<int> partition_rows(int ndim, const std::vector<Row> &rows, int R, const CodegenOptions &opt)
+{
+    std::vector<std::pair<int64_t, int>> cost;
+    for (int i = 1; i <= ndim; ++i) {
+        int64_t c = 2 + (int64_t)rows[i].lin.size();
+        for (auto &g : group_by_abs(rows[i].bil, opt.group_coeff)) c += (int64_t)g.size() + 1;
+        cost.push_back({c, i});
+    }
+    std::sort(cost.begin(), cost.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    std::vector<int64_t> load(R, 0);
+    std::vector<int> owner(ndim + 1, 0);
+    for (auto &ci : cost) {
+        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[ci.second] = w;
+        load[w] += ci.first;
+    }
+    return owner;
+}
+
+void emit_rk_split_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, int S, int R,
+                          const CodegenOptions &opt)
+{
+    const std::vector<int> owner = partition_rows(ndim, rows, R, opt);
+    const std::string kname = "qgs_spec_rksplit" + std::to_string(R) + "_s" + std::to_string(S);
+    o << "\n// " << S << "-stage RK, rows split over " << R << " wavefronts per 64 members (LDS exchange per stage)\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * R << ", " << R << ") " << kname << "(\n"
+      << "    const f64* __restrict__ y_in, f64* __restrict__ y_out, f64* __restrict__ rec, f64* __restrict__ stages,\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
+    o << "    __shared__ f64 xs[2][" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x & 63;\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+      << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
+      << "    const bool live = m0 < n_traj;\n"
+      << "    const i64 m = live ? m0 : (n_traj - 1);\n";
+    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
+    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    for (int w = 0; w < R; ++w) {
+        std::vector<int> own, other;
+        for (int i = 1; i <= ndim; ++i) (owner[i] == w ? own : other).push_back(i);
+        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
+        for (int i : own) o << " " << i;
+        o << "\n";
+        o << "        " << decl_list("y", ndim) << "\n";
+        for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+        o << "        QGS_REC_INIT\n";
+        o << "        for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << "            const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+        o << "            const int par0 = (int)(((ti - step_begin) * " << S << ") & 1);\n";
+        o << "            if (ti == next_rec) {\n"
+          << "                f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
+          << "                ++iw; next_rec += write_steps;\n"
+          << "                if (live) {\n";
+        for (int d : own) o << "                    p[" << (d - 1) << " * ld] = y" << d << ";\n";
+        o << "                }\n            }\n";
+        o << "            f64 ";
+        for (size_t n = 0; n < own.size(); ++n) o << "acc" << own[n] << (n + 1 < own.size() ? ", " : ";\n");
+        if (S > 1) o << "            " << decl_list("xa", ndim) << "\n";
+        if (S > 2) o << "            " << decl_list("xb", ndim) << "\n";
+        for (int st = 0; st < S; ++st) {
+            const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
+            const std::string out = (st % 2 == 0) ? "xa" : "xb";
+            const bool last = (st == S - 1);
+            o << "            {   // stage " << st << "\n";
+            o << "                const f64 hb = dt * tb" << st << ";\n";
+            if (!last) o << "                const f64 ha = dt * ta" << st << ";\n";
+            o << "                const int pb = (par0 + " << st << ") & 1;\n";
+            for (int i : own) {
+                o << "                {\n";
+                emit_tend_row(o, "                    ", rows[i], "r", names(in), opt, w * 10000 + st * 100 + i);
+                o << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
+                if (!last) {
+                    o << "                    " << out << i << " = __builtin_fma(ha, r, y" << i << ");\n";
+                    o << "                    xs[pb][" << (i - 1) << "][lane] = " << out << i << ";\n";
+                } else {
+                    o << "                    xs[pb][" << (i - 1) << "][lane] = acc" << i << ";\n";
+                }
+                o << "                }\n";
+            }
+            o << "                __syncthreads();\n";
+            if (!last) {
+                for (int j : other) o << "                " << out << j << " = xs[pb][" << (j - 1) << "][lane];\n";
+            } else {
+                for (int i : own) o << "                y" << i << " = acc" << i << ";\n";
+                for (int j : other) o << "                y" << j << " = xs[pb][" << (j - 1) << "][lane];\n";
+            }
+            o << "            }\n";
+        }
+        o << "        }\n";
+        o << "        if (live) {\n            if (y_out) {\n";
+        for (int d : own) o << "                y_out[" << (d - 1) << " * ld + m] = y" << d << ";\n";
+        o << "            }\n            if (write_final) {\n"
+          << "                f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
+        for (int d : own) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+        o << "            }\n        }\n    }\n";
+    }
+    o << "}\n";
+}
+
 // Tangent-linear / adjoint propagation along stored stage states.  One lane per (member, column):
 // lane l = col*ld + member; tangent arrays are F[mode][col][member] = element d*(n_tg*ld) + l.
 void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vector<WX>> &tgl,
@@ -324,10 +437,12 @@ void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vec
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    o << "    QGS_REC_INIT\n";
     o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
     o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
-    o << "        if (write_steps > 0 && (ti % write_steps) == 0) {\n"
-      << "            f64* p = rec + qgs_rec_index(ti / write_steps, n_records, backward) * " << ndim << " * L + l;\n"
+    o << "        if (ti == next_rec) {\n"
+      << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * L + l;\n"
+      << "            ++iw; next_rec += write_steps;\n"
       << "            if (live) {\n";
     for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
     o << "            }\n        }\n";
@@ -390,6 +505,7 @@ std::string generate_source(int ndim, const std::vector<Term> &tensor, const std
     const auto adj = build_wx_rows(ndim, jac_tensor, true);
     for (int S : stages) {
         emit_rk_kernel(o, ndim, rows, S, false, opt);
+        if (opt.row_split > 1) emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt);
         if (!jac_tensor.empty()) {
             emit_rk_kernel(o, ndim, rows, S, true, opt);
             emit_tgl_kernel(o, ndim, tgl, adj, S, opt);

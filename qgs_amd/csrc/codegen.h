@@ -22,6 +22,7 @@ struct Term {          // one COO entry (i, j, k, value); index 0 is the constan
 struct CodegenOptions {
     bool group_coeff = true;   // factor equal-|coefficient| bilinear terms of a row: c*(m1 +- m2 ...)
     int min_waves_per_simd = 1;
+    int row_split = 2;         // also emit the row-split stepper with this many wavefronts per 64 members
 };
 
 // Classification of a Butcher tableau (reference: integrate.py:214-219 uses the full matrix `a`).

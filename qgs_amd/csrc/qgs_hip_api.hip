@@ -200,6 +200,7 @@ struct qgs_model {
     std::vector<qgs::Term> T, J;
     DevCsr dT, dJ_by_i, dJ_by_j;
     int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
+    int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
     qgs::CodegenOptions cg;
     // compiled specialised modules: key 0 = base (tend, jac), key S = S-stage steppers
@@ -323,6 +324,13 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     return 0;
 }
 
+// Developer knobs (the defaults are what ships): QGS_HIP_NO_GROUP=1, QGS_HIP_ROW_SPLIT=<R>
+void apply_env_options(qgs::CodegenOptions &cg)
+{
+    if (const char *e = std::getenv("QGS_HIP_NO_GROUP")) if (*e == '1') cg.group_coeff = false;
+    if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
+}
+
 bool use_spec(const qgs_model *m, int s, const double *a)
 {
     if (m->kernel_kind == 1) return false;
@@ -387,6 +395,11 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
     m->device = device;
     m->ndim = ndim;
     m->arch = target_arch(device);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            m->n_simd = 4 * prop.multiProcessorCount;
+    }
     for (int64_t e = 0; e < nnz; ++e) {
         const int i = coo[3 * e], j = coo[3 * e + 1], k = coo[3 * e + 2];
         if (i < 0 || j < 0 || k < 0 || i > ndim || j > ndim || k > ndim) { delete m; return fail("tensor coordinate out of range"); }
@@ -408,8 +421,7 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
     HostCsr hJj = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.j; }, [&](const qgs::Term &t) { return pack(t.i, t.k); });
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
     m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM);
-    const char *nogroup = std::getenv("QGS_HIP_NO_GROUP");
-    if (nogroup && *nogroup == '1') m->cg.group_coeff = false;
+    apply_env_options(m->cg);
     *out = m;
     return 0;
 }
@@ -558,8 +570,18 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
     const int64_t n_records = qgs_n_records(time, n_time, write_steps);
     const int backward = time_direction == -1;
     if (use_spec(m, s, a)) {
+        // Row-split stepper (R wavefronts per 64 members) when the ensemble alone cannot put two
+        // wavefronts on every SIMD; plain one-wave-per-64-members stepper otherwise.
+        const int R = m->cg.row_split;
+        const int64_t waves = (n_traj + 63) / 64;
+        bool split = R > 1 && waves < 2 * (int64_t)m->n_simd;
+        if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
+            if (!std::strcmp(e, "plain")) split = false;
+            if (!std::strcmp(e, "split") && R > 1) split = true;
+        }
         hipFunction_t f;
-        const std::string name = "qgs_spec_rk_s" + std::to_string(s);
+        const std::string name = split ? "qgs_spec_rksplit" + std::to_string(R) + "_s" + std::to_string(s)
+                                       : "qgs_spec_rk_s" + std::to_string(s);
         if (get_function(m, s, name, &f)) return -1;
         double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
@@ -567,7 +589,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         void *args[] = {(void *)&d_ic, &y_out, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_spec,
                         &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
         note_kernel(m, name, f);
-        return launch(f, n_traj, st, args);
+        const unsigned blocks = (unsigned)waves;
+        HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, split ? 64 * R : 64, 1, 1, 0, st, args, nullptr));
+        return 0;
     }
     if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * ld)) return -1;
     qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
@@ -751,8 +775,7 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, i
     m.arch = (arch && *arch) ? arch : target_arch(-1);
     for (int64_t e = 0; e < nnz; ++e) m.T.push_back({coo[3 * e], coo[3 * e + 1], coo[3 * e + 2], val[e]});
     for (int64_t e = 0; e < jnnz; ++e) m.J.push_back({jcoo[3 * e], jcoo[3 * e + 1], jcoo[3 * e + 2], jval[e]});
-    const char *nogroup = std::getenv("QGS_HIP_NO_GROUP");
-    if (nogroup && *nogroup == '1') m.cg.group_coeff = false;
+    apply_env_options(m.cg);
     std::vector<int> all = {0};
     for (int i = 0; i < n_stage_counts; ++i) all.push_back(stage_counts[i]);
     for (int S : all) {
