@@ -1,0 +1,44 @@
+"""The four model configurations of the goldens, built with qgs_amd's own QgParams (same calls as
+tests/golden/make_golden.py makes on the reference)."""
+import numpy as np
+
+from qgs_amd.params.params import QgParams
+
+
+def params_rp20():
+    p = QgParams({'phi0_npi': np.deg2rad(50.) / np.pi, 'hd': 0.1})
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.ground_params.set_orography(0.2, 1)
+    p.atemperature_params.set_thetas(0.2, 0)
+    return p
+
+
+def params_a36():
+    p = QgParams({'rr': 287.e0, 'sb': 5.6e-8})
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_oceanic_basin_fourier_modes(2, 4)
+    p.set_params({'kd': 0.04, 'kdp': 0.04, 'n': 1.5})
+    return p
+
+
+def params_m36():
+    p = QgParams()
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_oceanic_basin_fourier_modes(2, 4)
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'n': 1.5, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'T0': 289.3, 'hlambda': 15.06, })
+    p.gotemperature_params.set_params({'gamma': 5.6e8, 'T0': 301.46})
+    p.atemperature_params.set_insolation(103.3333, 0)
+    p.gotemperature_params.set_insolation(310., 0)
+    return p
+
+
+def params_t228():
+    p = QgParams({'rr': 287.e0, 'sb': 5.6e-8})
+    p.set_atmospheric_channel_fourier_modes(6, 6)
+    p.set_oceanic_basin_fourier_modes(6, 6)
+    p.set_params({'kd': 0.04, 'kdp': 0.04, 'n': 1.5})
+    return p
+
+
+MAKERS = {'rp20': params_rp20, 'a36': params_a36, 'm36': params_m36, 't228': params_t228}

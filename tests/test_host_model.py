@@ -1,0 +1,183 @@
+"""CPU: the host-side model setup (QgParams -> analytic inner products -> QgsTensor -> create_tendencies)
+against (1) the goldens captured from the reference and (2) the reference tests' own .ref data files
+(model_test/*.ref, gzip copies under tests/golden/ref/), compared the way the reference's tests do
+(model_test/test_base.py: sorted "name[i][j][k] = % .5E" strings, numerically within machine epsilon)."""
+import gzip
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, load_golden
+from model_configs import MAKERS
+
+REAL_EPS = np.finfo(np.float64).eps
+
+
+@pytest.fixture(scope='module')
+def built():
+    from qgs_amd.functions.tendencies import create_tendencies
+    out = {}
+    for name, mk in MAKERS.items():
+        p = mk()
+        f, Df, ips, T = create_tendencies(p, return_inner_products=True, return_qgtensor=True)
+        out[name] = (p, f, Df, ips, T)
+    return out
+
+
+def _ref_lines(fn):
+    with gzip.open(os.path.join(GOLDEN_DIR, 'ref', fn + '.gz'), 'rt') as f:
+        return [l.rstrip('\n') for l in f if l.strip()]
+
+
+def _fmt(symbol, idx, v, one_based=False):
+    off = 1 if one_based else 0
+    return symbol + "".join("[%d]" % (i + off) for i in idx) + " = % .5E" % v
+
+
+def _match_str(s1, s2, cmax=1):
+    """model_test/test_base.py:80-91: at most `cmax` differing characters."""
+    return sum(1 for c1, c2 in zip(s1, s2) if c1 != c2) <= cmax
+
+
+def _compare_sorted(values, reference, mode):
+    """mode 'str': TestBase.check_lists (string match, one differing character allowed);
+    mode 'flt': TestBase.check_lists_flt (|v1 - v2| < eps on the printed 6-digit values)."""
+    values, reference = sorted(values, reverse=True), sorted(reference, reverse=True)
+    assert len(values) == len(reference), (len(values), len(reference))
+    for v, r in zip(values, reference):
+        if mode == 'str':
+            assert _match_str(v, r), (v, r)
+        else:
+            assert v.split('=')[0] == r.split('=')[0], (v, r)
+            assert abs(float(v.split('=')[1]) - float(r.split('=')[1])) < REAL_EPS, (v, r)
+
+
+@pytest.mark.parametrize('name', list(MAKERS))
+def test_dimensions_and_derived_parameters(built, name):
+    g = load_golden(name)
+    p = built[name][0]
+    assert p.ndim == g.ndim
+    assert list(p.nmod) == [int(v) for v in g['par_nmod']]
+    assert list(p.variables_range) == [int(v) for v in g['par_variables_range']]
+    vals = {'L': p.scale_params.L, 'n': p.scale_params.n, 'beta': p.scale_params.beta, 'kd': p.atmospheric_params.kd,
+            'kdp': p.atmospheric_params.kdp, 'sig0': p.atmospheric_params.sig0}
+    if p.oceanic_params is not None:
+        vals.update(oc_r=p.oceanic_params.r, oc_d=p.oceanic_params.d, oc_gp=p.oceanic_params.gp, oc_h=p.oceanic_params.h)
+    for k in ('LR', 'G', 'Cpgo', 'Lpgo', 'Cpa', 'Lpa', 'sbpgo', 'sbpa', 'LSBpgo', 'LSBpa'):
+        vals[k] = getattr(p, k)
+    if p.atemperature_params.hd is not None:
+        vals['hd'] = p.atemperature_params.hd
+    if p.atemperature_params.thetas is not None:
+        vals['thetas'] = p.atemperature_params.thetas
+    if p.ground_params is not None and p.ground_params.hk is not None:
+        vals['hk'] = p.ground_params.hk
+    for k, v in vals.items():
+        key = 'par_' + k
+        if v is None:
+            assert key not in g, k
+        else:
+            assert key in g, k
+            assert np.array_equal(np.asarray(v, dtype=float), g[key]), k     # bitwise
+
+
+def test_survey_known_answers(built):
+    """SURVEY.md appendix A known-answer parameters."""
+    pa, pm, pb = built['a36'][0], built['m36'][0], built['rp20'][0]
+    assert float(pa.scale_params.L) == 1591549.4309189534
+    assert float(pa.scale_params.beta) == 0.2498507740846081 and float(pb.scale_params.beta) == 0.20964969238375256
+    assert pa.LR == 38149.26295548358 and pa.G == -1740.4756820564055
+    assert pm.LR == 19932.761727485995 and pm.G == -6375.368798741413
+    assert pm.Lpgo == 0.00026058970099667773 and pm.Lpa == 0.014593023255813953
+    assert pb.LR is None and pb.G is None and pb.Cpa is None
+    assert float(pb.atemperature_params.hd) == 0.1
+    assert list(pb.atemperature_params.thetas[:2]) == [0.2, 0.0] and list(pb.ground_params.hk[:3]) == [0.0, 0.2, 0.0]
+    assert len(pa.Cpa) == 10 and len(pa.Cpgo) == 10          # ocean insolation lives on the ATMOSPHERIC basis
+
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36'])
+def test_inner_products_bitwise_vs_golden(built, name):
+    g = load_golden(name)
+    aip, oip, _ = built[name][3]
+    for k in ('a', 'u', 'c', 'b', 'g', 's', 'd'):
+        if 'aip_' + k in g:
+            assert np.array_equal(getattr(aip, '_' + k), g['aip_' + k]), k
+    if oip is not None:
+        for k in ('M', 'U', 'N', 'O', 'C', 'K', 'W'):
+            assert np.array_equal(getattr(oip, '_' + k), g['oip_' + k]), k
+
+
+@pytest.mark.parametrize('name,fn', [('a36', 'test_inprod_analytic.ref'), ('t228', 'test_inprod_analytic_6x6.ref')])
+def test_inner_products_vs_reference_ref_file(built, name, fn):
+    """model_test/test_inner_products.py: every non-zero inner product, 1-based indices."""
+    aip, oip, _ = built[name][3]
+    vals = []
+    for sym, arr in (('a', aip._a), ('c', aip._c), ('b', aip._b), ('g', aip._g), ('s', aip._s), ('d', aip._d),
+                     ('M', oip._M), ('N', oip._N), ('O', oip._O), ('C', oip._C), ('K', oip._K), ('W', oip._W)):
+        for idx in zip(*np.nonzero(arr)):
+            if abs(arr[idx]) >= REAL_EPS:
+                vals.append(_fmt(sym, idx, arr[idx], one_based=True))
+    ref = _ref_lines(fn)
+    ref_syms = sorted(set(l.split('[')[0] for l in ref))
+    vals = [v for v in vals if v.split('[')[0] in ref_syms]
+    _compare_sorted(vals, ref, 'str')
+
+
+@pytest.mark.parametrize('name', list(MAKERS))
+def test_tensors_bitwise_vs_golden(built, name):
+    g = load_golden(name)
+    T = built[name][4]
+    assert np.array_equal(T.tensor.coords.T, g['coo']) and np.array_equal(T.tensor.data, g['val'])
+    assert np.array_equal(T.jacobian_tensor.coords.T, g['jcoo']) and np.array_equal(T.jacobian_tensor.data, g['jval'])
+    c = T.tensor.coords
+    assert (c[1] <= c[2]).all() and (c[0] >= 1).all()                         # upper triangular, no row 0
+    order = np.lexsort((c[2], c[1], c[0]))
+    assert np.array_equal(order, np.arange(c.shape[1]))                       # lexicographic (i, j, k)
+
+
+@pytest.mark.parametrize('name,fn,sym,eps,mode', [('a36', 'test_aotensor.ref', 'aotensor', REAL_EPS, 'str'),
+                                                  ('t228', 'test_aotensor_6x6.ref', 'aotensor', 5 * REAL_EPS, 'flt')])
+def test_tensor_vs_reference_ref_file(built, name, fn, sym, eps, mode):
+    """model_test/test_aotensor.py (check_lists) / test_aotensor_6x6.py (check_lists_flt)."""
+    T = built[name][4]
+    vals = [_fmt(sym, c, v) for c, v in zip(T.tensor.coords.T, T.tensor.data) if abs(v) >= eps]
+    _compare_sorted(vals, _ref_lines(fn), mode)
+
+
+def test_jacobian_tensor_vs_reference_ref_file(built):
+    """model_test/test_aotensor_jacobian.py."""
+    T = built['a36'][4]
+    vals = [_fmt('jac_aotensor', c, v) for c, v in zip(T.jacobian_tensor.coords.T, T.jacobian_tensor.data) if abs(v) >= REAL_EPS]
+    ref = _ref_lines('test_aotensor_jacobian.ref')
+    ref_sym = ref[0].split('[')[0]
+    vals = [ref_sym + v[len('jac_aotensor'):] for v in vals]
+    _compare_sorted(vals, ref, 'str')
+
+
+def test_create_tendencies_contract(built):
+    from qgs_amd.functions.tendencies import create_tendencies
+    p = built['a36'][0]
+    ret = create_tendencies(p)
+    assert isinstance(ret, list) and len(ret) == 2
+    f, Df = ret
+    assert f.ndim == 36 and f.coo.shape == (351, 3) and Df.coo.shape == (699, 3)
+    assert len(create_tendencies(p, return_inner_products=True, return_qgtensor=True)) == 4
+    f2, p2 = pickle.loads(pickle.dumps((f, p)))                              # f and QgParams are picklable
+    assert np.array_equal(f2.val, f.val) and p2.ndim == 36
+
+
+def test_oracle_agrees_with_own_tensor_on_f(built):
+    """End to end on the CPU side: own tensor + oracle == golden f(x) bitwise."""
+    from oracle.oracle import OracleModel
+    for name in ('rp20', 'm36'):
+        g = load_golden(name)
+        f = built[name][1]
+        m = OracleModel(f.ndim, f.coo, f.val)
+        assert np.array_equal(m.f(0., g['fx_x']), g['fx_f'])
+
+
+def test_print_tensor(built, capsys):
+    built['rp20'][4].print_tensor('T')
+    out = capsys.readouterr().out.strip().split('\n')
+    assert len(out) == 225 and out[0].startswith('T[1][0][')
