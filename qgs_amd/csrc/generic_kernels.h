@@ -48,6 +48,26 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
                     const double *w_in, double *w_out, double *rec, const double *stages,
                     double *work, const double *dtime, const double *tab_full, hipStream_t st);
 
+// ---- tiled generic stepper ------------------------------------------------------------------------
+// Tensor re-laid for the tiled kernel: a flat stream of terms per output row, padded with zero terms to a
+// multiple of 4 so that one s_load_dwordx4 + s_load_dwordx4 + s_load_dwordx8 feeds four terms:
+//     dx_i = sum_terms c * x_j * x_k ,      x_0 = 1 lives in LDS slot 0.
+// Offsets are LDS byte offsets of the 64-lane slots (index * 512).
+struct TiledTensor {
+    const int32_t *row_term;   // ndim + 2 : terms of row i are [row_term[i], row_term[i+1]), both multiples of 4
+    const uint32_t *term_joff; // n_terms : j * 512
+    const uint32_t *term_koff; // n_terms : k * 512
+    const double *term_c;      // n_terms
+};
+
+// True if the tiled kernel can run this problem (sub-diagonal tableau is checked by the caller).
+bool tiled_supported(int ndim);
+// One workgroup of 16 wavefronts per 64 members: lanes = members, wavefronts split the rows, the stage
+// state lives in LDS ((ndim+1) x 64 doubles), each wavefront keeps y / acc / x_next of its own rows in
+// registers.  tab_spec = b[s], a[1][0], a[2][1], ...   Returns hipSuccess or the launch error.
+hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec,
+                               double *stages, const double *dtime, const double *tab_spec, hipStream_t st);
+
 // Layout conversion kernels (host layout <-> device layout), see include/qgs_hip.h
 void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);
 void launch_unpack_states(int ndim, int64_t n_traj, int64_t ld, const double *modes, double *rows, hipStream_t st);

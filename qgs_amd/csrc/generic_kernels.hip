@@ -7,6 +7,8 @@ namespace {
 
 constexpr int WAVE = 64;
 
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
 // One tendency row: r = sum_e val_e * x_a * x_b  with x_0 = 1 (sparse_mul.py:76-80; the row loop
 // is the COO loop restricted to coo[n,0] == i, entries kept in the reference's (j,k) order).
 __device__ __forceinline__ double row_dot2(const DevTensor &T, int i, const double *__restrict__ x, int64_t ld, int64_t m)
@@ -155,6 +157,144 @@ __global__ void __launch_bounds__(WAVE) gen_tgl_kernel(DevTensor Jr, RkArgs p, i
     }
 }
 
+// ---- tiled generic stepper ----------------------------------------------------------------------------
+// RPW rows per wavefront (static register slots), NW = 16 wavefronts per workgroup, 64 members per
+// workgroup.  The tensor entries of a row are wave-uniform (scalar loads); x_j / x_k are conflict-free
+// 512-byte LDS reads (lane-consecutive doubles).
+constexpr int TILED_NW = 16;
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const int32_t ci32;
+typedef __attribute__((address_space(4))) const uint32_t cu32;
+typedef __attribute__((address_space(4))) const double cf64;
+typedef __attribute__((address_space(4))) const u32x4 cu32x4;
+typedef __attribute__((address_space(4))) const f64x4 cf64x4;
+
+template <int RPW>
+__global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor T, RkArgs p, const double *__restrict__ y_in,
+                                                                      double *__restrict__ y_out, double *__restrict__ rec,
+                                                                      double *__restrict__ stages,
+                                                                      const double *__restrict__ dtime,
+                                                                      const double *__restrict__ tab)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t m0 = (int64_t)blockIdx.x * WAVE + lane;
+    const bool live = m0 < p.n_traj;
+    const int64_t m = live ? m0 : p.n_traj - 1;
+    const int ndim = p.ndim, s = p.s;
+    const int64_t ld = p.ld, A = (int64_t)ndim * ld;
+    const int row0 = wave * RPW + 1;                       // first own row (1-based tensor index)
+    const uint32_t lane8 = (uint32_t)lane * 8u;
+    char *xs = smem;                                       // slot r at byte r*512, lane l at +l*8
+    // the tensor stream is read-only for the whole launch: constant address space => scalar (s_load) fetches
+    const ci32 *row_term = (const ci32 *)T.row_term;
+    const cu32 *term_joff = (const cu32 *)T.term_joff;
+    const cu32 *term_koff = (const cu32 *)T.term_koff;
+    const cf64 *term_c = (const cf64 *)T.term_c;
+
+    double y[RPW], acc[RPW], xn[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int row = row0 + r;
+        y[r] = (row <= ndim) ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
+        if (row <= ndim) *(double *)(xs + (uint32_t)row * 512u + lane8) = y[r];
+    }
+    if (wave == 0) *(double *)(xs + lane8) = 1.0;          // eta_0 = 1
+    __syncthreads();
+
+    int64_t iw = 0, next_rec = -1;
+    if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
+
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (ti == next_rec) {
+            double *q = rec + rec_index(iw, p.n_records, p.backward) * A + m;
+            ++iw; next_rec += p.write_steps;
+            if (live) {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) if (row0 + r <= ndim) q[(int64_t)(row0 + r - 1) * ld] = y[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) acc[r] = y[r];
+        for (int st = 0; st < s; ++st) {
+            const double hb = dt * tab[st];
+            const double ha = (st + 1 < s) ? dt * tab[s + st] : 0.0;
+            if (stages && live) {
+                double *sp = stages + ((ti - p.step_begin) * s + st) * A + m;
+#pragma unroll
+                for (int r = 0; r < RPW; ++r)
+                    if (row0 + r <= ndim) sp[(int64_t)(row0 + r - 1) * ld] = *(double *)(xs + (uint32_t)(row0 + r) * 512u + lane8);
+            }
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = row0 + r;
+                if (row <= ndim) {
+                    double k0 = 0.0, k1 = 0.0;               // two partial sums: independent FMA chains
+                    const int t1 = row_term[row + 1];
+                    for (int t = row_term[row]; t < t1; t += 4) {
+                        const u32x4 jo = *(const cu32x4 *)(term_joff + t);
+                        const u32x4 ko = *(const cu32x4 *)(term_koff + t);
+                        const f64x4 cc = *(const cf64x4 *)(term_c + t);
+                        const double xj0 = *(const double *)(xs + jo.x + lane8), xk0 = *(const double *)(xs + ko.x + lane8);
+                        const double xj1 = *(const double *)(xs + jo.y + lane8), xk1 = *(const double *)(xs + ko.y + lane8);
+                        const double xj2 = *(const double *)(xs + jo.z + lane8), xk2 = *(const double *)(xs + ko.z + lane8);
+                        const double xj3 = *(const double *)(xs + jo.w + lane8), xk3 = *(const double *)(xs + ko.w + lane8);
+                        k0 = __builtin_fma(cc.x, xj0 * xk0, k0);
+                        k1 = __builtin_fma(cc.y, xj1 * xk1, k1);
+                        k0 = __builtin_fma(cc.z, xj2 * xk2, k0);
+                        k1 = __builtin_fma(cc.w, xj3 * xk3, k1);
+                    }
+                    const double k = k0 + k1;
+                    acc[r] = __builtin_fma(hb, k, acc[r]);
+                    xn[r] = __builtin_fma(ha, k, y[r]);
+                }
+            }
+            __syncthreads();                               // every wavefront is done reading the stage state
+            const bool last = (st == s - 1);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const int row = row0 + r;
+                if (row <= ndim) {
+                    const double v = last ? acc[r] : xn[r];
+                    *(double *)(xs + (uint32_t)row * 512u + lane8) = v;
+                    if (last) y[r] = acc[r];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int row = row0 + r;
+            if (row <= ndim) {
+                if (y_out) y_out[(int64_t)(row - 1) * ld + m] = y[r];
+                if (p.write_final) rec[rec_index(p.n_records - 1, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y[r];
+            }
+        }
+    }
+}
+
+template <int RPW>
+hipError_t launch_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
+                        const double *dtime, const double *tab, hipStream_t st)
+{
+    const size_t lds = (size_t)(p.ndim + 1) * 512;
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void *)gen_rk_tiled_kernel<RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(gen_rk_tiled_kernel<RPW>, dim3(blocks_for(p.n_traj, WAVE)), dim3(64 * TILED_NW), lds, st, T, p, y_in, y_out,
+                       rec, stages, dtime, tab);
+    return hipGetLastError();
+}
+
 // ---- layout conversion ----------------------------------------------------------------------
 // 64 members x 64 inner elements per block through an LDS tile so that both sides are coalesced.
 constexpr int TILE = 64;
@@ -206,8 +346,6 @@ __global__ void __launch_bounds__(256) unpack_records_kernel(int64_t n_inner, in
     for (int64_t r = 0; r < n_records; ++r) o[r] = i[r * n_inner * ld];
 }
 
-inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
-
 }  // namespace
 
 void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, const double *x, double *dx, hipStream_t st)
@@ -233,6 +371,19 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
 {
     hipLaunchKernelGGL(gen_tgl_kernel, dim3(blocks_for(n_tg * p.ld, WAVE)), dim3(WAVE), 0, st, Jrow, p, n_tg, inverse, w_in,
                        w_out, rec, stages, work, dtime, tab_full);
+}
+
+bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }
+
+hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec,
+                               double *stages, const double *dtime, const double *tab_spec, hipStream_t st)
+{
+    const int rpw = (p.ndim + TILED_NW - 1) / TILED_NW;
+    if (rpw <= 2) return launch_tiled<2>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    if (rpw <= 4) return launch_tiled<4>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    if (rpw <= 8) return launch_tiled<8>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    if (rpw <= 16) return launch_tiled<16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    return hipErrorInvalidValue;
 }
 
 void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)

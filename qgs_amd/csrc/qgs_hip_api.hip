@@ -199,6 +199,11 @@ struct qgs_model {
     std::string arch;
     std::vector<qgs::Term> T, J;
     DevCsr dT, dJ_by_i, dJ_by_j;
+    // regrouped tendencies tensor for the tiled generic stepper (generic_kernels.h TiledTensor)
+    int32_t *t_row_term = nullptr;
+    uint32_t *t_term_joff = nullptr, *t_term_koff = nullptr;
+    double *t_term_c = nullptr;
+    qgs::TiledTensor tiled() const { return qgs::TiledTensor{t_row_term, t_term_joff, t_term_koff, t_term_c}; }
     int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
@@ -227,6 +232,39 @@ int upload_csr(const HostCsr &h, DevCsr &d)
         HIPCHK(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
     }
+    return 0;
+}
+
+template <class T>
+int upload_vec(const std::vector<T> &h, T **d)
+{
+    HIPCHK(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(1, h.size())));
+    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// rows -> flat term stream (reference (j,k) order kept), each row padded to a multiple of 4 terms with
+// zero-coefficient terms that read slot 0; offsets are LDS byte offsets (generic_kernels.h TiledTensor)
+int upload_tiled(qgs_model *m, const std::vector<qgs::Term> &Tr)
+{
+    const int ndim = m->ndim;
+    std::vector<std::vector<const qgs::Term *>> by_row(ndim + 2);
+    for (const auto &t : Tr) by_row[t.i].push_back(&t);
+    std::vector<int32_t> row_term(ndim + 2, 0);
+    std::vector<uint32_t> joff, koff;
+    std::vector<double> c;
+    for (int i = 0; i <= ndim; ++i) {
+        row_term[i] = (int32_t)c.size();
+        for (const qgs::Term *t : by_row[i]) {
+            joff.push_back((uint32_t)t->j * 512u);
+            koff.push_back((uint32_t)t->k * 512u);
+            c.push_back(t->v);
+        }
+        while (c.size() % 4) { joff.push_back(0); koff.push_back(0); c.push_back(0.0); }
+    }
+    row_term[ndim + 1] = (int32_t)c.size();
+    if (upload_vec(row_term, &m->t_row_term) || upload_vec(joff, &m->t_term_joff) || upload_vec(koff, &m->t_term_koff) ||
+        upload_vec(c, &m->t_term_c)) return -1;
     return 0;
 }
 
@@ -339,6 +377,13 @@ bool use_spec(const qgs_model *m, int s, const double *a)
     return a == nullptr || qgs::tableau_is_subdiagonal(s, a);
 }
 
+// tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
+bool use_tiled(const qgs_model *m, int s, const double *a)
+{
+    if (const char *e = std::getenv("QGS_HIP_GENERIC")) if (!std::strcmp(e, "simple")) return false;
+    return s >= 1 && s <= 8 && qgs::tiled_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+}
+
 int check_common(const qgs_model *m, int64_t n_traj, int64_t ld)
 {
     if (!m) return fail("null model");
@@ -419,7 +464,7 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
     // Jacobian kernel wants (j,k) per row i; tangent model wants (w=j, x=k) per row i; adjoint (w=i, x=k) per row j
     HostCsr hJi = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
     HostCsr hJj = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.j; }, [&](const qgs::Term &t) { return pack(t.i, t.k); });
-    if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
+    if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j) || upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
     m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM);
     apply_env_options(m->cg);
     *out = m;
@@ -432,6 +477,8 @@ int qgs_model_destroy(qgs_model *m)
     (void)hipSetDevice(m->device);
     for (auto &kv : m->modules) (void)hipModuleUnload(kv.second);
     free_csr(m->dT); free_csr(m->dJ_by_i); free_csr(m->dJ_by_j);
+    for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c})
+        if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
                       &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2})
         b->release();
@@ -593,8 +640,13 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, split ? 64 * R : 64, 1, 1, 0, st, args, nullptr));
         return 0;
     }
-    if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * ld)) return -1;
     qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
+    if (use_tiled(m, s, a)) {
+        HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
+        note_kernel(m, "gen_rk_tiled_kernel", nullptr);
+        return 0;
+    }
+    if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * ld)) return -1;
     qgs::launch_gen_rk(m->dT.view(), p, d_ic, nullptr, d_rec, nullptr, m->work.f64(), d_time, d_tab_full, st);
     note_kernel(m, "gen_rk_kernel", nullptr);
     HIPCHK(hipGetLastError());
@@ -664,7 +716,10 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             if (launch(f2, L, st, a2)) return -1;
         } else {
             qgs::RkArgs p{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
-            qgs::launch_gen_rk(m->dT.view(), p, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
+            if (use_tiled(m, s, a))
+                HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+            else
+                qgs::launch_gen_rk(m->dT.view(), p, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
             qgs::launch_gen_tgl(Jrow, p, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);
             note_kernel(m, "gen_tgl_kernel", nullptr);
             HIPCHK(hipGetLastError());
