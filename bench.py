@@ -149,7 +149,9 @@ def main():
     d_ic_modes = torch.empty((ndim, ld), dtype=torch.float64, device=dev)
     d_rec = torch.empty((1, ndim, ld), dtype=torch.float64, device=dev)
     d_out_rows = torch.empty((n_traj, ndim), dtype=torch.float64, device=dev)
-    gathered = torch.empty((world * n_traj, ndim), dtype=torch.float64, device=dev) if world > 1 else None
+    from qgs_amd.parallel import ShardedEnsemble
+    ens = ShardedEnsemble(world * n_traj)                              # contiguous member blocks, one per rank
+    assert ens.n_local == n_traj
     stream = torch.cuda.current_stream().cuda_stream
 
     kern_events = []
@@ -165,7 +167,7 @@ def main():
             kern_events.append((e0, e1))
         model.unpack_records(n_traj, ld, ndim, 1, d_rec.data_ptr(), d_out_rows.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, d_out_rows)          # RCCL over xGMI: the only collective
+            ens.gather(d_out_rows)                                     # RCCL all-gather over xGMI: the only collective
 
     def barrier():
         if world > 1:

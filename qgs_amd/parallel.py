@@ -1,0 +1,114 @@
+"""Multi-GPU ensembles: one process per GPU, members sharded, one final gather.
+
+The reference's only parallelism is one task per trajectory handed to `multiprocessing` workers through
+pickling queues (qgs/integrators/integrator.py:133-142, 388-395).  Ensemble members never interact, so
+here every rank (one process per GPU, `torch.distributed`, backend "nccl" = RCCL over xGMI) integrates a
+contiguous block of members with the HIP engine and the only communication is the final gather of the
+results.  Nothing in the data path needs a collective.
+
+PyTorch is used for process-group plumbing and device buffers only.
+"""
+import numpy as np
+
+
+def shard_bounds(n_total, world_size):
+    """Contiguous blocks of members per rank, remainder to the first ranks: list of (start, stop)."""
+    base, rem = divmod(int(n_total), int(world_size))
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < rem else 0)
+        out.append((start, start + n))
+        start += n
+    return out
+
+
+class ShardedEnsemble(object):
+    """Bookkeeping of an ensemble of `n_total` members split over the ranks of a process group."""
+
+    def __init__(self, n_total, process_group=None):
+        import torch.distributed as dist
+        self._dist = dist
+        self.group = process_group
+        if dist.is_available() and dist.is_initialized():
+            self.rank = dist.get_rank(process_group)
+            self.world_size = dist.get_world_size(process_group)
+        else:
+            self.rank, self.world_size = 0, 1
+        self.n_total = int(n_total)
+        self.bounds = shard_bounds(self.n_total, self.world_size)
+        self.counts = [b - a for a, b in self.bounds]
+
+    @property
+    def local_slice(self):
+        a, b = self.bounds[self.rank]
+        return slice(a, b)
+
+    @property
+    def n_local(self):
+        return self.counts[self.rank]
+
+    def gather(self, local):
+        """All-gather the per-rank results (a torch tensor whose first axis is the local member axis) into the
+        full ensemble, in member order, on every rank.  Equal shards take the single-buffer fast path
+        (`all_gather_into_tensor`, one RCCL call); ragged shards are padded to the largest shard."""
+        import torch
+        dist = self._dist
+        if self.world_size == 1:
+            return local
+        local = local.contiguous()
+        if len(set(self.counts)) == 1:
+            out = torch.empty((self.n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(out, local, group=self.group)
+            return out
+        nmax = max(self.counts)
+        padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+        parts = [torch.empty_like(padded) for _ in range(self.world_size)]
+        dist.all_gather(parts, padded, group=self.group)
+        return torch.cat([p[:n] for p, n in zip(parts, self.counts)], dim=0)
+
+
+def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=None, a=None, process_group=None,
+                       device=None, integrator_factory=None):
+    """Integrate a (n_traj, n_dim) ensemble sharded over the ranks of `process_group`; every rank returns the
+    full ``(time, traj)`` with traj of shape (n_traj, n_dim, n_records) (not squeezed).
+
+    Each rank integrates `ic[shard]` on its own GPU through `RungeKuttaIntegrator` and the trajectories are
+    gathered once at the end.  `integrator_factory` is a test seam: a callable returning an object with the
+    `RungeKuttaIntegrator` interface.
+    """
+    import torch
+    ic = np.asarray(ic, dtype=np.float64)
+    if ic.ndim == 1:
+        ic = ic.reshape((1, -1))
+    ens = ShardedEnsemble(ic.shape[0], process_group)
+    if integrator_factory is None:
+        from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+        integ = RungeKuttaIntegrator(b=b, c=c, a=a)
+    else:
+        integ = integrator_factory(b=b, c=c, a=a)
+    integ.set_func(f)
+    local_ic = np.ascontiguousarray(ic[ens.local_slice])
+    time = None
+    if ens.n_local > 0:
+        integ.integrate(t0, t, dt, ic=local_ic, forward=forward, write_steps=write_steps)
+        time, _ = integ.get_trajectories()
+        local = np.asarray(integ._recorded_traj)
+    else:
+        local = np.zeros((0, ic.shape[1], 1))
+    integ.terminate()
+    if ens.world_size == 1:
+        return time, local
+    if device is None:
+        backend = ens._dist.get_backend(process_group)
+        device = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    # ranks with an empty shard still need the record count for the gather buffer
+    nrec = torch.tensor([local.shape[2] if ens.n_local > 0 else 0], dtype=torch.int64, device=device)
+    ens._dist.all_reduce(nrec, op=ens._dist.ReduceOp.MAX, group=process_group)
+    if ens.n_local == 0:
+        local = np.zeros((0, ic.shape[1], int(nrec.item())))
+    full = ens.gather(torch.from_numpy(np.ascontiguousarray(local)).to(device))
+    if time is None:
+        from qgs_amd.integrators.integrate import record_times, time_grid
+        time = record_times(time_grid(t0, t, dt), write_steps, forward)
+    return time, full.cpu().numpy()

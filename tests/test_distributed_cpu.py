@@ -1,0 +1,82 @@
+"""CPU, world_size 2, gloo: the multi-GPU path (member sharding + final gather) with the per-rank engine
+replaced by an oracle-backed stand-in (the HIP engine needs a GPU; sharding / gathering does not)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import RK4, load_golden
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+class _OracleIntegrator(object):
+    """RungeKuttaIntegrator interface on top of the CPU oracle (test seam of integrate_ensemble)."""
+
+    def __init__(self, b=None, c=None, a=None):
+        self.b, self.c, self.a = (RK4['b'], RK4['c'], RK4['a']) if b is None else (b, c, a)
+        self._recorded_traj = None
+
+    def set_func(self, f):
+        from oracle.oracle import OracleModel
+        self._m = OracleModel(f.ndim, f.coo, f.val)
+
+    def integrate(self, t0, t, dt, ic=None, forward=True, write_steps=1):
+        from qgs_amd.integrators.integrate import time_grid
+        self._time, self._ws, self._fw = time_grid(t0, t, dt), write_steps, forward
+        self._recorded_traj = self._m.integrate_runge_kutta_jit(self._time, ic, 1 if forward else -1, write_steps,
+                                                                self.b, self.c, self.a)
+
+    def get_trajectories(self):
+        from qgs_amd.integrators.integrate import record_times
+        return record_times(self._time, self._ws, self._fw), np.squeeze(self._recorded_traj)
+
+    def terminate(self):
+        pass
+
+
+def _worker(rank, world, port, n_traj, write_steps, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.parallel import integrate_ensemble, ShardedEnsemble
+    g = load_golden('a36')
+    f, _ = tendencies_from_tensor(g.ndim, g['coo'], g['val'])
+    ic = np.random.RandomState(0).rand(n_traj, g.ndim) * 0.01
+    ens = ShardedEnsemble(n_traj)
+    assert ens.rank == rank and sum(ens.counts) == n_traj
+    time, traj = integrate_ensemble(f, 0., 1., 0.1, ic, write_steps=write_steps, integrator_factory=_OracleIntegrator)
+    np.savez(os.path.join(out_dir, 'r%d.npz' % rank), time=np.asarray(time), traj=traj)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_traj,write_steps', [(8, 0), (7, 3), (1, 1)])
+def test_sharded_ensemble_gloo_world2(tmp_path, n_traj, write_steps):
+    import torch.multiprocessing as mp
+    from oracle.oracle import OracleModel
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_traj, write_steps, str(tmp_path)), nprocs=2, join=True)
+    g = load_golden('a36')
+    ic = np.random.RandomState(0).rand(n_traj, g.ndim) * 0.01
+    from qgs_amd.integrators.integrate import time_grid
+    ref = OracleModel(g.ndim, g['coo'], g['val']).integrate_runge_kutta_jit(time_grid(0., 1., 0.1), ic, 1, write_steps,
+                                                                            RK4['b'], RK4['c'], RK4['a'])
+    for r in range(2):
+        z = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
+        assert z['traj'].shape == ref.shape
+        assert np.array_equal(z['traj'], ref)              # every rank holds the full, ordered ensemble
+
+
+def test_shard_bounds():
+    from qgs_amd.parallel import shard_bounds
+    assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert shard_bounds(1048576, 8) == [(i * 131072, (i + 1) * 131072) for i in range(8)]
+    assert shard_bounds(1, 2) == [(0, 1), (1, 1)]
