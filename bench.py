@@ -9,7 +9,7 @@ One bench "step" = one pass of the hot path over one batch: every rank takes its
 `--members` (default 65 536) synthetic initial conditions that are already resident in HBM in the
 reference's (n_traj, ndim) layout, packs them mode-major, integrates `--rk-steps` (default 1000) classic
 RK4 steps of MAOOAM 2x2/2x4 (36 variables, the qgs_maooam.py parameter set) with write_steps=0 in ONE
-fused HIP kernel, unpacks the final states to (n_traj, ndim) and (N>1) gathers them on rank 0 with RCCL.
+fused HIP kernel, unpacks the final states to (n_traj, ndim) and (N>1) all-gathers them with RCCL.
 Members are independent, so ranks shard them with no data-path collective except that final gather
 ("scaling": "weak": per-GPU work is fixed).
 
@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--rk-steps', type=int, default=1000, help='RK4 steps per pass')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'spec'], default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (plumbing check)')
     args = ap.parse_args()
 
     import torch
@@ -127,9 +128,11 @@ def main():
         sys.exit(1)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     from qgs_amd import _lib
 
@@ -166,11 +169,14 @@ def main():
             e1.record()
             kern_events.append((e0, e1))
         model.unpack_records(n_traj, ld, ndim, 1, d_rec.data_ptr(), d_out_rows.data_ptr(), stream)
-        if world > 1:
-            ens.gather(d_out_rows)                                     # RCCL all-gather over xGMI: the only collective
+        if use_dist:
+            if world > 1:
+                ens.gather(d_out_rows)                                 # RCCL all-gather over xGMI: the only collective
+            else:
+                dist.all_gather_into_tensor(torch.empty_like(d_out_rows), d_out_rows)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -184,7 +190,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     el_t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     elapsed = float(el_t.item())
 
@@ -237,7 +243,7 @@ def main():
                 print('bench.py: PARITY FAILURE vs oracle: %g' % err, file=sys.stderr)
                 result['value'] = 0.0
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
