@@ -15,11 +15,81 @@ namespace qgs {
 
 namespace {
 
-std::string lit(double v)
+std::string hexlit(double v)
 {
     char buf[64];
     std::snprintf(buf, sizeof buf, "%a", v);   // exact hex-float literal (C++17)
     return std::string(buf);
+}
+
+// Coefficient table mode: instead of a literal (two s_mov_b32 per use) a coefficient can be the next entry of
+// a __constant__ table that the kernel walks sequentially (fetched eight at a time by s_load_dwordx16).
+// Every stage emits the same rows in the same order, so one table per (kernel, wave partition) serves all stages.
+struct KTable {
+    std::vector<double> vals;
+    size_t cursor = 0;
+};
+thread_local KTable *g_ktab = nullptr;
+
+std::string lit(double v)
+{
+    if (!g_ktab) return hexlit(v);
+    return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
+}
+
+// Replace the @K<value>@ placeholders of one stage's text by sequential table references.
+std::string resolve_ktab(const std::string &text, KTable &t)
+{
+    std::string out;
+    t.cursor = 0;
+    size_t pos = 0;
+    while (true) {
+        size_t a = text.find("@K", pos);
+        if (a == std::string::npos) { out.append(text, pos, std::string::npos); break; }
+        size_t b = text.find('@', a + 2);
+        out.append(text, pos, a - pos);
+        const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
+        if (t.cursor == t.vals.size()) t.vals.push_back(v);
+        if (t.vals[t.cursor] == v) out += "kt[" + std::to_string(t.cursor++) + "]";
+        else out += hexlit(v);                // cannot happen: every stage emits the same sequence
+        pos = b + 1;
+    }
+    return out;
+}
+
+std::vector<std::string> split_lines(const std::string &text)
+{
+    std::vector<std::string> lines;
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t e = text.find('\n', pos);
+        if (e == std::string::npos) e = text.size();
+        lines.push_back(text.substr(pos, e - pos));
+        pos = e + 1;
+    }
+    return lines;
+}
+
+// Round-robin merge of independent statement lists: consecutive statements then belong to different rows,
+// i.e. to independent fp64 dependency chains (a lone v_fma_f64 chain issues every 9 cycles, independent
+// ones every 4-5.6).
+std::string interleave(const std::vector<std::vector<std::string>> &lists)
+{
+    std::string out;
+    size_t n = 0;
+    for (auto &l : lists) n = std::max(n, l.size());
+    for (size_t k = 0; k < n; ++k)
+        for (auto &l : lists)
+            if (k < l.size()) { out += l[k]; out += '\n'; }
+    return out;
+}
+
+void emit_ktable(std::ostringstream &o, const std::string &name, const KTable &t)
+{
+    o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << std::max<size_t>(1, t.vals.size()) << "] = {";
+    for (size_t n = 0; n < t.vals.size(); ++n) o << (n ? ", " : "") << hexlit(t.vals[n]);
+    if (t.vals.empty()) o << "0.0";
+    o << "};\n";
 }
 
 struct Bil { int j, k; double c; };
@@ -185,6 +255,7 @@ const char *PRELUDE = R"(// ---- generated by qgs_amd/csrc/codegen.cpp: tensor-s
 #endif
 typedef double f64;
 typedef long long i64;
+typedef const double __attribute__((address_space(4))) kf64;   // coefficient tables: scalar (s_load) fetches
 #define QGS_WAVE 64
 )";
 
@@ -243,9 +314,11 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // Fused S-stage explicit RK stepper for sub-diagonal tableaus, one member per lane, all state in
 // registers for the whole run.  Storage: y (step start), acc (running y + dt*sum b_i k_i),
 // xa/xb (ping-pong stage inputs).  k_i is consumed row by row as it is produced.
-void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
+void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
                     const CodegenOptions &opt)
 {
+    std::ostringstream o;
+    KTable table;
     const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : "qgs_spec_rk_s") + std::to_string(S);
     o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only") << "\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
@@ -277,7 +350,7 @@ void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &row
     if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
     for (int st = 0; st < S; ++st) {
         const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
-        const std::string out = (st % 2 == 0) ? "xa" : "xb";
+        const std::string outn = (st % 2 == 0) ? "xa" : "xb";
         const bool last = (st == S - 1);
         o << "        {   // stage " << st << "\n";
         o << "            const f64 hb = dt * tb" << st << ";\n";
@@ -287,13 +360,20 @@ void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &row
             for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
             o << "            }\n";
         }
-        for (int i = 1; i <= ndim; ++i) {
-            o << "            {\n";
-            emit_tend_row(o, "                ", rows[i], "r", names(in), opt, st * 1000 + i);
-            o << "                acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
-            if (!last) o << "                " << out << i << " = __builtin_fma(ha, r, y" << i << ");\n";
-            o << "            }\n";
+        if (opt.const_table) {
+            g_ktab = &table;
+            o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
         }
+        std::ostringstream so;
+        for (int i = 1; i <= ndim; ++i) {
+            so << "            {\n";
+            emit_tend_row(so, "                ", rows[i], "r", names(in), opt, st * 1000 + i);
+            so << "                acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
+            if (!last) so << "                " << outn << i << " = __builtin_fma(ha, r, y" << i << ");\n";
+            so << "            }\n";
+        }
+        o << (opt.const_table ? resolve_ktab(so.str(), table) : so.str());
+        g_ktab = nullptr;
         o << "        }\n";
     }
     for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = acc" << d << ";\n";
@@ -305,6 +385,8 @@ void emit_rk_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &row
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
     o << "        }\n    }\n}\n";
+    if (opt.const_table) emit_ktable(out, kname + "_kt", table);
+    out << o.str();
 }
 
 // Row-split variant of the fused stepper: a workgroup of R wavefronts shares 64 members; wave w evaluates
@@ -334,11 +416,13 @@ std::vector<int> partition_rows(int ndim, const std::vector<Row> &rows, int R, c
     return owner;
 }
 
-void emit_rk_split_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, int S, int R,
+void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, int R,
                           const CodegenOptions &opt)
 {
     const std::vector<int> owner = partition_rows(ndim, rows, R, opt);
     const std::string kname = "qgs_spec_rksplit" + std::to_string(R) + "_s" + std::to_string(S);
+    std::ostringstream o;                       // kernel text; the coefficient tables are emitted in front of it
+    std::vector<KTable> tables(R);
     o << "\n// " << S << "-stage RK, rows split over " << R << " wavefronts per 64 members (LDS exchange per stage)\n";
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * R << ", " << R << ") " << kname << "(\n"
       << "    const f64* __restrict__ y_in, f64* __restrict__ y_out, f64* __restrict__ rec, f64* __restrict__ stages,\n"
@@ -358,6 +442,7 @@ void emit_rk_split_kernel(std::ostringstream &o, int ndim, const std::vector<Row
         o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
         for (int i : own) o << " " << i;
         o << "\n";
+        if (opt.const_table) g_ktab = &tables[w];
         o << "        " << decl_list("y", ndim) << "\n";
         for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
         o << "        QGS_REC_INIT\n";
@@ -382,17 +467,31 @@ void emit_rk_split_kernel(std::ostringstream &o, int ndim, const std::vector<Row
             o << "                const f64 hb = dt * tb" << st << ";\n";
             if (!last) o << "                const f64 ha = dt * ta" << st << ";\n";
             o << "                const int pb = (par0 + " << st << ") & 1;\n";
-            for (int i : own) {
-                o << "                {\n";
-                emit_tend_row(o, "                    ", rows[i], "r", names(in), opt, w * 10000 + st * 100 + i);
-                o << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
-                if (!last) {
-                    o << "                    " << out << i << " = __builtin_fma(ha, r, y" << i << ");\n";
-                    o << "                    xs[pb][" << (i - 1) << "][lane] = " << out << i << ";\n";
-                } else {
-                    o << "                    xs[pb][" << (i - 1) << "][lane] = acc" << i << ";\n";
+            if (opt.const_table) {
+                o << "                kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
+            }
+            {
+                std::ostringstream so;
+                const int W = std::max(1, opt.interleave);
+                for (size_t c0 = 0; c0 < own.size(); c0 += W) {
+                    std::vector<std::vector<std::string>> lists;
+                    for (size_t q = c0; q < std::min(own.size(), c0 + W); ++q) {
+                        const int i = own[q];
+                        const std::string rn = "r" + std::to_string(i);
+                        std::ostringstream ro;
+                        emit_tend_row(ro, "                ", rows[i], rn, names(in), opt, w * 10000 + st * 100 + i);
+                        ro << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
+                        if (!last) {
+                            ro << "                " << out << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
+                            ro << "                xs[pb][" << (i - 1) << "][lane] = " << out << i << ";\n";
+                        } else {
+                            ro << "                xs[pb][" << (i - 1) << "][lane] = acc" << i << ";\n";
+                        }
+                        lists.push_back(split_lines(ro.str()));
+                    }
+                    so << interleave(lists);
                 }
-                o << "                }\n";
+                o << (opt.const_table ? resolve_ktab(so.str(), tables[w]) : so.str());
             }
             o << "                __syncthreads();\n";
             if (!last) {
@@ -410,15 +509,22 @@ void emit_rk_split_kernel(std::ostringstream &o, int ndim, const std::vector<Row
           << "                f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
         for (int d : own) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
         o << "            }\n        }\n    }\n";
+        g_ktab = nullptr;
     }
     o << "}\n";
+    if (opt.const_table)
+        for (int w = 0; w < R; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    out << o.str();
 }
 
 // Tangent-linear / adjoint propagation along stored stage states.  One lane per (member, column):
 // lane l = col*ld + member; tangent arrays are F[mode][col][member] = element d*(n_tg*ld) + l.
-void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vector<WX>> &tgl,
+void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
                      const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt)
 {
+    std::ostringstream o;
+    KTable tables[2];
+    const std::string kname = "qgs_spec_tgl_s" + std::to_string(S);
     o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") qgs_spec_tgl_s" << S << "(\n"
       << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
@@ -451,7 +557,7 @@ void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vec
     if (S > 2) o << "        " << decl_list("wb", ndim) << "\n";
     for (int st = 0; st < S; ++st) {
         const std::string in = (st == 0) ? "v" : ((st % 2 == 1) ? "wa" : "wb");
-        const std::string out = (st % 2 == 0) ? "wa" : "wb";
+        const std::string outn = (st % 2 == 0) ? "wa" : "wb";
         const bool last = (st == S - 1);
         o << "        {   // stage " << st << "\n";
         o << "            const f64 hb = dt * tb" << st << " * inverse;\n";      // inverse = +-1: exact
@@ -460,14 +566,21 @@ void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vec
         for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
         for (int pass = 0; pass < 2; ++pass) {
             o << "            if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
-            for (int i = 1; i <= ndim; ++i) {
-                o << "                {\n";
-                emit_wx_row(o, "                    ", pass == 0 ? tgl[i] : adj[i], "r", names("x"), names(in), opt,
-                            pass * 100000 + st * 1000 + i);
-                o << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "v" : "acc") << i << ");\n";
-                if (!last) o << "                    " << out << i << " = __builtin_fma(ha, r, v" << i << ");\n";
-                o << "                }\n";
+            if (opt.const_table) {
+                g_ktab = &tables[pass];
+                o << "                kf64* kt = (kf64*)" << kname << "_kt" << pass << "; asm volatile(\"\" : \"+s\"(kt));\n";
             }
+            std::ostringstream so;
+            for (int i = 1; i <= ndim; ++i) {
+                so << "                {\n";
+                emit_wx_row(so, "                    ", pass == 0 ? tgl[i] : adj[i], "r", names("x"), names(in), opt,
+                            pass * 100000 + st * 1000 + i);
+                so << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "v" : "acc") << i << ");\n";
+                if (!last) so << "                    " << outn << i << " = __builtin_fma(ha, r, v" << i << ");\n";
+                so << "                }\n";
+            }
+            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass]) : so.str());
+            g_ktab = nullptr;
             o << "            }\n";
         }
         o << "        }\n";
@@ -480,6 +593,9 @@ void emit_tgl_kernel(std::ostringstream &o, int ndim, const std::vector<std::vec
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * L] = v" << d << ";\n";
     o << "        }\n    }\n}\n";
+    if (opt.const_table)
+        for (int pass = 0; pass < 2; ++pass) emit_ktable(out, kname + "_kt" + std::to_string(pass), tables[pass]);
+    out << o.str();
 }
 
 }  // namespace

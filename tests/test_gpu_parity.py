@@ -176,3 +176,29 @@ def test_linearity_of_tangent_model(models):
         _, fm = m.rk_tgls_integrate(t, ic, tg, 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         fm = fm[..., 0]
         assert rel_err(fm[:, :, 2], 2.0 * fm[:, :, 0] - 3.0 * fm[:, :, 1]) < 1e-13, kind
+
+
+@pytest.mark.parametrize('env', [{'QGS_HIP_RK_VARIANT': 'plain'}, {'QGS_HIP_RK_VARIANT': 'split'},
+                                 {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '3'},
+                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}])
+def test_kernel_variants_agree_with_oracle(monkeypatch, env):
+    """Every code-generation / kernel-selection variant (plain one-wave stepper, row split 2 and 3, literal
+    coefficients, ungrouped terms, simple generic kernel) against the oracle on the same inputs."""
+    from qgs_amd import _lib
+    from oracle.oracle import OracleModel
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    g = load_golden('a36')
+    m = _lib.HipModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])      # env is read at model creation
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = np.random.RandomState(17).rand(130, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 3.0, 0.1), [3.0]))
+    ref = ora.integrate_runge_kutta_jit(t, ic, -1, 4, RK4['b'], RK4['c'], RK4['a'], threads=4)
+    tg = np.random.RandomState(18).randn(3, g.ndim, 2)
+    rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+    for kind in (1, 2):
+        m.set_kernel(kind)
+        assert rel_err(m.rk_integrate(t, ic, -1, 4, RK4['b'], RK4['c'], RK4['a']), ref) < 1e-12, (env, kind)
+        tr, fm = m.rk_tgls_integrate(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+        assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (env, kind)
+    m.close()
