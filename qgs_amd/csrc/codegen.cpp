@@ -598,6 +598,130 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     out << o.str();
 }
 
+// Row-split tangent / adjoint kernel: R wavefronts share 64 (member, column) lanes, each evaluates the rows
+// of its partition of (J w) or (J^T w) and the partitions exchange the new tangent stage vector through LDS
+// (one barrier per stage).  Per wave: x (full), w_in (full), and v / acc / w_out of the own rows only, which
+// brings the 444-VGPR single-wave kernel under 256 VGPRs, i.e. two wavefronts per SIMD.
+void emit_tgl_split_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
+                           const std::vector<std::vector<WX>> &adj, int S, int R, const CodegenOptions &opt)
+{
+    // partition by the combined tangent + adjoint cost of a row index
+    std::vector<std::pair<int64_t, int>> cost;
+    for (int i = 1; i <= ndim; ++i) cost.push_back({(int64_t)tgl[i].size() + (int64_t)adj[i].size(), i});
+    std::sort(cost.begin(), cost.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    std::vector<int64_t> load(R, 0);
+    std::vector<int> owner(ndim + 1, 0);
+    for (auto &ci : cost) {
+        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        owner[ci.second] = w;
+        load[w] += ci.first;
+    }
+    const std::string kname = "qgs_spec_tglsplit" + std::to_string(R) + "_s" + std::to_string(S);
+    std::ostringstream o;
+    std::vector<KTable> tables(2 * R);
+    o << "\n// tangent / adjoint model, rows split over " << R << " wavefronts per 64 lanes\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * R << ", 2) " << kname << "(\n"
+      << "    const f64* __restrict__ w_in_p, f64* __restrict__ w_out_p, f64* __restrict__ rec, const f64* __restrict__ stages,\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
+      << "    int backward, int write_final, int adjoint, f64 inverse)\n{\n";
+    o << "    __shared__ f64 xs[2][" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x & 63;\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+      << "    const i64 L = n_tg * ld;\n"
+      << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
+      << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
+      << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
+      << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
+    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
+    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    for (int w = 0; w < R; ++w) {
+        std::vector<int> own, other;
+        for (int i = 1; i <= ndim; ++i) (owner[i] == w ? own : other).push_back(i);
+        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {\n";
+        o << "        " << decl_list("v", ndim) << "\n";
+        for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
+        o << "        QGS_REC_INIT\n";
+        o << "        for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << "            const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+        o << "            const int par0 = (int)(((ti - step_begin) * " << S << ") & 1);\n";
+        o << "            if (ti == next_rec) {\n"
+          << "                f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * L + l;\n"
+          << "                ++iw; next_rec += write_steps;\n"
+          << "                if (live) {\n";
+        for (int d : own) o << "                    p[" << (d - 1) << " * L] = v" << d << ";\n";
+        o << "                }\n            }\n";
+        o << "            f64 ";
+        for (size_t n = 0; n < own.size(); ++n) o << "acc" << own[n] << (n + 1 < own.size() ? ", " : ";\n");
+        if (S > 1) o << "            " << decl_list("wa", ndim) << "\n";
+        if (S > 2) o << "            " << decl_list("wb", ndim) << "\n";
+        for (int st = 0; st < S; ++st) {
+            const std::string in = (st == 0) ? "v" : ((st % 2 == 1) ? "wa" : "wb");
+            const std::string outn = (st % 2 == 0) ? "wa" : "wb";
+            const bool last = (st == S - 1);
+            o << "            {   // stage " << st << "\n";
+            o << "                const f64 hb = dt * tb" << st << " * inverse;\n";
+            if (!last) o << "                const f64 ha = dt * ta" << st << " * inverse;\n";
+            o << "                const int pb = (par0 + " << st << ") & 1;\n";
+            o << "                const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+            for (int d = 1; d <= ndim; ++d) o << "                const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+            for (int pass = 0; pass < 2; ++pass) {
+                o << "                if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
+                KTable &tb = tables[2 * w + pass];
+                if (opt.const_table) {
+                    g_ktab = &tb;
+                    o << "                    kf64* kt = (kf64*)" << kname << "_kt" << (2 * w + pass) << "; asm volatile(\"\" : \"+s\"(kt));\n";
+                }
+                std::ostringstream so;
+                const int W = std::max(1, opt.interleave);
+                for (size_t c0 = 0; c0 < own.size(); c0 += W) {
+                    std::vector<std::vector<std::string>> lists;
+                    for (size_t q = c0; q < std::min(own.size(), c0 + W); ++q) {
+                        const int i = own[q];
+                        const std::string rn = "r" + std::to_string(i);
+                        std::ostringstream ro;
+                        emit_wx_row(ro, "                    ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
+                                    w * 1000000 + pass * 100000 + st * 1000 + i);
+                        ro << "                    acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
+                        if (!last) {
+                            ro << "                    " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
+                            ro << "                    xs[pb][" << (i - 1) << "][lane] = " << outn << i << ";\n";
+                        } else {
+                            ro << "                    xs[pb][" << (i - 1) << "][lane] = acc" << i << ";\n";
+                        }
+                        lists.push_back(split_lines(ro.str()));
+                    }
+                    so << interleave(lists);
+                }
+                o << (opt.const_table ? resolve_ktab(so.str(), tb) : so.str());
+                g_ktab = nullptr;
+                o << "                }\n";
+            }
+            o << "                __syncthreads();\n";
+            if (!last) {
+                for (int j : other) o << "                " << outn << j << " = xs[pb][" << (j - 1) << "][lane];\n";
+            } else {
+                for (int i : own) o << "                v" << i << " = acc" << i << ";\n";
+                for (int j : other) o << "                v" << j << " = xs[pb][" << (j - 1) << "][lane];\n";
+            }
+            o << "            }\n";
+        }
+        o << "        }\n";
+        o << "        if (live) {\n            if (w_out_p) {\n";
+        for (int d : own) o << "                w_out_p[" << (d - 1) << " * L + l] = v" << d << ";\n";
+        o << "            }\n            if (write_final) {\n"
+          << "                f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
+        for (int d : own) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
+        o << "            }\n        }\n    }\n";
+    }
+    o << "}\n";
+    if (opt.const_table)
+        for (int t = 0; t < 2 * R; ++t) emit_ktable(out, kname + "_kt" + std::to_string(t), tables[t]);
+    out << o.str();
+}
+
 }  // namespace
 
 bool tableau_is_subdiagonal(int s, const double *a)
@@ -625,6 +749,7 @@ std::string generate_source(int ndim, const std::vector<Term> &tensor, const std
         if (!jac_tensor.empty()) {
             emit_rk_kernel(o, ndim, rows, S, true, opt);
             emit_tgl_kernel(o, ndim, tgl, adj, S, opt);
+            if (opt.tgl_split > 1) emit_tgl_split_kernel(o, ndim, tgl, adj, S, opt.tgl_split, opt);
         }
     }
     return o.str();

@@ -368,6 +368,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_NO_GROUP")) if (*e == '1') cg.group_coeff = false;
     if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_KTAB")) cg.const_table = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
 }
 
@@ -704,7 +705,12 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         const double *w_src = first ? d_tg_ic : w_state;
         if (spec) {
             hipFunction_t f1, f2;
-            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s), n2 = "qgs_spec_tgl_s" + std::to_string(s);
+            // row-split tangent kernel (R wavefronts per 64 lanes, 2 waves per SIMD) unless disabled
+            bool tgl_split = m->cg.tgl_split > 1;
+            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
+            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s);
+            const std::string n2 = tgl_split ? "qgs_spec_tglsplit" + std::to_string(m->cg.tgl_split) + "_s" + std::to_string(s)
+                                             : "qgs_spec_tgl_s" + std::to_string(s);
             if (get_function(m, s, n1, &f1) || get_function(m, s, n2, &f2)) return -1;
             long long nt = n_traj, l = ld, sb = begin, se = end, ws = write_steps, nr = n_records, ntg = n_tg;
             int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
@@ -715,7 +721,9 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
-            if (launch(f2, L, st, a2)) return -1;
+            if (tgl_split) {
+                HIPCHK(hipModuleLaunchKernel(f2, (unsigned)((L + 63) / 64), 1, 1, 64 * m->cg.tgl_split, 1, 1, 0, st, a2, nullptr));
+            } else if (launch(f2, L, st, a2)) return -1;
         } else {
             qgs::RkArgs p{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
             if (use_tiled(m, s, a))
