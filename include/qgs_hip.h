@@ -118,6 +118,12 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
                                  int adjoint, double inverse,
                                  double *d_rec, double *d_rec_fm, void *stream);
 
+/* Batched QR of one (n_rows x n_cols) matrix per member, device layout A[row][col][member]: A is replaced by Q
+ * (LAPACK Householder sign convention), d_rdiag[col][member] receives diag(R).  Replaces the per-trajectory
+ * `np.linalg.qr` of the Benettin loops, qgs/toolbox/lyapunov.py:540-547, 599-628. */
+int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_cols,
+                          double *d_a, double *d_rdiag, void *stream);
+
 /* Name, VGPR/SGPR/LDS/scratch use of the kernel the last *_device call launched (for profiling
  * reports).  Any pointer may be NULL. */
 int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,

@@ -41,6 +41,7 @@ SIGNATURES = {
     'qgs_rk_integrate_device': (_int, [_vp, _i64, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp, _vp]),
     'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
                                             _f64p, _int, _dbl, _vp, _vp, _vp]),
+    'qgs_batched_qr_device': (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
     'qgs_last_kernel_info': (_int, [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
                                     ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
@@ -222,6 +223,9 @@ class HipModel(object):
         time, b, c, a = _c(time), _c(b), _c(c), _c(a)
         _check(lib().qgs_rk_integrate_device(self._h, n_traj, ld, d_ic, time, len(time), int(time_direction),
                                              int(write_steps), len(b), b, c, a, d_rec, stream or None))
+
+    def batched_qr_device(self, n_traj, ld, n_rows, n_cols, d_a, d_rdiag, stream=0):
+        _check(lib().qgs_batched_qr_device(self._h, n_traj, ld, int(n_rows), int(n_cols), d_a, d_rdiag, stream or None))
 
     def rk_tgls_integrate_device(self, n_traj, ld, n_tg, d_ic, d_tg_ic, time, time_direction, write_steps, b, c, a,
                                  adjoint, inverse, d_rec, d_rec_fm, stream=0):

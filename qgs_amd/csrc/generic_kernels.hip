@@ -295,6 +295,53 @@ hipError_t launch_tiled(const TiledTensor &T, const RkArgs &p, const double *y_i
     return hipGetLastError();
 }
 
+// ---- batched QR ------------------------------------------------------------------------------------------
+// One member per lane, matrix in global memory (coalesced over members), unblocked Householder.
+__global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
+                                                          double *__restrict__ a, double *__restrict__ rdiag,
+                                                          double *__restrict__ tau)
+{
+    const int64_t m = (int64_t)blockIdx.x * WAVE + threadIdx.x;
+    if (m >= n_traj) return;
+#define A_(i, c) a[((int64_t)(i) * n_cols + (c)) * ld + m]
+    const int k = n_cols < n_rows ? n_cols : n_rows;
+    for (int j = 0; j < k; ++j) {                                   // dgeqr2: H_j annihilates A[j+1:, j]
+        const double alpha = A_(j, j);
+        double xn2 = 0.0;
+        for (int i = j + 1; i < n_rows; ++i) { const double v = A_(i, j); xn2 = __builtin_fma(v, v, xn2); }
+        double t = 0.0, beta = alpha;
+        if (xn2 != 0.0) {                                           // dlarfg
+            beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha);
+            t = (beta - alpha) / beta;
+            const double scale = 1.0 / (alpha - beta);
+            for (int i = j + 1; i < n_rows; ++i) A_(i, j) *= scale;
+        }
+        tau[(int64_t)j * ld + m] = t;
+        rdiag[(int64_t)j * ld + m] = beta;
+        for (int c = j + 1; c < n_cols; ++c) {                      // dlarf: A[j:, c] -= tau * v * (v^T A[j:, c])
+            double w = A_(j, c);
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A_(i, j), A_(i, c), w);
+            w *= t;
+            A_(j, c) -= w;
+            for (int i = j + 1; i < n_rows; ++i) A_(i, c) = __builtin_fma(-w, A_(i, j), A_(i, c));
+        }
+    }
+    for (int j = k - 1; j >= 0; --j) {                              // dorg2r: accumulate Q in place
+        const double t = tau[(int64_t)j * ld + m];
+        for (int c = j + 1; c < n_cols; ++c) {                      // apply H_j to Q[j:, j+1:] with Q[j][j] taken as 1
+            double w = A_(j, c);
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A_(i, j), A_(i, c), w);
+            w *= t;
+            A_(j, c) -= w;
+            for (int i = j + 1; i < n_rows; ++i) A_(i, c) = __builtin_fma(-w, A_(i, j), A_(i, c));
+        }
+        for (int i = j + 1; i < n_rows; ++i) A_(i, j) *= -t;
+        A_(j, j) = 1.0 - t;
+        for (int i = 0; i < j; ++i) A_(i, j) = 0.0;
+    }
+#undef A_
+}
+
 // ---- layout conversion ----------------------------------------------------------------------
 // 64 members x 64 inner elements per block through an LDS tile so that both sides are coalesced.
 constexpr int TILE = 64;
@@ -371,6 +418,11 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
 {
     hipLaunchKernelGGL(gen_tgl_kernel, dim3(blocks_for(n_tg * p.ld, WAVE)), dim3(WAVE), 0, st, Jrow, p, n_tg, inverse, w_in,
                        w_out, rec, stages, work, dtime, tab_full);
+}
+
+void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *tau, hipStream_t st)
+{
+    hipLaunchKernelGGL(batched_qr_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, n_rows, n_cols, n_traj, ld, a, rdiag, tau);
 }
 
 bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }

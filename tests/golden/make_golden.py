@@ -322,6 +322,41 @@ def gen(name):
           flush=True)
 
 
+def gen_lyapunov(name):
+    """Benettin Lyapunov goldens (reference: qgs/toolbox/lyapunov.py:471-632, the jitted loops called
+    directly so that the np.random draw order is deterministic)."""
+    from qgs.toolbox.lyapunov import _compute_backward_lyap_jit, _compute_forward_lyap_jit
+    cfg = CONFIGS[name]
+    p = cfg['make']()
+    f, Df = create_tendencies(p)
+    ndim = p.ndim
+    out = {'ndim': np.int64(ndim)}
+    ic = np.random.RandomState(4242).rand(2, ndim) * cfg['ic_scale']
+    out['ic'] = ic
+    t0, tw, t, dt, mdt = 0., 0.5, 1.0, 0.1, 0.02
+    pretime = np.concatenate((np.arange(t0, tw, dt), np.full((1,), tw)))
+    time = np.concatenate((np.arange(tw, t, dt), np.full((1,), t)))
+    out['pretime'], out['time'], out['mdt'] = pretime, time, np.float64(mdt)
+    cases = []
+    for tag, forward, ws, n_vec, adjoint, inverse in [('b_w1_full', False, 1, ndim, False, False),
+                                                      ('b_w2_v5', False, 2, 5, False, False),
+                                                      ('b_w0_v3', False, 0, 3, False, False),
+                                                      ('f_w1_full', True, 1, ndim, False, False),
+                                                      ('f_w2_v5', True, 2, 5, False, False),
+                                                      ('b_w1_v4_adj', False, 1, 4, True, False),
+                                                      ('f_w1_v4_adj_inv', True, 1, 4, True, True)]:
+        np.random.seed(1234)
+        fn = _compute_forward_lyap_jit if forward else _compute_backward_lyap_jit
+        rt, re, rv = fn(f, Df, pretime, time, mdt, ic, n_vec, ws, adjoint, -1. if inverse else 1., RK4['b'], RK4['c'], RK4['a'])
+        out['%s_traj' % tag], out['%s_exp' % tag], out['%s_vec' % tag] = rt, re, rv
+        cases.append(dict(tag=tag, forward=forward, ws=ws, n_vec=int(n_vec), adjoint=adjoint, inverse=inverse, seed=1234))
+    out['meta_json'] = np.frombuffer(json.dumps({'cases': cases, 't0': t0, 'tw': tw, 't': t, 'dt': dt, 'mdt': mdt}).encode(),
+                                     dtype=np.uint8)
+    path = os.path.join(HERE, 'lyap_' + name + '.npz')
+    np.savez_compressed(path, **out)
+    print('[lyap %s] wrote %s (%.1f KB)' % (name, path, os.path.getsize(path) / 1024.), flush=True)
+
+
 def copy_ref_data():
     """gzip copies of the reference tests' own DATA files (model_test/*.ref)."""
     dst = os.path.join(HERE, 'ref')
@@ -334,7 +369,11 @@ def copy_ref_data():
 
 
 if __name__ == '__main__':
-    names = sys.argv[1:] or list(CONFIGS)
+    names = sys.argv[1:] or (list(CONFIGS) + ['lyap'])
     copy_ref_data()
     for nm in names:
-        gen(nm)
+        if nm == 'lyap':
+            gen_lyapunov('rp20')
+            gen_lyapunov('m36')
+        else:
+            gen(nm)

@@ -1,0 +1,60 @@
+"""GPU: Benettin Lyapunov estimator (qgs_amd/toolbox/lyapunov.py) against goldens captured from the reference's
+jitted loops (qgs/toolbox/lyapunov.py:471-632) with the same np.random seed, and the batched QR kernel against
+np.linalg.qr."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batched_qr_matches_lapack():
+    import torch
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    f, _ = tendencies_from_tensor(2, np.array([[1, 0, 1]], dtype=np.int32), np.array([1.0]))
+    m = f.hip_model()
+    rng = np.random.RandomState(0)
+    for n_rows, n_cols, n in ((36, 36, 70), (20, 5, 3), (7, 1, 64)):
+        a = rng.randn(n, n_rows, n_cols)
+        ld = (n + 63) // 64 * 64
+        d = torch.zeros((n_rows, n_cols, ld), dtype=torch.float64, device='cuda')
+        d[:, :, :n] = torch.from_numpy(np.ascontiguousarray(a.transpose(1, 2, 0))).cuda()
+        rd = torch.zeros((n_cols, ld), dtype=torch.float64, device='cuda')
+        m.batched_qr_device(n, ld, n_rows, n_cols, d.data_ptr(), rd.data_ptr())
+        q = d[:, :, :n].cpu().numpy().transpose(2, 0, 1)
+        r_diag = rd[:, :n].cpu().numpy().T
+        for i in range(n):
+            qr, rr = np.linalg.qr(a[i])
+            assert np.abs(q[i] - qr).max() < 1e-13 and np.abs(r_diag[i] - np.diag(rr)).max() < 1e-13
+    f.operands.release()
+
+
+@pytest.mark.parametrize('name', ['rp20', 'm36'])
+def test_lyapunov_estimator_vs_reference(name):
+    from model_configs import MAKERS
+    from qgs_amd.functions.tendencies import create_tendencies
+    from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
+    g = np.load(os.path.join(GOLDEN_DIR, 'lyap_%s.npz' % name))
+    meta = json.loads(bytes(g['meta_json']).decode())
+    f, Df = create_tendencies(MAKERS[name]())
+    est = LyapunovsEstimator(num_threads=1)
+    est.set_func(f, Df)
+    for cs in meta['cases']:
+        np.random.seed(cs['seed'])
+        est.compute_lyapunovs(meta['t0'], meta['tw'], meta['t'], meta['dt'], meta['mdt'], ic=g['ic'], write_steps=cs['ws'],
+                              n_vec=cs['n_vec'], forward=cs['forward'], adjoint=cs['adjoint'], inverse=cs['inverse'])
+        tt, traj, exps, vecs = est.get_lyapunovs()
+        tag = cs['tag']
+        assert rel_err(traj, np.squeeze(g[tag + '_traj'])) < 1e-12, tag
+        assert rel_err(vecs, np.squeeze(g[tag + '_vec'])) < 1e-9, tag
+        assert np.abs(exps - np.squeeze(g[tag + '_exp'])).max() < 1e-8 * max(1.0, np.abs(g[tag + '_exp']).max()), tag
+        grid = g['pretime'] if cs['forward'] else g['time']
+        if cs['ws'] > 0:
+            assert np.shape(tt)[0] == traj.shape[-1]
+        else:
+            assert tt == grid[-1]
+    est.terminate()
