@@ -50,7 +50,7 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
 
 // ---- tiled generic stepper ------------------------------------------------------------------------
 // Tensor re-laid for the tiled kernel: a flat stream of terms per output row, padded with zero terms to a
-// multiple of 4 so that one s_load_dwordx4 + s_load_dwordx4 + s_load_dwordx8 feeds four terms:
+// multiple of 4 (small rows) or 16 (long rows) so that one round of wide scalar loads feeds a whole trip:
 //     dx_i = sum_terms c * x_j * x_k ,      x_0 = 1 lives in LDS slot 0.
 // Offsets are LDS byte offsets of the 64-lane slots (index * 512).
 struct TiledTensor {
@@ -58,6 +58,9 @@ struct TiledTensor {
     const uint32_t *term_joff; // n_terms : j * 512
     const uint32_t *term_koff; // n_terms : k * 512
     const double *term_c;      // n_terms
+    int terms_per_trip;        // 4 or 16: rows are padded to a multiple of it
+    const int32_t *row_map;    // 16 * rpw : tensor row of (wavefront, slot), 0 = empty; balanced by term count
+    int rpw;                   // rows per wavefront the map was built for (2, 4, 8 or 16)
 };
 
 // True if the tiled kernel can run this problem (sub-diagonal tableau is checked by the caller).

@@ -171,7 +171,7 @@ typedef __attribute__((address_space(4))) const double cf64;
 typedef __attribute__((address_space(4))) const u32x4 cu32x4;
 typedef __attribute__((address_space(4))) const f64x4 cf64x4;
 
-template <int RPW>
+template <int RPW, int TPI>
 __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor T, RkArgs p, const double *__restrict__ y_in,
                                                                       double *__restrict__ y_out, double *__restrict__ rec,
                                                                       double *__restrict__ stages,
@@ -186,7 +186,9 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
     const int64_t m = live ? m0 : p.n_traj - 1;
     const int ndim = p.ndim, s = p.s;
     const int64_t ld = p.ld, A = (int64_t)ndim * ld;
-    const int row0 = wave * RPW + 1;                       // first own row (1-based tensor index)
+    // own rows: slot r of this wavefront evaluates tensor row row_map[wave*RPW + r] (0 = empty slot); the map
+    // balances the number of terms per wavefront (rows have 16-237 terms at MAOOAM 6x6)
+    const ci32 *row_map = (const ci32 *)T.row_map + wave * RPW;
     const uint32_t lane8 = (uint32_t)lane * 8u;
     char *xs = smem;                                       // slot r at byte r*512, lane l at +l*8
     // the tensor stream is read-only for the whole launch: constant address space => scalar (s_load) fetches
@@ -194,13 +196,16 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
     const cu32 *term_joff = (const cu32 *)T.term_joff;
     const cu32 *term_koff = (const cu32 *)T.term_koff;
     const cf64 *term_c = (const cf64 *)T.term_c;
+    int rows[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) rows[r] = row_map[r];
 
     double y[RPW], acc[RPW], xn[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-        const int row = row0 + r;
-        y[r] = (row <= ndim) ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
-        if (row <= ndim) *(double *)(xs + (uint32_t)row * 512u + lane8) = y[r];
+        const int row = rows[r];
+        y[r] = row ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
+        if (row) *(double *)(xs + (uint32_t)row * 512u + lane8) = y[r];
     }
     if (wave == 0) *(double *)(xs + lane8) = 1.0;          // eta_0 = 1
     __syncthreads();
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
             ++iw; next_rec += p.write_steps;
             if (live) {
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) if (row0 + r <= ndim) q[(int64_t)(row0 + r - 1) * ld] = y[r];
+                for (int r = 0; r < RPW; ++r) if (rows[r]) q[(int64_t)(rows[r] - 1) * ld] = y[r];
             }
         }
 #pragma unroll
@@ -227,26 +232,43 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
                 double *sp = stages + ((ti - p.step_begin) * s + st) * A + m;
 #pragma unroll
                 for (int r = 0; r < RPW; ++r)
-                    if (row0 + r <= ndim) sp[(int64_t)(row0 + r - 1) * ld] = *(double *)(xs + (uint32_t)(row0 + r) * 512u + lane8);
+                    if (rows[r]) sp[(int64_t)(rows[r] - 1) * ld] = *(double *)(xs + (uint32_t)rows[r] * 512u + lane8);
             }
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int row = row0 + r;
-                if (row <= ndim) {
+                const int row = rows[r];
+                if (row) {
                     double k0 = 0.0, k1 = 0.0;               // two partial sums: independent FMA chains
                     const int t1 = row_term[row + 1];
-                    for (int t = row_term[row]; t < t1; t += 4) {
-                        const u32x4 jo = *(const cu32x4 *)(term_joff + t);
-                        const u32x4 ko = *(const cu32x4 *)(term_koff + t);
-                        const f64x4 cc = *(const cf64x4 *)(term_c + t);
-                        const double xj0 = *(const double *)(xs + jo.x + lane8), xk0 = *(const double *)(xs + ko.x + lane8);
-                        const double xj1 = *(const double *)(xs + jo.y + lane8), xk1 = *(const double *)(xs + ko.y + lane8);
-                        const double xj2 = *(const double *)(xs + jo.z + lane8), xk2 = *(const double *)(xs + ko.z + lane8);
-                        const double xj3 = *(const double *)(xs + jo.w + lane8), xk3 = *(const double *)(xs + ko.w + lane8);
-                        k0 = __builtin_fma(cc.x, xj0 * xk0, k0);
-                        k1 = __builtin_fma(cc.y, xj1 * xk1, k1);
-                        k0 = __builtin_fma(cc.z, xj2 * xk2, k0);
-                        k1 = __builtin_fma(cc.w, xj3 * xk3, k1);
+                    for (int t = row_term[row]; t < t1; t += TPI) {
+                        // TPI terms per trip: one round of scalar loads (j offsets, k offsets, coefficients) ...
+                        u32x4 jo[TPI / 4], ko[TPI / 4];
+                        f64x4 cc[TPI / 4];
+#pragma unroll
+                        for (int q = 0; q < TPI / 4; ++q) {
+                            jo[q] = *(const cu32x4 *)(term_joff + t + 4 * q);
+                            ko[q] = *(const cu32x4 *)(term_koff + t + 4 * q);
+                            cc[q] = *(const cf64x4 *)(term_c + t + 4 * q);
+                        }
+                        // ... then the LDS reads and the FMAs, eight terms (16 ds_read_b64) at a time
+#pragma unroll
+                        for (int h = 0; h < TPI / 4; h += 2) {
+                            double xj[8], xk[8];
+#pragma unroll
+                            for (int q = 0; q < 2 && h + q < TPI / 4; ++q) {
+                                xj[4 * q + 0] = *(const double *)(xs + jo[h + q].x + lane8); xk[4 * q + 0] = *(const double *)(xs + ko[h + q].x + lane8);
+                                xj[4 * q + 1] = *(const double *)(xs + jo[h + q].y + lane8); xk[4 * q + 1] = *(const double *)(xs + ko[h + q].y + lane8);
+                                xj[4 * q + 2] = *(const double *)(xs + jo[h + q].z + lane8); xk[4 * q + 2] = *(const double *)(xs + ko[h + q].z + lane8);
+                                xj[4 * q + 3] = *(const double *)(xs + jo[h + q].w + lane8); xk[4 * q + 3] = *(const double *)(xs + ko[h + q].w + lane8);
+                            }
+#pragma unroll
+                            for (int q = 0; q < 2 && h + q < TPI / 4; ++q) {
+                                k0 = __builtin_fma(cc[h + q].x, xj[4 * q + 0] * xk[4 * q + 0], k0);
+                                k1 = __builtin_fma(cc[h + q].y, xj[4 * q + 1] * xk[4 * q + 1], k1);
+                                k0 = __builtin_fma(cc[h + q].z, xj[4 * q + 2] * xk[4 * q + 2], k0);
+                                k1 = __builtin_fma(cc[h + q].w, xj[4 * q + 3] * xk[4 * q + 3], k1);
+                            }
+                        }
                     }
                     const double k = k0 + k1;
                     acc[r] = __builtin_fma(hb, k, acc[r]);
@@ -257,8 +279,8 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
             const bool last = (st == s - 1);
 #pragma unroll
             for (int r = 0; r < RPW; ++r) {
-                const int row = row0 + r;
-                if (row <= ndim) {
+                const int row = rows[r];
+                if (row) {
                     const double v = last ? acc[r] : xn[r];
                     *(double *)(xs + (uint32_t)row * 512u + lane8) = v;
                     if (last) y[r] = acc[r];
@@ -270,8 +292,8 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
     if (live) {
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
-            const int row = row0 + r;
-            if (row <= ndim) {
+            const int row = rows[r];
+            if (row) {
                 if (y_out) y_out[(int64_t)(row - 1) * ld + m] = y[r];
                 if (p.write_final) rec[rec_index(p.n_records - 1, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y[r];
             }
@@ -279,18 +301,18 @@ __global__ void __launch_bounds__(64 * TILED_NW) gen_rk_tiled_kernel(TiledTensor
     }
 }
 
-template <int RPW>
+template <int RPW, int TPI>
 hipError_t launch_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
                         const double *dtime, const double *tab, hipStream_t st)
 {
     const size_t lds = (size_t)(p.ndim + 1) * 512;
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void *)gen_rk_tiled_kernel<RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)gen_rk_tiled_kernel<RPW, TPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(gen_rk_tiled_kernel<RPW>, dim3(blocks_for(p.n_traj, WAVE)), dim3(64 * TILED_NW), lds, st, T, p, y_in, y_out,
+    hipLaunchKernelGGL((gen_rk_tiled_kernel<RPW, TPI>), dim3(blocks_for(p.n_traj, WAVE)), dim3(64 * TILED_NW), lds, st, T, p, y_in, y_out,
                        rec, stages, dtime, tab);
     return hipGetLastError();
 }
@@ -430,11 +452,15 @@ bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }
 hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec,
                                double *stages, const double *dtime, const double *tab_spec, hipStream_t st)
 {
-    const int rpw = (p.ndim + TILED_NW - 1) / TILED_NW;
-    if (rpw <= 2) return launch_tiled<2>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
-    if (rpw <= 4) return launch_tiled<4>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
-    if (rpw <= 8) return launch_tiled<8>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
-    if (rpw <= 16) return launch_tiled<16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    const int rpw = T.rpw;
+#define QGS_TILED_CASE(R)                                                                                   \
+    if (rpw == R) return T.terms_per_trip == 16 ? launch_tiled<R, 16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st) \
+                                                : launch_tiled<R, 4>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);
+    QGS_TILED_CASE(2)
+    QGS_TILED_CASE(4)
+    QGS_TILED_CASE(8)
+    QGS_TILED_CASE(16)
+#undef QGS_TILED_CASE
     return hipErrorInvalidValue;
 }
 

@@ -203,7 +203,12 @@ struct qgs_model {
     int32_t *t_row_term = nullptr;
     uint32_t *t_term_joff = nullptr, *t_term_koff = nullptr;
     double *t_term_c = nullptr;
-    qgs::TiledTensor tiled() const { return qgs::TiledTensor{t_row_term, t_term_joff, t_term_koff, t_term_c}; }
+    int t_terms_per_trip = 4, t_rpw = 16;
+    int32_t *t_row_map = nullptr;
+    qgs::TiledTensor tiled() const
+    {
+        return qgs::TiledTensor{t_row_term, t_term_joff, t_term_koff, t_term_c, t_terms_per_trip, t_row_map, t_rpw};
+    }
     int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
@@ -253,6 +258,10 @@ int upload_tiled(qgs_model *m, const std::vector<qgs::Term> &Tr)
     std::vector<int32_t> row_term(ndim + 2, 0);
     std::vector<uint32_t> joff, koff;
     std::vector<double> c;
+    // long rows (MAOOAM 6x6: ~120 terms) take 16 terms per loop trip to amortise the scalar-load latency
+    const size_t pad = (Tr.size() >= (size_t)32 * ndim) ? 16 : 4;
+    if (const char *e = std::getenv("QGS_HIP_TILED_TPI")) m->t_terms_per_trip = (std::atoi(e) == 16) ? 16 : 4;
+    else m->t_terms_per_trip = (int)pad;
     for (int i = 0; i <= ndim; ++i) {
         row_term[i] = (int32_t)c.size();
         for (const qgs::Term *t : by_row[i]) {
@@ -260,9 +269,32 @@ int upload_tiled(qgs_model *m, const std::vector<qgs::Term> &Tr)
             koff.push_back((uint32_t)t->k * 512u);
             c.push_back(t->v);
         }
-        while (c.size() % 4) { joff.push_back(0); koff.push_back(0); c.push_back(0.0); }
+        while (c.size() % (size_t)m->t_terms_per_trip) { joff.push_back(0); koff.push_back(0); c.push_back(0.0); }
     }
     row_term[ndim + 1] = (int32_t)c.size();
+    // rows -> (wavefront, slot): longest-processing-time greedy over the padded term counts, 16 wavefronts
+    const int NW = 16;
+    int rpw = 2;
+    while (rpw < 16 && rpw * NW < ndim) rpw *= 2;
+    m->t_rpw = rpw;
+    std::vector<int32_t> row_map((size_t)NW * rpw, 0);
+    if (rpw * NW >= ndim) {
+        std::vector<int> order(ndim);
+        for (int i = 0; i < ndim; ++i) order[i] = i + 1;
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+            return (row_term[x + 1] - row_term[x]) > (row_term[y + 1] - row_term[y]);
+        });
+        std::vector<int64_t> load(NW, 0);
+        std::vector<int> used(NW, 0);
+        for (int row : order) {
+            int best = -1;
+            for (int w = 0; w < NW; ++w)
+                if (used[w] < rpw && (best < 0 || load[w] < load[best])) best = w;
+            row_map[(size_t)best * rpw + used[best]++] = row;
+            load[best] += row_term[row + 1] - row_term[row];
+        }
+    }
+    if (upload_vec(row_map, &m->t_row_map)) return -1;
     if (upload_vec(row_term, &m->t_row_term) || upload_vec(joff, &m->t_term_joff) || upload_vec(koff, &m->t_term_koff) ||
         upload_vec(c, &m->t_term_c)) return -1;
     return 0;
@@ -480,7 +512,7 @@ int qgs_model_destroy(qgs_model *m)
     (void)hipSetDevice(m->device);
     for (auto &kv : m->modules) (void)hipModuleUnload(kv.second);
     free_csr(m->dT); free_csr(m->dJ_by_i); free_csr(m->dJ_by_j);
-    for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c})
+    for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
                       &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_qr_tau})
