@@ -71,6 +71,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise QgsHipError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "or `make -C qgs_amd/csrc`.  qgs_amd has no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhiprtc.so.7 with the
+        # same sonames as /opt/rocm's.  Whichever is mapped first serves both; torch does not find the GPU when
+        # the system runtime was mapped first, so torch (the device-memory / stream plumbing of this stack) is
+        # imported before libqgs_hip.so whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
