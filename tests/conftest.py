@@ -10,7 +10,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
-CONFIGS = ('rp20', 'a36', 'm36', 't228')
+CONFIGS = ('rp20', 'a36', 'm36', 't228', 'g30')
 
 
 def pytest_configure(config):
@@ -47,7 +47,7 @@ def golden(request):
     return load_golden(request.param)
 
 
-@pytest.fixture(params=('rp20', 'a36', 'm36'))
+@pytest.fixture(params=('rp20', 'a36', 'm36', 'g30'))
 def golden_small(request):
     return load_golden(request.param)
 

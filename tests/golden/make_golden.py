@@ -18,6 +18,8 @@ Configs
     a36   : model_test/test_aotensor.py:37-44 parameters (MAOOAM 2x2/2x4, ndim 36)
     m36   : qgs_maooam.py:78-92 parameters (MAOOAM 2x2/2x4, ndim 36; BASELINE configs 2,4,5)
     t228  : model_test/test_aotensor_6x6.py:42-47 parameters (MAOOAM 6x6/6x6, ndim 228)
+    g30   : 2x2 atmosphere + ground temperature on the atmospheric modes (ndim 30), parameters in the
+            style of notebooks/ground_heat.ipynb
 """
 import gzip
 import json
@@ -79,11 +81,26 @@ def params_t228():
     return p
 
 
+def params_g30():
+    """Land-atmosphere model (Li et al. 2018 type): 2x2 atmosphere + ground temperature on the same modes."""
+    p = QgParams({'phi0_npi': np.deg2rad(50.) / np.pi, 'n': 1.3, 'oro_scale': 1}, dynamic_T=False)
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_ground_channel_fourier_modes()
+    p.ground_params.set_orography(0.2, 1)
+    p.gotemperature_params.set_params({'gamma': 1.6e7, 'T0': 300})
+    p.atemperature_params.set_params({'hlambda': 10, 'T0': 290})
+    p.atmospheric_params.set_params({'sigma': 0.2, 'kd': 0.085, 'kdp': 0.02})
+    p.atemperature_params.set_insolation(0.4 * 300., 0)
+    p.gotemperature_params.set_insolation(300., 0)
+    return p
+
+
 CONFIGS = {
     'rp20': dict(make=params_rp20, ic_scale=0.1, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     'a36': dict(make=params_a36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     'm36': dict(make=params_m36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     't228': dict(make=params_t228, ic_scale=0.01, n_x=8, n_jac=2, long_steps=(10,), n_traj=2),
+    'g30': dict(make=params_g30, ic_scale=0.01, n_x=16, n_jac=8, long_steps=(100,), n_traj=4),
 }
 
 RK4 = dict(c=np.array([0., 0.5, 0.5, 1.]), b=np.array([1. / 6, 1. / 3, 1. / 3, 1. / 6]),

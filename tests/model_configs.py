@@ -41,4 +41,17 @@ def params_t228():
     return p
 
 
-MAKERS = {'rp20': params_rp20, 'a36': params_a36, 'm36': params_m36, 't228': params_t228}
+def params_g30():
+    p = QgParams({'phi0_npi': np.deg2rad(50.) / np.pi, 'n': 1.3, 'oro_scale': 1})
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_ground_channel_fourier_modes()
+    p.ground_params.set_orography(0.2, 1)
+    p.gotemperature_params.set_params({'gamma': 1.6e7, 'T0': 300})
+    p.atemperature_params.set_params({'hlambda': 10, 'T0': 290})
+    p.atmospheric_params.set_params({'sigma': 0.2, 'kd': 0.085, 'kdp': 0.02})
+    p.atemperature_params.set_insolation(0.4 * 300., 0)
+    p.gotemperature_params.set_insolation(300., 0)
+    return p
+
+
+MAKERS = {'rp20': params_rp20, 'a36': params_a36, 'm36': params_m36, 't228': params_t228, 'g30': params_g30}

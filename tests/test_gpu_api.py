@@ -10,7 +10,7 @@ from conftest import load_golden, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['rp20', 'a36', 'm36'])
+@pytest.fixture(scope='module', params=['rp20', 'a36', 'm36', 'g30'])
 def setup(request):
     from qgs_amd.functions.tendencies import tendencies_from_tensor
     g = load_golden(request.param)
