@@ -71,6 +71,16 @@ bool tiled_supported(int ndim);
 hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec,
                                double *stages, const double *dtime, const double *tab_spec, hipStream_t st);
 
+// ---- wavefront-per-trajectory stepper (small ensembles) --------------------------------------------------
+// With fewer members than lanes on the chip (n_traj << 65 536) one-member-per-lane leaves the GPU idle and a
+// single trajectory advances at the pace of one in-order wavefront doing ALL rows (7.5 us per RK4 step at
+// ndim 36).  Here a trajectory owns a whole workgroup: lane = tensor row, the stage state lives in LDS, each lane
+// keeps its row's terms in registers (rows of at most 16 terms) or streams them from memory.
+// Tensor = the CSR `DevTensor` (idx = j<<16 | k).  Sub-diagonal tableaus; tab_spec = b[s], a[1][0], a[2][1], ...
+bool wave_supported(int ndim);
+hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArgs &p, const double *y_in, double *y_out,
+                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st);
+
 // Batched Householder QR (LAPACK dgeqr2 + dorg2r conventions: R_jj = -sign(a_jj)*||.||) of one
 // (n_rows x n_cols) matrix per member in the device layout A[row][col][member]; A is overwritten by Q,
 // rdiag[col][member] receives diag(R), tau[col][member] is scratch.  Used by the Benettin Lyapunov

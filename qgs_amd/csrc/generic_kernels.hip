@@ -317,6 +317,137 @@ hipError_t launch_tiled(const TiledTensor &T, const RkArgs &p, const double *y_i
     return hipGetLastError();
 }
 
+// ---- wavefront-per-trajectory stepper ---------------------------------------------------------------------
+// One workgroup (NWV wavefronts, 64*NWV >= ndim) per trajectory, lane = row.  REG_TERMS > 0: the row's terms
+// (at most REG_TERMS) live in registers as (LDS byte offset of x_j, of x_k, coefficient); REG_TERMS == 0: streamed
+// from the CSR arrays every stage.  S > 0: stage loop unrolled (tableau in registers, LDS buffer parity known at
+// compile time so the double-buffer switch is an immediate offset); S == 0: run-time stage count.
+constexpr int WAVE_XS_STRIDE = 264;                        // doubles per LDS stage buffer (>= 256 + 1)
+
+template <int REG_TERMS>
+__device__ __forceinline__ double wave_row_eval(const char *xb, const uint32_t *jo, const uint32_t *ko, const double *cf,
+                                                const DevTensor &T, int e0, int e1)
+{
+    double k0 = 0.0, k1 = 0.0;
+    if (REG_TERMS > 0) {
+        double xj[REG_TERMS > 0 ? REG_TERMS : 1], xk[REG_TERMS > 0 ? REG_TERMS : 1];
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; ++t) { xj[t] = *(const double *)(xb + jo[t]); xk[t] = *(const double *)(xb + ko[t]); }
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; t += 2) {
+            k0 = __builtin_fma(cf[t], xj[t] * xk[t], k0);
+            if (t + 1 < REG_TERMS) k1 = __builtin_fma(cf[t + 1], xj[t + 1] * xk[t + 1], k1);
+        }
+    } else {
+        for (int e = e0; e < e1; ++e) {
+            const uint32_t q = T.idx[e];
+            k0 = __builtin_fma(T.val[e], *(const double *)(xb + (q >> 16) * 8u) * *(const double *)(xb + (q & 0xffffu) * 8u), k0);
+        }
+    }
+    return k0 + k1;
+}
+
+template <int NWV, int REG_TERMS, int S>
+__global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkArgs p, const double *__restrict__ y_in,
+                                                               double *__restrict__ y_out, double *__restrict__ rec,
+                                                               double *__restrict__ stages,
+                                                               const double *__restrict__ dtime,
+                                                               const double *__restrict__ tab)
+{
+    __shared__ double xs[2 * WAVE_XS_STRIDE];              // two stage buffers, slot 0 of each = eta_0 = 1
+    const int ndim = p.ndim, s = (S > 0) ? S : p.s;
+    const int row = (int)threadIdx.x + 1;                  // tensor row of this lane
+    const bool active = row <= ndim;
+    const int64_t m = blockIdx.x;                          // trajectory
+    const int64_t ld = p.ld, A = (int64_t)ndim * ld;
+    const int e0 = active ? T.rowptr[row] : 0, e1 = active ? T.rowptr[row + 1] : 0;
+
+    uint32_t jo[REG_TERMS > 0 ? REG_TERMS : 1], ko[REG_TERMS > 0 ? REG_TERMS : 1];
+    double cf[REG_TERMS > 0 ? REG_TERMS : 1];
+    if (REG_TERMS > 0) {
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; ++t) {              // pad with zero terms reading slot 0
+            const bool have = e0 + t < e1;
+            const uint32_t q = have ? T.idx[e0 + t] : 0u;
+            jo[t] = (q >> 16) * 8u;
+            ko[t] = (q & 0xffffu) * 8u;
+            cf[t] = have ? T.val[e0 + t] : 0.0;
+        }
+    }
+    double tb[S > 0 ? S : 1], ta[S > 0 ? S : 1];
+    if (S > 0) {
+#pragma unroll
+        for (int st = 0; st < S; ++st) { tb[st] = tab[st]; ta[st] = (st + 1 < S) ? tab[S + st] : 0.0; }
+    }
+    double y = active ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
+    if (threadIdx.x == 0) { xs[0] = 1.0; xs[WAVE_XS_STRIDE] = 1.0; }
+    if (active) xs[row] = y;
+    __syncthreads();
+
+    int64_t iw = 0, next_rec = -1;
+    if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
+    const char *xb0 = (const char *)xs, *xb1 = (const char *)(xs + WAVE_XS_STRIDE);
+    int cur = 0;                                           // buffer holding the current stage input (run-time s only)
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (ti == next_rec) {
+            if (active) rec[rec_index(iw, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y;
+            ++iw; next_rec += p.write_steps;
+        }
+        double acc = y;
+        if (S > 0) {
+            // every step starts and (for even S) ends in buffer (ti*S) & 1; parity per stage is a compile-time pattern
+            // only for even S, so odd S toggles `cur` like the run-time path
+#pragma unroll
+            for (int st = 0; st < S; ++st) {
+                const bool in1 = (S % 2 == 0) ? (st & 1) : ((cur + st) & 1);
+                const char *xb = in1 ? xb1 : xb0;
+                double *xo = in1 ? xs : xs + WAVE_XS_STRIDE;
+                if (stages && active) stages[((ti - p.step_begin) * S + st) * A + (int64_t)(row - 1) * ld + m] = *(const double *)(xb + row * 8);
+                const double k = wave_row_eval<REG_TERMS>(xb, jo, ko, cf, T, e0, e1);
+                acc = __builtin_fma(dt * tb[st], k, acc);
+                const bool last = (st == S - 1);
+                const double xn = last ? acc : __builtin_fma(dt * ta[st], k, y);
+                if (active) xo[row] = xn;
+                if (last) y = acc;
+                __syncthreads();
+            }
+            if (S % 2) cur ^= 1;
+        } else {
+            for (int st = 0; st < s; ++st) {
+                const char *xb = cur ? xb1 : xb0;
+                double *xo = cur ? xs : xs + WAVE_XS_STRIDE;
+                if (stages && active) stages[((ti - p.step_begin) * s + st) * A + (int64_t)(row - 1) * ld + m] = *(const double *)(xb + row * 8);
+                const double k = wave_row_eval<REG_TERMS>(xb, jo, ko, cf, T, e0, e1);
+                acc = __builtin_fma(dt * tab[st], k, acc);
+                const bool last = (st == s - 1);
+                const double xn = last ? acc : __builtin_fma(dt * tab[s + st], k, y);
+                if (active) xo[row] = xn;
+                if (last) y = acc;
+                cur ^= 1;
+                __syncthreads();
+            }
+        }
+    }
+    if (active) {
+        if (y_out) y_out[(int64_t)(row - 1) * ld + m] = y;
+        if (p.write_final) rec[rec_index(p.n_records - 1, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y;
+    }
+}
+
+template <int NWV, int REG_TERMS>
+hipError_t launch_wave(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
+                       const double *dtime, const double *tab, hipStream_t st)
+{
+    const dim3 grid((unsigned)p.n_traj), block(64 * NWV);
+    switch (p.s) {
+    case 2: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 2>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
+    case 4: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 4>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
+    default: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 0>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
+    }
+    return hipGetLastError();
+}
+
 // ---- batched QR ------------------------------------------------------------------------------------------
 // One member per lane, matrix in global memory (coalesced over members), unblocked Householder.
 __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
@@ -440,6 +571,25 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
 {
     hipLaunchKernelGGL(gen_tgl_kernel, dim3(blocks_for(n_tg * p.ld, WAVE)), dim3(WAVE), 0, st, Jrow, p, n_tg, inverse, w_in,
                        w_out, rec, stages, work, dtime, tab_full);
+}
+
+bool wave_supported(int ndim) { return ndim <= 256; }
+
+hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArgs &p, const double *y_in, double *y_out,
+                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st)
+{
+    const int nwv = (p.ndim + 63) / 64;
+#define QGS_WAVE_CASE(N)                                                                                          \
+    if (nwv == N) {                                                                                               \
+        if (max_row_terms <= 16) return launch_wave<N, 16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);   \
+        return launch_wave<N, 0>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);                             \
+    }
+    QGS_WAVE_CASE(1)
+    QGS_WAVE_CASE(2)
+    QGS_WAVE_CASE(3)
+    QGS_WAVE_CASE(4)
+#undef QGS_WAVE_CASE
+    return hipErrorInvalidValue;
 }
 
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *tau, hipStream_t st)

@@ -203,6 +203,7 @@ struct qgs_model {
     int32_t *t_row_term = nullptr;
     uint32_t *t_term_joff = nullptr, *t_term_koff = nullptr;
     double *t_term_c = nullptr;
+    int max_row_terms = 0;        // longest tendencies-tensor row (selects the register-resident wave kernel)
     int t_terms_per_trip = 4, t_rpw = 16;
     int32_t *t_row_map = nullptr;
     qgs::TiledTensor tiled() const
@@ -412,6 +413,16 @@ bool use_spec(const qgs_model *m, int s, const double *a)
     return a == nullptr || qgs::tableau_is_subdiagonal(s, a);
 }
 
+// wavefront-per-trajectory stepper for small ensembles: below QGS_HIP_WAVE_MAX_TRAJ members (default 4096, see
+// DESIGN.md 3.5) it beats one-member-per-lane because the lanes of the few wavefronts would do all rows serially
+bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
+{
+    if (m->kernel_kind != 0) return false;                 // explicit generic / specialised request
+    int64_t limit = (m->max_row_terms <= 16) ? 4096 : 256;   // measured crossovers (tools/latency_bench.py)
+    if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
+    return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+}
+
 // tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
 bool use_tiled(const qgs_model *m, int s, const double *a)
 {
@@ -495,6 +506,10 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
     for (const auto &t : m->T) if (t.i >= 1) Tr.push_back(t);
     for (const auto &t : m->J) if (t.i >= 1 && t.j >= 1) Jr.push_back(t);
     auto pack = [](int a, int b) { return ((uint32_t)a << 16) | (uint32_t)b; };
+    {
+        std::vector<int> cnt(ndim + 2, 0);
+        for (const auto &t : Tr) m->max_row_terms = std::max(m->max_row_terms, ++cnt[t.i]);
+    }
     HostCsr hT = build_csr(ndim, Tr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
     // Jacobian kernel wants (j,k) per row i; tangent model wants (w=j, x=k) per row i; adjoint (w=i, x=k) per row j
     HostCsr hJi = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
@@ -651,6 +666,13 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
     const int64_t n_records = qgs_n_records(time, n_time, write_steps);
     const int backward = time_direction == -1;
+    if (use_wave(m, n_traj, s, a)) {
+        // small ensemble: one workgroup per trajectory, lane = tensor row (latency-optimised)
+        qgs::RkArgs pw{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
+        HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
+        note_kernel(m, "gen_rk_wave_kernel", nullptr);
+        return 0;
+    }
     if (use_spec(m, s, a)) {
         // Row-split stepper (R wavefronts per 64 members) when the ensemble alone cannot put two
         // wavefronts on every SIMD; plain one-wave-per-64-members stepper otherwise.

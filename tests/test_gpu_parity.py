@@ -14,7 +14,7 @@ from conftest import RK4, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
-KINDS = {'generic': 1, 'specialised': 2}
+KINDS = {'auto': 0, 'generic': 1, 'specialised': 2}      # auto = wave-per-trajectory kernel for small ensembles
 
 
 @pytest.fixture(scope='module')
@@ -33,7 +33,7 @@ def models():
 
 
 def _kinds(model):
-    return [k for k in KINDS if k == 'generic' or model.specialised_available]
+    return [k for k in KINDS if k != 'specialised' or model.specialised_available]
 
 
 def test_backend_is_gfx950():
@@ -147,7 +147,7 @@ def test_full_size_properties(models):
     """
     from oracle.oracle import OracleModel
     g, m = load_golden('m36'), models('m36')
-    m.set_kernel(0)
+    m.set_kernel(2)          # one kernel family for the bitwise batch-independence property
     n = 65536
     ic = np.random.RandomState(21217).rand(n, g.ndim) * 0.01
     t = np.concatenate((np.arange(0., 5.0, 0.1), [5.0]))
@@ -156,6 +156,9 @@ def test_full_size_properties(models):
     pick = np.array([0, 1, 63, 64, 4097, 32768, 65535])
     alone = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
     assert np.array_equal(alone, full[pick])
+    m.set_kernel(0)          # automatic selection takes the wave-per-trajectory kernel for 7 members
+    auto = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert rel_err(auto, alone) < 1e-12
     back = m.rk_integrate(t, full, -1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
     assert np.abs(back - ic).max() < 1e-6
     ora = OracleModel(g.ndim, g['coo'], g['val'])
@@ -180,7 +183,7 @@ def test_linearity_of_tangent_model(models):
 
 @pytest.mark.parametrize('env', [{'QGS_HIP_RK_VARIANT': 'plain'}, {'QGS_HIP_RK_VARIANT': 'split'},
                                  {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '3'},
-                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}])
+                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
 def test_kernel_variants_agree_with_oracle(monkeypatch, env):
     """Every code-generation / kernel-selection variant (plain one-wave stepper, row split 2 and 3, literal
     coefficients, ungrouped terms, simple generic kernel) against the oracle on the same inputs."""
@@ -196,7 +199,7 @@ def test_kernel_variants_agree_with_oracle(monkeypatch, env):
     ref = ora.integrate_runge_kutta_jit(t, ic, -1, 4, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = np.random.RandomState(18).randn(3, g.ndim, 2)
     rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
-    for kind in (1, 2):
+    for kind in (0, 1, 2):
         m.set_kernel(kind)
         assert rel_err(m.rk_integrate(t, ic, -1, 4, RK4['b'], RK4['c'], RK4['a']), ref) < 1e-12, (env, kind)
         tr, fm = m.rk_tgls_integrate(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
