@@ -449,50 +449,78 @@ hipError_t launch_wave(const DevTensor &T, const RkArgs &p, const double *y_in, 
 }
 
 // ---- batched QR ------------------------------------------------------------------------------------------
-// One member per lane, matrix in global memory (coalesced over members), unblocked Householder.
+// One wavefront per member, lane = column, the matrix lives in LDS as A[row][lane] with a row stride of 65
+// doubles (column walks are then bank-conflict free).  Unblocked Householder with LAPACK's conventions
+// (dgeqr2 / dlarfg: beta = -sign(alpha)*norm, v_0 = 1; dorg2r for Q).  The reflector is applied to all columns
+// c > j at once: every lane accumulates v^T a_c for its own column (v_i is a broadcast LDS read), so the only
+// cross-lane reduction per step is the norm of the pivot column.
+constexpr int QR_STRIDE = 65;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
                                                           double *__restrict__ a, double *__restrict__ rdiag,
-                                                          double *__restrict__ tau)
+                                                          double *__restrict__ tau_unused)
 {
-    const int64_t m = (int64_t)blockIdx.x * WAVE + threadIdx.x;
-    if (m >= n_traj) return;
-#define A_(i, c) a[((int64_t)(i) * n_cols + (c)) * ld + m]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *A = (double *)smem;                            // [n_rows][QR_STRIDE]
+    const int64_t m = blockIdx.x;
+    const int c = threadIdx.x;                             // own column
+    const bool col = c < n_cols;
+    (void)tau_unused;
+    for (int i = 0; i < n_rows; ++i) A[i * QR_STRIDE + c] = col ? a[((int64_t)i * n_cols + c) * ld + m] : 0.0;
+    __syncthreads();
     const int k = n_cols < n_rows ? n_cols : n_rows;
-    for (int j = 0; j < k; ++j) {                                   // dgeqr2: H_j annihilates A[j+1:, j]
-        const double alpha = A_(j, j);
-        double xn2 = 0.0;
-        for (int i = j + 1; i < n_rows; ++i) { const double v = A_(i, j); xn2 = __builtin_fma(v, v, xn2); }
+    double my_tau = 0.0;                                   // lane j keeps tau_j
+    for (int j = 0; j < k; ++j) {
+        // ---- dlarfg on column j (rows j..n_rows-1): lanes cooperate over the rows below the diagonal
+        double part = 0.0;
+        for (int i = j + 1 + c; i < n_rows; i += WAVE) { const double v = A[i * QR_STRIDE + j]; part = __builtin_fma(v, v, part); }
+        const double xn2 = wave_sum(part);
+        const double alpha = A[j * QR_STRIDE + j];
         double t = 0.0, beta = alpha;
-        if (xn2 != 0.0) {                                           // dlarfg
+        if (xn2 != 0.0) {
             beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha);
             t = (beta - alpha) / beta;
             const double scale = 1.0 / (alpha - beta);
-            for (int i = j + 1; i < n_rows; ++i) A_(i, j) *= scale;
+            for (int i = j + 1 + c; i < n_rows; i += WAVE) A[i * QR_STRIDE + j] *= scale;
         }
-        tau[(int64_t)j * ld + m] = t;
-        rdiag[(int64_t)j * ld + m] = beta;
-        for (int c = j + 1; c < n_cols; ++c) {                      // dlarf: A[j:, c] -= tau * v * (v^T A[j:, c])
-            double w = A_(j, c);
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A_(i, j), A_(i, c), w);
+        if (c == j) { my_tau = t; rdiag[(int64_t)j * ld + m] = beta; }
+        __syncthreads();
+        // ---- dlarf: columns c > j get a_c -= tau * v * (v^T a_c), v = (1, A[j+1:, j])
+        if (col && c > j) {
+            double w = A[j * QR_STRIDE + c];
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w);
             w *= t;
-            A_(j, c) -= w;
-            for (int i = j + 1; i < n_rows; ++i) A_(i, c) = __builtin_fma(-w, A_(i, j), A_(i, c));
+            A[j * QR_STRIDE + c] -= w;
+            for (int i = j + 1; i < n_rows; ++i) A[i * QR_STRIDE + c] = __builtin_fma(-w, A[i * QR_STRIDE + j], A[i * QR_STRIDE + c]);
         }
+        if (c == j) A[j * QR_STRIDE + j] = beta;
+        __syncthreads();
     }
-    for (int j = k - 1; j >= 0; --j) {                              // dorg2r: accumulate Q in place
-        const double t = tau[(int64_t)j * ld + m];
-        for (int c = j + 1; c < n_cols; ++c) {                      // apply H_j to Q[j:, j+1:] with Q[j][j] taken as 1
-            double w = A_(j, c);
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A_(i, j), A_(i, c), w);
+    for (int j = k - 1; j >= 0; --j) {                     // ---- dorg2r
+        const double t = __shfl(my_tau, j);
+        if (col && c > j) {                                // apply H_j to Q[j:, j+1:], Q[j][j] taken as 1
+            double w = A[j * QR_STRIDE + c];
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w);
             w *= t;
-            A_(j, c) -= w;
-            for (int i = j + 1; i < n_rows; ++i) A_(i, c) = __builtin_fma(-w, A_(i, j), A_(i, c));
+            A[j * QR_STRIDE + c] -= w;
+            for (int i = j + 1; i < n_rows; ++i) A[i * QR_STRIDE + c] = __builtin_fma(-w, A[i * QR_STRIDE + j], A[i * QR_STRIDE + c]);
         }
-        for (int i = j + 1; i < n_rows; ++i) A_(i, j) *= -t;
-        A_(j, j) = 1.0 - t;
-        for (int i = 0; i < j; ++i) A_(i, j) = 0.0;
+        __syncthreads();
+        // column j itself: Q[i][j] = -tau v_i (i > j), Q[j][j] = 1 - tau, zeros above; lanes cooperate over rows
+        for (int i = c; i < n_rows; i += WAVE) {
+            const double v = A[i * QR_STRIDE + j];
+            A[i * QR_STRIDE + j] = (i > j) ? -t * v : ((i == j) ? 1.0 - t : 0.0);
+        }
+        __syncthreads();
     }
-#undef A_
+    if (col) for (int i = 0; i < n_rows; ++i) a[((int64_t)i * n_cols + c) * ld + m] = A[i * QR_STRIDE + c];
 }
 
 // ---- layout conversion ----------------------------------------------------------------------
@@ -594,7 +622,13 @@ hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArg
 
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *tau, hipStream_t st)
 {
-    hipLaunchKernelGGL(batched_qr_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, n_rows, n_cols, n_traj, ld, a, rdiag, tau);
+    const size_t lds = sizeof(double) * (size_t)n_rows * QR_STRIDE;
+    static size_t configured = 64 * 1024;
+    if (lds > configured) {
+        if (hipFuncSetAttribute((const void *)batched_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            configured = lds;
+    }
+    hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)n_traj), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag, tau);
 }
 
 bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }

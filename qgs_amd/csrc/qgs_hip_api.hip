@@ -771,7 +771,10 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             double inv = inverse;
             void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
-            if (launch(f1, n_traj, st, a1)) return -1;
+            if (use_wave(m, n_traj, s, a)) {           // few members: latency-optimised trajectory pass
+                qgs::RkArgs pw{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
+                HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+            } else if (launch(f1, n_traj, st, a1)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
@@ -799,6 +802,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
 {
     if (check_common(m, n_traj, ld)) return -1;
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows) return fail("batched QR needs 1 <= n_cols <= n_rows");
+    if (n_cols > 64 || n_rows > 300) return fail("batched QR supports n_cols <= 64 (one column per lane) and n_rows <= 300 (LDS)");
     HIPCHK(hipSetDevice(m->device));
     if (m->b_qr_tau.ensure(sizeof(double) * (size_t)n_cols * ld)) return -1;
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->b_qr_tau.f64(), (hipStream_t)stream);
