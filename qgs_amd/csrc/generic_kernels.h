@@ -81,6 +81,13 @@ bool wave_supported(int ndim);
 hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArgs &p, const double *y_in, double *y_out,
                               double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st);
 
+// Same idea for the tangent / adjoint model: one workgroup per (member, tangent column), lane = row of J (or J^T),
+// the row's entries (w index, x index, value) in registers when there are at most 32, x and w staged in LDS.
+// Jrow as for launch_gen_tgl; stages as written by the trajectory pass.
+hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const RkArgs &p, int64_t n_tg, double inverse,
+                               const double *w_in, double *w_out, double *rec, const double *stages, const double *dtime,
+                               const double *tab_spec, hipStream_t st);
+
 // Batched Householder QR (LAPACK dgeqr2 + dorg2r conventions: R_jj = -sign(a_jj)*||.||) of one
 // (n_rows x n_cols) matrix per member in the device layout A[row][col][member]; A is overwritten by Q,
 // rdiag[col][member] receives diag(R), tau[col][member] is scratch.  Used by the Benettin Lyapunov

@@ -448,6 +448,90 @@ hipError_t launch_wave(const DevTensor &T, const RkArgs &p, const double *y_in, 
     return hipGetLastError();
 }
 
+// ---- wavefront-per-(member, column) tangent model -----------------------------------------------------------
+template <int REG_TERMS>
+__device__ __forceinline__ double wave_wx_eval(const char *xb, const char *wb, const uint32_t *wo, const uint32_t *xo,
+                                               const double *cf, const DevTensor &J, int e0, int e1)
+{
+    double k0 = 0.0, k1 = 0.0;
+    if (REG_TERMS > 0) {
+        double xv[REG_TERMS > 0 ? REG_TERMS : 1], wv[REG_TERMS > 0 ? REG_TERMS : 1];
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; ++t) { xv[t] = *(const double *)(xb + xo[t]); wv[t] = *(const double *)(wb + wo[t]); }
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; t += 2) {
+            k0 = __builtin_fma(cf[t], xv[t] * wv[t], k0);
+            if (t + 1 < REG_TERMS) k1 = __builtin_fma(cf[t + 1], xv[t + 1] * wv[t + 1], k1);
+        }
+    } else {
+        for (int e = e0; e < e1; ++e) {
+            const uint32_t q = J.idx[e];
+            k0 = __builtin_fma(J.val[e], *(const double *)(xb + (q & 0xffffu) * 8u) * *(const double *)(wb + (q >> 16) * 8u), k0);
+        }
+    }
+    return k0 + k1;
+}
+
+template <int NWV, int REG_TERMS>
+__global__ void __launch_bounds__(64 * NWV) gen_tgl_wave_kernel(DevTensor J, RkArgs p, int64_t n_tg, double inverse,
+                                                                const double *__restrict__ w_in, double *__restrict__ w_out,
+                                                                double *__restrict__ rec, const double *__restrict__ stages,
+                                                                const double *__restrict__ dtime, const double *__restrict__ tab)
+{
+    __shared__ double xsh[WAVE_XS_STRIDE];                 // stage state of the member, slot 0 = 1
+    __shared__ double wsh[2 * WAVE_XS_STRIDE];             // tangent stage vector, double buffered (slot 0 unused = 0)
+    const int ndim = p.ndim, s = p.s;
+    const int row = (int)threadIdx.x + 1;
+    const bool active = row <= ndim;
+    const int64_t col = blockIdx.x / p.n_traj, m = blockIdx.x % p.n_traj;
+    const int64_t ld = p.ld, L = n_tg * ld, l = col * ld + m;
+    const int64_t A = (int64_t)ndim * L, AS = (int64_t)ndim * ld;
+    const int e0 = active ? J.rowptr[row] : 0, e1 = active ? J.rowptr[row + 1] : 0;
+    uint32_t wo[REG_TERMS > 0 ? REG_TERMS : 1], xo[REG_TERMS > 0 ? REG_TERMS : 1];
+    double cf[REG_TERMS > 0 ? REG_TERMS : 1];
+    if (REG_TERMS > 0) {
+#pragma unroll
+        for (int t = 0; t < REG_TERMS; ++t) {
+            const bool have = e0 + t < e1;
+            const uint32_t q = have ? J.idx[e0 + t] : 0u;
+            wo[t] = (q >> 16) * 8u;
+            xo[t] = (q & 0xffffu) * 8u;
+            cf[t] = have ? J.val[e0 + t] : 0.0;
+        }
+    }
+    double v = active ? w_in[(int64_t)(row - 1) * L + l] : 0.0;
+    if (threadIdx.x == 0) { xsh[0] = 1.0; wsh[0] = 0.0; wsh[WAVE_XS_STRIDE] = 0.0; }
+    if (active) wsh[row] = v;
+    int64_t iw = 0, next_rec = -1;
+    if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
+    int cur = 0;
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (ti == next_rec) {
+            if (active) rec[rec_index(iw, p.n_records, p.backward) * A + (int64_t)(row - 1) * L + l] = v;
+            ++iw; next_rec += p.write_steps;
+        }
+        double acc = v;
+        for (int st = 0; st < s; ++st) {
+            if (active) xsh[row] = stages[((ti - p.step_begin) * s + st) * AS + (int64_t)(row - 1) * ld + m];
+            __syncthreads();                               // x of this stage and w written by the previous stage visible
+            const char *wb = (const char *)(wsh + cur * WAVE_XS_STRIDE);
+            const double k = inverse * wave_wx_eval<REG_TERMS>((const char *)xsh, wb, wo, xo, cf, J, e0, e1);
+            acc = __builtin_fma(dt * tab[st], k, acc);
+            const bool last = (st == s - 1);
+            const double wn = last ? acc : __builtin_fma(dt * tab[s + st], k, v);
+            __syncthreads();                               // everybody has read xsh before the next stage overwrites it
+            if (active) wsh[(cur ^ 1) * WAVE_XS_STRIDE + row] = wn;
+            if (last) v = acc;
+            cur ^= 1;
+        }
+    }
+    if (active) {
+        if (w_out) w_out[(int64_t)(row - 1) * L + l] = v;
+        if (p.write_final) rec[rec_index(p.n_records - 1, p.n_records, p.backward) * A + (int64_t)(row - 1) * L + l] = v;
+    }
+}
+
 // ---- batched QR ------------------------------------------------------------------------------------------
 // One wavefront per member, lane = column, the matrix lives in LDS as A[row][lane] with a row stride of 65
 // doubles (column walks are then bank-conflict free).  Unblocked Householder with LAPACK's conventions
@@ -461,6 +545,22 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
+}
+
+// A[j][c] + sum_{i>j} A[i][j] * A[i][c] with four independent partial sums (the LDS reads of consecutive rows
+// are independent, a single accumulator would serialise them behind the FMA latency)
+__device__ __forceinline__ double qr_col_dot(const double *A, int j, int c, int n_rows)
+{
+    double w0 = A[j * QR_STRIDE + c], w1 = 0.0, w2 = 0.0, w3 = 0.0;
+    int i = j + 1;
+    for (; i + 3 < n_rows; i += 4) {
+        w0 = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w0);
+        w1 = __builtin_fma(A[(i + 1) * QR_STRIDE + j], A[(i + 1) * QR_STRIDE + c], w1);
+        w2 = __builtin_fma(A[(i + 2) * QR_STRIDE + j], A[(i + 2) * QR_STRIDE + c], w2);
+        w3 = __builtin_fma(A[(i + 3) * QR_STRIDE + j], A[(i + 3) * QR_STRIDE + c], w3);
+    }
+    for (; i < n_rows; ++i) w0 = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w0);
+    return (w0 + w1) + (w2 + w3);
 }
 
 __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
@@ -494,10 +594,9 @@ __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols
         __syncthreads();
         // ---- dlarf: columns c > j get a_c -= tau * v * (v^T a_c), v = (1, A[j+1:, j])
         if (col && c > j) {
-            double w = A[j * QR_STRIDE + c];
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w);
-            w *= t;
+            double w = qr_col_dot(A, j, c, n_rows) * t;
             A[j * QR_STRIDE + c] -= w;
+#pragma unroll 4
             for (int i = j + 1; i < n_rows; ++i) A[i * QR_STRIDE + c] = __builtin_fma(-w, A[i * QR_STRIDE + j], A[i * QR_STRIDE + c]);
         }
         if (c == j) A[j * QR_STRIDE + j] = beta;
@@ -506,10 +605,9 @@ __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols
     for (int j = k - 1; j >= 0; --j) {                     // ---- dorg2r
         const double t = __shfl(my_tau, j);
         if (col && c > j) {                                // apply H_j to Q[j:, j+1:], Q[j][j] taken as 1
-            double w = A[j * QR_STRIDE + c];
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(A[i * QR_STRIDE + j], A[i * QR_STRIDE + c], w);
-            w *= t;
+            double w = qr_col_dot(A, j, c, n_rows) * t;
             A[j * QR_STRIDE + c] -= w;
+#pragma unroll 4
             for (int i = j + 1; i < n_rows; ++i) A[i * QR_STRIDE + c] = __builtin_fma(-w, A[i * QR_STRIDE + j], A[i * QR_STRIDE + c]);
         }
         __syncthreads();
@@ -617,6 +715,30 @@ hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArg
     QGS_WAVE_CASE(3)
     QGS_WAVE_CASE(4)
 #undef QGS_WAVE_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const RkArgs &p, int64_t n_tg, double inverse,
+                               const double *w_in, double *w_out, double *rec, const double *stages, const double *dtime,
+                               const double *tab_spec, hipStream_t st)
+{
+    const int nwv = (p.ndim + 63) / 64;
+    const dim3 grid((unsigned)(p.n_traj * n_tg));
+#define QGS_TGLW_CASE(N)                                                                                                 \
+    if (nwv == N) {                                                                                                      \
+        if (max_row_terms <= 32)                                                                                         \
+            hipLaunchKernelGGL((gen_tgl_wave_kernel<N, 32>), grid, dim3(64 * N), 0, st, Jrow, p, n_tg, inverse, w_in, w_out, rec, \
+                               stages, dtime, tab_spec);                                                                 \
+        else                                                                                                             \
+            hipLaunchKernelGGL((gen_tgl_wave_kernel<N, 0>), grid, dim3(64 * N), 0, st, Jrow, p, n_tg, inverse, w_in, w_out, rec, \
+                               stages, dtime, tab_spec);                                                                 \
+        return hipGetLastError();                                                                                        \
+    }
+    QGS_TGLW_CASE(1)
+    QGS_TGLW_CASE(2)
+    QGS_TGLW_CASE(3)
+    QGS_TGLW_CASE(4)
+#undef QGS_TGLW_CASE
     return hipErrorInvalidValue;
 }
 

@@ -204,6 +204,7 @@ struct qgs_model {
     uint32_t *t_term_joff = nullptr, *t_term_koff = nullptr;
     double *t_term_c = nullptr;
     int max_row_terms = 0;        // longest tendencies-tensor row (selects the register-resident wave kernel)
+    int max_jrow_terms = 0;       // longest Jacobian-tensor row, by i or by j
     int t_terms_per_trip = 4, t_rpw = 16;
     int32_t *t_row_map = nullptr;
     qgs::TiledTensor tiled() const
@@ -510,6 +511,10 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
         std::vector<int> cnt(ndim + 2, 0);
         for (const auto &t : Tr) m->max_row_terms = std::max(m->max_row_terms, ++cnt[t.i]);
     }
+    {
+        std::vector<int> ci(ndim + 2, 0), cj(ndim + 2, 0);
+        for (const auto &t : Jr) m->max_jrow_terms = std::max(m->max_jrow_terms, std::max(++ci[t.i], ++cj[t.j]));
+    }
     HostCsr hT = build_csr(ndim, Tr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
     // Jacobian kernel wants (j,k) per row i; tangent model wants (w=j, x=k) per row i; adjoint (w=i, x=k) per row j
     HostCsr hJi = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
@@ -757,7 +762,14 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         const int final_chunk = (end == n_steps);
         const double *y_src = first ? d_ic : y_state;
         const double *w_src = first ? d_tg_ic : w_state;
-        if (spec) {
+        if (m->kernel_kind == 0 && use_wave(m, n_traj * n_tg, s, a) && use_wave(m, n_traj, s, a)) {
+            // few (member, column) pairs: both passes with the latency-optimised wavefront-per-trajectory kernels
+            qgs::RkArgs pw{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
+            HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+            HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pw, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
+                                            d_tab_spec, st));
+            note_kernel(m, "gen_tgl_wave_kernel", nullptr);
+        } else if (spec) {
             hipFunction_t f1, f2;
             // row-split tangent kernel (R wavefronts per 64 lanes, 2 waves per SIMD) unless disabled
             bool tgl_split = m->cg.tgl_split > 1;
