@@ -365,12 +365,18 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
         }
         std::ostringstream so;
-        for (int i = 1; i <= ndim; ++i) {
-            so << "            {\n";
-            emit_tend_row(so, "                ", rows[i], "r", names(in), opt, st * 1000 + i);
-            so << "                acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "y" : "acc") << i << ");\n";
-            if (!last) so << "                " << outn << i << " = __builtin_fma(ha, r, y" << i << ");\n";
-            so << "            }\n";
+        const int W = std::max(1, opt.interleave_plain);
+        for (int c0 = 1; c0 <= ndim; c0 += W) {
+            std::vector<std::vector<std::string>> lists;
+            for (int i = c0; i <= std::min(ndim, c0 + W - 1); ++i) {
+                const std::string rn = "r" + std::to_string(i);
+                std::ostringstream ro;
+                emit_tend_row(ro, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
+                ro << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
+                if (!last) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
+                lists.push_back(split_lines(ro.str()));
+            }
+            so << interleave(lists);
         }
         o << (opt.const_table ? resolve_ktab(so.str(), table) : so.str());
         g_ktab = nullptr;

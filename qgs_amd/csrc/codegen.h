@@ -22,6 +22,7 @@ struct Term {          // one COO entry (i, j, k, value); index 0 is the constan
 struct CodegenOptions {
     bool group_coeff = true;   // factor equal-|coefficient| bilinear terms of a row: c*(m1 +- m2 ...)
     int min_waves_per_simd = 1;
+    int interleave_plain = 1;  // same for the plain one-wave stepper
     int interleave = 2;        // rows whose statements are interleaved in the row-split stepper (ILP)
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)

@@ -91,10 +91,22 @@ std::string target_arch(int device)
     return "gfx950";
 }
 
+// Compiler flags beyond -O3 that every specialised kernel is built with (part of the cache key).
+std::vector<std::string> default_extra_flags() { return {}; }
+
 // source -> code object (hsaco), through the on-disk cache
 int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
 {
+    // developer knob: extra compiler flags, e.g. QGS_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+    std::vector<std::string> extra;
+    if (const char *e = std::getenv("QGS_HIP_EXTRA_FLAGS")) {
+        std::istringstream is(e);
+        for (std::string tok; is >> tok;) extra.push_back(tok);
+    } else {
+        extra = default_extra_flags();
+    }
     std::string opts_key = arch + "|O3|c++17|v1";
+    for (const auto &x : extra) opts_key += "|" + x;
     char name[64];
     std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
     const std::string path = cache_dir() + "/" + name + ".hsaco";
@@ -110,8 +122,9 @@ int compile_source(const std::string &src, const std::string &arch, std::vector<
     if (hiprtcCreateProgram(&prog, src.c_str(), "qgs_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail("hiprtcCreateProgram failed");
     const std::string archopt = "--offload-arch=" + arch;
-    const char *opts[] = {archopt.c_str(), "-O3", "-std=c++17"};
-    hiprtcResult r = hiprtcCompileProgram(prog, 3, opts);
+    std::vector<const char *> opts = {archopt.c_str(), "-O3", "-std=c++17"};
+    for (const auto &x : extra) opts.push_back(x.c_str());
+    hiprtcResult r = hiprtcCompileProgram(prog, (int)opts.size(), opts.data());
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
         hiprtcGetProgramLogSize(prog, &n);
@@ -404,6 +417,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_KTAB")) cg.const_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
 }
 
 bool use_spec(const qgs_model *m, int s, const double *a)
@@ -679,11 +693,13 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         return 0;
     }
     if (use_spec(m, s, a)) {
-        // Row-split stepper (R wavefronts per 64 members) when the ensemble alone cannot put two
-        // wavefronts on every SIMD; plain one-wave-per-64-members stepper otherwise.
+        // Plain one-wave-per-64-members stepper by default.  The row-split stepper (R wavefronts per 64 members,
+        // LDS stage exchange) was the faster one with literal coefficients; with coefficient tables the plain
+        // kernel reaches the lone-wave fp64 issue limit (5.75 ms vs 5.95 ms for 65 536 x 1000 steps) and needs
+        // neither LDS nor barriers, so the split is opt-in (QGS_HIP_RK_VARIANT=split).
         const int R = m->cg.row_split;
         const int64_t waves = (n_traj + 63) / 64;
-        bool split = R > 1 && waves < 2 * (int64_t)m->n_simd;
+        bool split = false;
         if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
             if (!std::strcmp(e, "plain")) split = false;
             if (!std::strcmp(e, "split") && R > 1) split = true;
