@@ -38,21 +38,77 @@ std::string lit(double v)
 }
 
 // Replace the @K<value>@ placeholders of one stage's text by sequential table references.
-std::string resolve_ktab(const std::string &text, KTable &t)
+//
+// group == 0: plain `kt[n]` references; the compiler places the scalar loads (it merges them into
+//   s_load_dwordx16 and issues each ~8 instructions ahead of its first use).
+// group == 16: explicit software pipeline.  SMEM returns out of order, so every wait is lgkmcnt(0) and also
+//   waits for whatever was issued last; a lone wavefront then stalls (L - 45) cycles per 8 coefficients (PMC:
+//   21 % of the stepper's cycles).  Here the coefficients are consumed in groups of 16 held in two 8-double vectors
+//   `kq<2g>`, `kq<2g+1>`; the loads of group g+1 are issued right AFTER the first statement that uses group g
+//   (which carries the wait) and pinned there with sched_barriers, so they fly during the 16 FMAs of group g.
+std::string resolve_ktab(const std::string &text, KTable &t, int group)
 {
     std::string out;
     t.cursor = 0;
-    size_t pos = 0;
-    while (true) {
-        size_t a = text.find("@K", pos);
-        if (a == std::string::npos) { out.append(text, pos, std::string::npos); break; }
-        size_t b = text.find('@', a + 2);
-        out.append(text, pos, a - pos);
-        const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
+    auto next_ref = [&](double v, bool *ok) {
         if (t.cursor == t.vals.size()) t.vals.push_back(v);
-        if (t.vals[t.cursor] == v) out += "kt[" + std::to_string(t.cursor++) + "]";
-        else out += hexlit(v);                // cannot happen: every stage emits the same sequence
-        pos = b + 1;
+        *ok = (t.vals[t.cursor] == v);        // always true: every stage emits the same sequence
+        return t.cursor++;
+    };
+    if (group != 16) {
+        size_t pos = 0;
+        while (true) {
+            size_t a = text.find("@K", pos);
+            if (a == std::string::npos) { out.append(text, pos, std::string::npos); break; }
+            size_t b = text.find('@', a + 2);
+            out.append(text, pos, a - pos);
+            const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
+            bool ok;
+            const size_t n = next_ref(v, &ok);
+            out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
+            pos = b + 1;
+        }
+        return out;
+    }
+    // count the coefficients of this stage first (number of 8-double blocks that exist)
+    size_t total = 0;
+    for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
+    const size_t nblocks = (total + 7) / 8;
+    auto load_group = [&](size_t g, const char *ind) {
+        std::string l;
+        for (size_t b = 2 * g; b < 2 * g + 2 && b < nblocks; ++b)
+            l += std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
+        return l;
+    };
+    const char *ind = "                ";
+    out += load_group(0, ind);
+    long opened = -1;                         // highest group whose successor has been requested
+    size_t pos = 0;
+    while (pos < text.size()) {
+        size_t eol = text.find('\n', pos);
+        if (eol == std::string::npos) eol = text.size();
+        std::string line = text.substr(pos, eol - pos), res;
+        long first_group = -1;
+        size_t lp = 0;
+        while (true) {
+            size_t a = line.find("@K", lp);
+            if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
+            size_t b = line.find('@', a + 2);
+            res.append(line, lp, a - lp);
+            const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
+            bool ok;
+            const size_t n = next_ref(v, &ok);
+            res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
+            if (first_group < 0) first_group = (long)(n / 16);
+            lp = b + 1;
+        }
+        out += res + "\n";
+        if (first_group > opened) {           // first statement of a new group: now request the next group
+            opened = first_group;
+            const std::string l = load_group((size_t)first_group + 1, ind);
+            if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
+        }
+        pos = eol + 1;
     }
     return out;
 }
@@ -86,9 +142,9 @@ std::string interleave(const std::vector<std::vector<std::string>> &lists)
 
 void emit_ktable(std::ostringstream &o, const std::string &name, const KTable &t)
 {
-    o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << std::max<size_t>(1, t.vals.size()) << "] = {";
-    for (size_t n = 0; n < t.vals.size(); ++n) o << (n ? ", " : "") << hexlit(t.vals[n]);
-    if (t.vals.empty()) o << "0.0";
+    const size_t padded = std::max<size_t>(8, (t.vals.size() + 7) / 8 * 8);      // whole 8-double blocks
+    o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << padded << "] = {";
+    for (size_t n = 0; n < padded; ++n) o << (n ? ", " : "") << (n < t.vals.size() ? hexlit(t.vals[n]) : std::string("0.0"));
     o << "};\n";
 }
 
@@ -256,6 +312,8 @@ const char *PRELUDE = R"(// ---- generated by qgs_amd/csrc/codegen.cpp: tensor-s
 typedef double f64;
 typedef long long i64;
 typedef const double __attribute__((address_space(4))) kf64;   // coefficient tables: scalar (s_load) fetches
+typedef double v8d __attribute__((ext_vector_type(8)));
+typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
 #define QGS_WAVE 64
 )";
 
@@ -378,7 +436,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             }
             so << interleave(lists);
         }
-        o << (opt.const_table ? resolve_ktab(so.str(), table) : so.str());
+        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
         g_ktab = nullptr;
         o << "        }\n";
     }
@@ -497,7 +555,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
                     }
                     so << interleave(lists);
                 }
-                o << (opt.const_table ? resolve_ktab(so.str(), tables[w]) : so.str());
+                o << (opt.const_table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
             }
             o << "                __syncthreads();\n";
             if (!last) {
@@ -585,7 +643,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 if (!last) so << "                    " << outn << i << " = __builtin_fma(ha, r, v" << i << ");\n";
                 so << "                }\n";
             }
-            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass]) : so.str());
+            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], 0) : so.str());
             g_ktab = nullptr;
             o << "            }\n";
         }
@@ -701,7 +759,7 @@ void emit_tgl_split_kernel(std::ostringstream &out, int ndim, const std::vector<
                     }
                     so << interleave(lists);
                 }
-                o << (opt.const_table ? resolve_ktab(so.str(), tb) : so.str());
+                o << (opt.const_table ? resolve_ktab(so.str(), tb, 0) : so.str());
                 g_ktab = nullptr;
                 o << "                }\n";
             }
