@@ -635,15 +635,14 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 o << "                kf64* kt = (kf64*)" << kname << "_kt" << pass << "; asm volatile(\"\" : \"+s\"(kt));\n";
             }
             std::ostringstream so;
-            for (int i = 1; i <= ndim; ++i) {
-                so << "                {\n";
-                emit_wx_row(so, "                    ", pass == 0 ? tgl[i] : adj[i], "r", names("x"), names(in), opt,
+            for (int i = 1; i <= ndim; ++i) {                 // brace-less rows: the coefficient group vectors stay in scope
+                const std::string rn = "r" + std::to_string(i);
+                emit_wx_row(so, "                ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
                             pass * 100000 + st * 1000 + i);
-                so << "                    acc" << i << " = __builtin_fma(hb, r, " << (st == 0 ? "v" : "acc") << i << ");\n";
-                if (!last) so << "                    " << outn << i << " = __builtin_fma(ha, r, v" << i << ");\n";
-                so << "                }\n";
+                so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
+                if (!last) so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
             }
-            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], 0) : so.str());
+            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group) : so.str());
             g_ktab = nullptr;
             o << "            }\n";
         }
