@@ -598,6 +598,13 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
       << "    int backward, int write_final, int adjoint, f64 inverse)\n{\n";
+    // Parking: `v` (needed after stage 0 only as the base of w_next) and `acc` (one read-modify-write per row and
+    // stage) live in LDS, [row][lane], so that x, w_in and w_out (216 VGPRs) fit the 256 architectural registers
+    // without accumulation-register moves or scratch.  36.9 KB per wavefront-workgroup: 4 per CU = one per SIMD,
+    // which is what the 400+-register variant gets as well.
+    const bool park = opt.tgl_park_lds && S > 1;
+    if (park) o << "    __shared__ f64 vsh[" << ndim << "][QGS_WAVE];\n    __shared__ f64 accsh[" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x;\n";
     o << "    const i64 L = n_tg * ld;\n"
       << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
@@ -605,6 +612,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
     o << "    " << decl_list("v", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
+    if (park) for (int d = 1; d <= ndim; ++d) o << "    vsh[" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
     o << "    QGS_REC_INIT\n";
@@ -616,7 +624,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "            if (live) {\n";
     for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
     o << "            }\n        }\n";
-    o << "        " << decl_list("acc", ndim) << "\n";
+    if (!park) o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("wa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("wb", ndim) << "\n";
     for (int st = 0; st < S; ++st) {
@@ -639,8 +647,22 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 const std::string rn = "r" + std::to_string(i);
                 emit_wx_row(so, "                ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
                             pass * 100000 + st * 1000 + i);
-                so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
-                if (!last) so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
+                if (!park) {
+                    so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
+                    if (!last) so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
+                } else {
+                    const std::string acc_l = "accsh[" + std::to_string(i - 1) + "][lane]";
+                    const std::string v_l = "vsh[" + std::to_string(i - 1) + "][lane]";
+                    const std::string vsrc = (st == 0) ? "v" + std::to_string(i) : v_l;
+                    const std::string asrc = (st == 0) ? "v" + std::to_string(i) : acc_l;
+                    if (!last) {
+                        so << "                " << acc_l << " = __builtin_fma(hb, " << rn << ", " << asrc << ");\n";
+                        so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", " << vsrc << ");\n";
+                    } else {
+                        so << "                v" << i << " = __builtin_fma(hb, " << rn << ", " << asrc << ");\n";
+                        so << "                " << v_l << " = v" << i << ";\n";
+                    }
+                }
             }
             o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group) : so.str());
             g_ktab = nullptr;
@@ -648,7 +670,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         }
         o << "        }\n";
     }
-    for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = acc" << d << ";\n";
+    if (!park) for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = acc" << d << ";\n";
     o << "    }\n";
     o << "    if (live) {\n        if (w_out_p) {\n";
     for (int d = 1; d <= ndim; ++d) o << "            w_out_p[" << (d - 1) << " * L + l] = v" << d << ";\n";

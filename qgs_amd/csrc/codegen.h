@@ -26,6 +26,7 @@ struct CodegenOptions {
     int interleave = 2;        // rows whose statements are interleaved in the row-split stepper (ILP)
     int ktab_group = 16;       // 16: software-pipelined coefficient fetch in groups of 16; 0: compiler-placed loads
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
+    bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
     int row_split = 2;         // also emit the row-split stepper with this many wavefronts per 64 members
 };

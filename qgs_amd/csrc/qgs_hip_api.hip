@@ -416,6 +416,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_KTAB")) cg.const_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) cg.ktab_group = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_TGL_PARK")) cg.tgl_park_lds = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
