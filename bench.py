@@ -158,6 +158,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     kern_events = []
+    gather_events = []
 
     def one_pass(record_events):
         model.pack_states(n_traj, ld, d_ic_rows.data_ptr(), d_ic_modes.data_ptr(), stream)
@@ -170,10 +171,16 @@ def main():
             kern_events.append((e0, e1))
         model.unpack_records(n_traj, ld, ndim, 1, d_rec.data_ptr(), d_out_rows.data_ptr(), stream)
         if use_dist:
+            if record_events:
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
             if world > 1:
                 ens.gather(d_out_rows)                                 # RCCL all-gather over xGMI: the only collective
             else:
                 dist.all_gather_into_tensor(torch.empty_like(d_out_rows), d_out_rows)
+            if record_events:
+                g1.record()
+                gather_events.append((g0, g1))
 
     def barrier():
         if use_dist:
@@ -196,6 +203,7 @@ def main():
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_events])) if kern_events else float('nan')
     kinfo = model.last_kernel_info()
+    gather_ms = float(np.mean([g0.elapsed_time(g1) for g0, g1 in gather_events])) if gather_events else None
 
     # correctness guard inside the bench (rank 0): a handful of members against the CPU oracle
     result = None
@@ -225,6 +233,7 @@ def main():
                        'dt': dt, 'tensor_source': tensor_src, 'parallelism': 'members sharded x%d, RCCL all_gather of final states' % world,
                        'kernel': kinfo},
             'mode_updates_per_s': value * ndim,
+            'gather_ms_per_step': gather_ms,        # RCCL all-gather of the final states (rank 0's view), None at N=1
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': kinfo['name'], 'kernel_ms': kern_ms,
