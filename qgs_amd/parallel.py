@@ -68,6 +68,32 @@ class ShardedEnsemble(object):
         return torch.cat([p[:n] for p, n in zip(parts, self.counts)], dim=0)
 
 
+class RootGather(object):
+    """Gather of equal per-rank blocks onto one rank, optionally asynchronous so that it overlaps the next
+    compute step (RCCL runs it on its own stream).  xGMI is point-to-point: N-1 ranks sending their block
+    straight to the root uses N-1 links in parallel, while a ring all-gather would push (N-1) blocks through
+    every link -- so the benchmark's "final trajectory gather" is a gather, not an all-gather."""
+
+    def __init__(self, ens, dst=0):
+        if len(set(ens.counts)) != 1:
+            raise ValueError('RootGather needs equal shards')
+        self.ens, self.dst = ens, dst
+
+    def start(self, local, out=None, async_op=True):
+        """Returns (work handle or None, list of per-rank views of `out` on the root)."""
+        import torch
+        dist = self.ens._dist
+        if self.ens.world_size == 1:
+            return None, [local]
+        parts = None
+        if self.ens.rank == self.dst:
+            if out is None:
+                out = torch.empty((self.ens.n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            parts = list(out.split(self.ens.counts[0], dim=0))
+        work = dist.gather(local, gather_list=parts, dst=self.dst, group=self.ens.group, async_op=async_op)
+        return work, parts
+
+
 def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=None, a=None, process_group=None,
                        device=None, integrator_factory=None):
     """Integrate a (n_traj, n_dim) ensemble sharded over the ranks of `process_group`; every rank returns the

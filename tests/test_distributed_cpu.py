@@ -75,6 +75,41 @@ def test_sharded_ensemble_gloo_world2(tmp_path, n_traj, write_steps):
         assert np.array_equal(z['traj'], ref)              # every rank holds the full, ordered ensemble
 
 
+def _root_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from qgs_amd.parallel import ShardedEnsemble, RootGather
+    ens = ShardedEnsemble(world * 5)
+    root = RootGather(ens, dst=0)
+    bufs = [torch.zeros((5, 3), dtype=torch.float64) for _ in range(2)]
+    pending = [None, None]
+    last = None
+    for k in range(4):                                     # double-buffered asynchronous gathers, as bench.py does
+        if pending[k % 2] is not None:
+            pending[k % 2].wait()
+        bufs[k % 2].fill_(100.0 * k + rank)
+        pending[k % 2], parts = root.start(bufs[k % 2], async_op=True)
+        last = parts
+    for w in pending:
+        if w is not None:
+            w.wait()
+    if rank == 0:
+        np.save(os.path.join(out_dir, 'root.npy'), torch.cat(last).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_root_gather_async_gloo_world2(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_root_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = np.load(os.path.join(str(tmp_path), 'root.npy'))
+    assert got.shape == (10, 3)
+    assert np.all(got[:5] == 300.0) and np.all(got[5:] == 301.0)
+
+
 def test_shard_bounds():
     from qgs_amd.parallel import shard_bounds
     assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
