@@ -440,6 +440,16 @@ bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
     return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
 
+// wavefront-per-(member, column) tangent kernel: against the specialised lane kernel it wins below 4096 pairs,
+// against the simple generic kernel (large ndim, latency-bound at ~350 ms per 10 steps) up to ~16k pairs
+bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
+{
+    if (m->kernel_kind != 0) return false;
+    int64_t limit = m->spec_possible ? 4096 : 16384;
+    if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
+    return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+}
+
 // tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
 bool use_tiled(const qgs_model *m, int s, const double *a)
 {
@@ -780,31 +790,38 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         const int final_chunk = (end == n_steps);
         const double *y_src = first ? d_ic : y_state;
         const double *w_src = first ? d_tg_ic : w_state;
-        if (m->kernel_kind == 0 && use_wave(m, n_traj * n_tg, s, a) && use_wave(m, n_traj, s, a)) {
-            // few (member, column) pairs: both passes with the latency-optimised wavefront-per-trajectory kernels
-            qgs::RkArgs pw{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
-            HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
-            HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pw, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
+        // --- trajectory pass (stores every stage input state) ---
+        qgs::RkArgs pa{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
+        long long nt = n_traj, l = ld, sb = begin, se = end, ws = write_steps, nr = n_records, ntg = n_tg;
+        int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
+        double inv = inverse;
+        if (use_wave(m, n_traj, s, a)) {                  // few members: latency-optimised, lane = tensor row
+            HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+        } else if (spec) {
+            hipFunction_t f1;
+            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s);
+            if (get_function(m, s, n1, &f1)) return -1;
+            void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
+                          &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+            if (launch(f1, n_traj, st, a1)) return -1;
+        } else if (use_tiled(m, s, a)) {
+            HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+        } else {
+            qgs::launch_gen_rk(m->dT.view(), pa, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
+        }
+        // --- tangent / adjoint pass ---
+        if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
+            HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
                                             d_tab_spec, st));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
         } else if (spec) {
-            hipFunction_t f1, f2;
-            // row-split tangent kernel (R wavefronts per 64 lanes, 2 waves per SIMD) unless disabled
+            // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
             bool tgl_split = m->cg.tgl_split > 1;
             if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
-            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s);
             const std::string n2 = tgl_split ? "qgs_spec_tglsplit" + std::to_string(m->cg.tgl_split) + "_s" + std::to_string(s)
                                              : "qgs_spec_tgl_s" + std::to_string(s);
-            if (get_function(m, s, n1, &f1) || get_function(m, s, n2, &f2)) return -1;
-            long long nt = n_traj, l = ld, sb = begin, se = end, ws = write_steps, nr = n_records, ntg = n_tg;
-            int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
-            double inv = inverse;
-            void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
-                          &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
-            if (use_wave(m, n_traj, s, a)) {           // few members: latency-optimised trajectory pass
-                qgs::RkArgs pw{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
-                HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
-            } else if (launch(f1, n_traj, st, a1)) return -1;
+            hipFunction_t f2;
+            if (get_function(m, s, n2, &f2)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
@@ -812,12 +829,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
                 HIPCHK(hipModuleLaunchKernel(f2, (unsigned)((L + 63) / 64), 1, 1, 64 * m->cg.tgl_split, 1, 1, 0, st, a2, nullptr));
             } else if (launch(f2, L, st, a2)) return -1;
         } else {
-            qgs::RkArgs p{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
-            if (use_tiled(m, s, a))
-                HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
-            else
-                qgs::launch_gen_rk(m->dT.view(), p, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
-            qgs::launch_gen_tgl(Jrow, p, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);
+            qgs::launch_gen_tgl(Jrow, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);
             note_kernel(m, "gen_tgl_kernel", nullptr);
             HIPCHK(hipGetLastError());
         }
