@@ -817,27 +817,73 @@ bool tableau_is_subdiagonal(int s, const double *a)
     return true;
 }
 
+std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
+{
+    switch (k) {
+    case Kernel::Tend: return "qgs_spec_tend";
+    case Kernel::Jac: return "qgs_spec_jac";
+    case Kernel::Rk: return "qgs_spec_rk_s" + std::to_string(S);
+    case Kernel::RkSplit: return "qgs_spec_rksplit" + std::to_string(opt.row_split) + "_s" + std::to_string(S);
+    case Kernel::RkStages: return "qgs_spec_rkstages_s" + std::to_string(S);
+    case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
+    case Kernel::TglSplit: return "qgs_spec_tglsplit" + std::to_string(opt.tgl_split) + "_s" + std::to_string(S);
+    }
+    return "";
+}
+
+// One kernel per translation unit: kernels compiled together share the register allocator's context and
+// perturb each other (the plain stepper went from 276 to 324 VGPRs and 4.6 -> 4.7 ms when a 4-way split
+// sibling was added to its module), so every kernel is generated, compiled and cached on its own.
+std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
+                            const CodegenOptions &opt)
+{
+    std::ostringstream o;
+    o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
+    o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
+    const std::vector<Row> rows = build_rows(ndim, tensor);
+    switch (k) {
+    case Kernel::Tend: emit_tend_kernel(o, ndim, rows, opt); break;
+    case Kernel::Jac: emit_jac_kernel(o, ndim, jac_tensor); break;
+    case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt); break;
+    case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt); break;
+    case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt); break;
+    case Kernel::Tgl:
+        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt);
+        break;
+    case Kernel::TglSplit:
+        emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
+                              opt.tgl_split, opt);
+        break;
+    }
+    return o.str();
+}
+
+std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const std::vector<int> &stages, const CodegenOptions &opt_in)
+{
+    CodegenOptions opt = opt_in;
+    if (ndim < 2 * opt.row_split) opt.row_split = 1;      // too few rows to split
+    if (ndim < 2 * opt.tgl_split) opt.tgl_split = 1;
+    std::vector<std::pair<Kernel, int>> l = {{Kernel::Tend, 0}};
+    if (have_jac) l.push_back({Kernel::Jac, 0});
+    for (int S : stages) {
+        l.push_back({Kernel::Rk, S});
+        if (opt.row_split > 1) l.push_back({Kernel::RkSplit, S});
+        if (have_jac) {
+            l.push_back({Kernel::RkStages, S});
+            l.push_back({Kernel::Tgl, S});
+            if (opt.tgl_split > 1) l.push_back({Kernel::TglSplit, S});
+        }
+    }
+    return l;
+}
+
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt)
 {
-    std::ostringstream o;
-    o << PRELUDE << RECORD_HELPERS;
-    o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
-    const std::vector<Row> rows = build_rows(ndim, tensor);
-    emit_tend_kernel(o, ndim, rows, opt);
-    if (!jac_tensor.empty()) emit_jac_kernel(o, ndim, jac_tensor);
-    const auto tgl = build_wx_rows(ndim, jac_tensor, false);
-    const auto adj = build_wx_rows(ndim, jac_tensor, true);
-    for (int S : stages) {
-        emit_rk_kernel(o, ndim, rows, S, false, opt);
-        if (opt.row_split > 1) emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt);
-        if (!jac_tensor.empty()) {
-            emit_rk_kernel(o, ndim, rows, S, true, opt);
-            emit_tgl_kernel(o, ndim, tgl, adj, S, opt);
-            if (opt.tgl_split > 1) emit_tgl_split_kernel(o, ndim, tgl, adj, S, opt.tgl_split, opt);
-        }
-    }
-    return o.str();
+    std::string all;
+    for (auto &ks : kernel_list(ndim, !jac_tensor.empty(), stages, opt))
+        all += generate_kernel(ndim, tensor, jac_tensor, ks.first, ks.second, opt) + "\n";
+    return all;
 }
 
 int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, const CodegenOptions &opt)

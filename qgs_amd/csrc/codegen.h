@@ -10,6 +10,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace qgs {
@@ -28,7 +29,7 @@ struct CodegenOptions {
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
-    int row_split = 2;         // also emit the row-split stepper with this many wavefronts per 64 members
+    int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
 };
 
 // Classification of a Butcher tableau (reference: integrate.py:214-219 uses the full matrix `a`).
@@ -43,6 +44,13 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_tgl_s<S>        tangent / adjoint propagation, one lane per (member, column)
 //                                                                       (integrate.py:226-231, 555-614)
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
+// generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
+// translation unit (generate_kernel), see codegen.cpp.
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit };
+std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
+std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
+                            const CodegenOptions &opt);
+std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const std::vector<int> &stages, const CodegenOptions &opt);
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt);
 

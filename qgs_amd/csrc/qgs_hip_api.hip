@@ -228,8 +228,8 @@ struct qgs_model {
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
     qgs::CodegenOptions cg;
-    // compiled specialised modules: key 0 = base (tend, jac), key S = S-stage steppers
-    std::map<int, hipModule_t> modules;
+    // compiled specialised kernels, one module per kernel (keyed by the kernel name)
+    std::map<std::string, hipModule_t> modules;
     std::map<std::string, hipFunction_t> functions;
     std::string source_all;
     // staged time grid / tableau
@@ -323,35 +323,24 @@ void free_csr(DevCsr &d)
     d = DevCsr();
 }
 
-std::string module_source(const qgs_model *m, int S)
+// Make sure kernel `k` (for S stages) is generated, compiled (or fetched from the cache) and loaded.
+int get_function(qgs_model *m, qgs::Kernel k, int S, hipFunction_t *fn, std::string *name_out = nullptr)
 {
-    // S == 0: tendencies + Jacobian; S > 0: the S-stage steppers
-    std::vector<int> stages;
-    if (S > 0) stages.push_back(S);
-    return qgs::generate_source(m->ndim, S == 0 ? m->T : m->T, m->J, stages, m->cg);
-}
-
-// Make sure the module holding `fname` (for S stages, 0 = base) is compiled and loaded.
-int get_function(qgs_model *m, int S, const std::string &fname, hipFunction_t *fn)
-{
+    const std::string fname = qgs::kernel_name(k, S, m->cg);
+    if (name_out) *name_out = fname;
     auto it = m->functions.find(fname);
     if (it != m->functions.end()) { *fn = it->second; return 0; }
-    if (!m->modules.count(S)) {
-        std::string src = module_source(m, S);
-        if (S > 0) {   // the stepper modules do not need another copy of tend/jac: strip them by regenerating
-            // (generate_source always emits tend/jac first; they are small, keep them: simpler and harmless)
-        }
-        std::vector<char> code;
-        bool cached = false;
-        if (compile_source(src, m->arch, code, &cached)) return -1;
-        hipModule_t mod;
-        HIPCHK(hipModuleLoadData(&mod, code.data()));
-        m->modules[S] = mod;
-        m->source_all += src;
-    }
+    const std::string src = qgs::generate_kernel(m->ndim, m->T, m->J, k, S, m->cg);
+    std::vector<char> code;
+    bool cached = false;
+    if (compile_source(src, m->arch, code, &cached)) return -1;
+    hipModule_t mod;
+    HIPCHK(hipModuleLoadData(&mod, code.data()));
+    m->modules[fname] = mod;
+    m->source_all += src;
     hipFunction_t f;
-    hipError_t e = hipModuleGetFunction(&f, m->modules[S], fname.c_str());
-    if (e != hipSuccess) return fail("kernel " + fname + " not found in the specialised module: " + hipGetErrorString(e));
+    hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
+    if (e != hipSuccess) return fail("kernel " + fname + " not found in its module: " + hipGetErrorString(e));
     m->functions[fname] = f;
     *fn = f;
     return 0;
@@ -435,7 +424,7 @@ bool use_spec(const qgs_model *m, int s, const double *a)
 bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
 {
     if (m->kernel_kind != 0) return false;                 // explicit generic / specialised request
-    int64_t limit = (m->max_row_terms <= 16) ? 4096 : 256;   // measured crossovers (tools/latency_bench.py)
+    int64_t limit = (m->max_row_terms <= 16) ? 2048 : 256;   // measured crossovers (tools/latency_bench.py)
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
     return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
@@ -605,7 +594,7 @@ int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen)
 {
     if (!m) return -1;
     std::string src = m->source_all;
-    if (src.empty() && m->spec_possible) src = module_source(m, 0);
+    if (src.empty() && m->spec_possible) src = qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::Tend, 0, m->cg);
     if (buf && buflen > 0) {
         const size_t n = std::min<size_t>(src.size(), (size_t)buflen - 1);
         std::memcpy(buf, src.data(), n);
@@ -652,7 +641,7 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
     hipStream_t st = (hipStream_t)stream;
     if (use_spec(m, 1, nullptr)) {
         hipFunction_t f;
-        if (get_function(m, 0, "qgs_spec_tend", &f)) return -1;
+        if (get_function(m, qgs::Kernel::Tend, 0, &f)) return -1;
         long long nt = n_traj, l = ld;
         void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
         note_kernel(m, "qgs_spec_tend", f);
@@ -670,7 +659,7 @@ static int jacobian_device(qgs_model *m, int64_t n_traj, int64_t ld, const doubl
     HIPCHK(hipMemsetAsync(d_jm, 0, sizeof(double) * (size_t)m->ndim * m->ndim * ld, st));
     if (use_spec(m, 1, nullptr)) {
         hipFunction_t f;
-        if (get_function(m, 0, "qgs_spec_jac", &f)) return -1;
+        if (get_function(m, qgs::Kernel::Jac, 0, &f)) return -1;
         long long nt = n_traj, l = ld;
         void *args[] = {(void *)&d_x, (void *)&d_jm, &nt, &l};
         note_kernel(m, "qgs_spec_jac", f);
@@ -705,21 +694,22 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         return 0;
     }
     if (use_spec(m, s, a)) {
-        // Plain one-wave-per-64-members stepper by default.  The row-split stepper (R wavefronts per 64 members,
-        // LDS stage exchange) was the faster one with literal coefficients; with coefficient tables the plain
-        // kernel reaches the lone-wave fp64 issue limit (5.75 ms vs 5.95 ms for 65 536 x 1000 steps) and needs
-        // neither LDS nor barriers, so the split is opt-in (QGS_HIP_RK_VARIANT=split).
+        // Kernel choice by ensemble size (measured, tools/kbench.py / tools/latency_bench.py, MAOOAM-36, ms per 1000 steps):
+        //   n <= 2048      wave-per-trajectory kernel (handled above)        0.8-1.5
+        //   n <= 40960     row-split stepper, R = 4 wavefronts per 64 members: 2.4 (n <= 16384), 3.7 (n = 32768) -- the
+        //                  chip is not full, so splitting the rows over more wavefronts shortens every trajectory
+        //   above          plain one-wave-per-64-members stepper: 4.6 at 65 536 members (fp64 VALU ~89 % busy);
+        //                  the split needs LDS + a barrier per stage and loses there (5.9)
         const int R = m->cg.row_split;
         const int64_t waves = (n_traj + 63) / 64;
-        bool split = false;
+        bool split = R > 1 && m->ndim >= 2 * R && waves * R <= (int64_t)m->n_simd * 5 / 2;
         if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
             if (!std::strcmp(e, "plain")) split = false;
-            if (!std::strcmp(e, "split") && R > 1) split = true;
+            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) split = true;
         }
         hipFunction_t f;
-        const std::string name = split ? "qgs_spec_rksplit" + std::to_string(R) + "_s" + std::to_string(s)
-                                       : "qgs_spec_rk_s" + std::to_string(s);
-        if (get_function(m, s, name, &f)) return -1;
+        std::string name;
+        if (get_function(m, split ? qgs::Kernel::RkSplit : qgs::Kernel::Rk, s, &f, &name)) return -1;
         double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
         int bw = backward, wf = 1;
@@ -799,8 +789,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
         } else if (spec) {
             hipFunction_t f1;
-            const std::string n1 = "qgs_spec_rkstages_s" + std::to_string(s);
-            if (get_function(m, s, n1, &f1)) return -1;
+            if (get_function(m, qgs::Kernel::RkStages, s, &f1)) return -1;
             void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
             if (launch(f1, n_traj, st, a1)) return -1;
@@ -816,12 +805,11 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
         } else if (spec) {
             // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
-            bool tgl_split = m->cg.tgl_split > 1;
+            bool tgl_split = m->cg.tgl_split > 1 && m->ndim >= 2 * m->cg.tgl_split;
             if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
-            const std::string n2 = tgl_split ? "qgs_spec_tglsplit" + std::to_string(m->cg.tgl_split) + "_s" + std::to_string(s)
-                                             : "qgs_spec_tgl_s" + std::to_string(s);
             hipFunction_t f2;
-            if (get_function(m, s, n2, &f2)) return -1;
+            std::string n2;
+            if (get_function(m, tgl_split ? qgs::Kernel::TglSplit : qgs::Kernel::Tgl, s, &f2, &n2)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
@@ -953,12 +941,11 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, i
     for (int64_t e = 0; e < nnz; ++e) m.T.push_back({coo[3 * e], coo[3 * e + 1], coo[3 * e + 2], val[e]});
     for (int64_t e = 0; e < jnnz; ++e) m.J.push_back({jcoo[3 * e], jcoo[3 * e + 1], jcoo[3 * e + 2], jval[e]});
     apply_env_options(m.cg);
-    std::vector<int> all = {0};
-    for (int i = 0; i < n_stage_counts; ++i) all.push_back(stage_counts[i]);
-    for (int S : all) {
+    std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
+    for (auto &ks : qgs::kernel_list(m.ndim, !m.J.empty(), stages, m.cg)) {
         std::vector<char> code;
         bool cached;
-        if (compile_source(module_source(&m, S), m.arch, code, &cached)) return -1;
+        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg), m.arch, code, &cached)) return -1;
     }
     return 0;
 }

@@ -182,7 +182,7 @@ def test_linearity_of_tangent_model(models):
 
 
 @pytest.mark.parametrize('env', [{'QGS_HIP_RK_VARIANT': 'plain'}, {'QGS_HIP_RK_VARIANT': 'split'},
-                                 {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '3'},
+                                 {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '2'}, {'QGS_HIP_KTAB_GROUP': '0'},
                                  {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
 def test_kernel_variants_agree_with_oracle(monkeypatch, env):
     """Every code-generation / kernel-selection variant (plain one-wave stepper, row split 2 and 3, literal
