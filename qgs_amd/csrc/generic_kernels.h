@@ -90,9 +90,9 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
 
 // Batched Householder QR (LAPACK dgeqr2 + dorg2r conventions: R_jj = -sign(a_jj)*||.||) of one
 // (n_rows x n_cols) matrix per member in the device layout A[row][col][member]; A is overwritten by Q,
-// rdiag[col][member] receives diag(R), tau[col][member] is scratch.  Used by the Benettin Lyapunov
+// rdiag[col][member] receives diag(R).  Used by the Benettin Lyapunov
 // estimator (reference: np.linalg.qr in qgs/toolbox/lyapunov.py:540-547, 599-628).
-void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *tau, hipStream_t st);
+void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st);
 
 // Layout conversion kernels (host layout <-> device layout), see include/qgs_hip.h
 void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);

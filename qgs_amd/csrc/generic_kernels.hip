@@ -564,15 +564,13 @@ __device__ __forceinline__ double qr_col_dot(const double *A, int j, int c, int 
 }
 
 __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
-                                                          double *__restrict__ a, double *__restrict__ rdiag,
-                                                          double *__restrict__ tau_unused)
+                                                          double *__restrict__ a, double *__restrict__ rdiag)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *A = (double *)smem;                            // [n_rows][QR_STRIDE]
     const int64_t m = blockIdx.x;
     const int c = threadIdx.x;                             // own column
     const bool col = c < n_cols;
-    (void)tau_unused;
     for (int i = 0; i < n_rows; ++i) A[i * QR_STRIDE + c] = col ? a[((int64_t)i * n_cols + c) * ld + m] : 0.0;
     __syncthreads();
     const int k = n_cols < n_rows ? n_cols : n_rows;
@@ -742,7 +740,7 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
     return hipErrorInvalidValue;
 }
 
-void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *tau, hipStream_t st)
+void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (size_t)n_rows * QR_STRIDE;
     static size_t configured = 64 * 1024;
@@ -750,7 +748,7 @@ void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, doubl
         if (hipFuncSetAttribute((const void *)batched_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             configured = lds;
     }
-    hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)n_traj), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag, tau);
+    hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)n_traj), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag);
 }
 
 bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }

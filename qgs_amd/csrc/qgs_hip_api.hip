@@ -236,7 +236,7 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_qr_tau;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2;
     KernelInfo last;
 };
 
@@ -550,7 +550,7 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_qr_tau})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2})
         b->release();
     delete m;
     return 0;
@@ -834,8 +834,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows) return fail("batched QR needs 1 <= n_cols <= n_rows");
     if (n_cols > 64 || n_rows > 300) return fail("batched QR supports n_cols <= 64 (one column per lane) and n_rows <= 300 (LDS)");
     HIPCHK(hipSetDevice(m->device));
-    if (m->b_qr_tau.ensure(sizeof(double) * (size_t)n_cols * ld)) return -1;
-    qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->b_qr_tau.f64(), (hipStream_t)stream);
+    qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
