@@ -152,3 +152,37 @@ def test_trajectories_statistics(setup):
     _, traj = integ.get_trajectories()
     assert rel_err(one[0], traj.mean(axis=0)) < 1e-15
     integ.terminate()
+
+
+def test_user_defined_quadratic_system_lorenz63():
+    """The integrators accept any system of the form dx_i = sum T_ijk x_j x_k (x_0 = 1), not only qgs models:
+    Lorenz-63 written as a COO tensor (the reference's docstrings integrate such user systems with jitted
+    Python functions; here the tensor form runs on the same kernels)."""
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+    from oracle.oracle import OracleModel
+    sigma, rho, beta = 10., 28., 8. / 3.
+    terms = [(1, 0, 1, -sigma), (1, 0, 2, sigma),                 # dx = sigma (y - x)
+             (2, 0, 1, rho), (2, 0, 2, -1.), (2, 1, 3, -1.),       # dy = x (rho - z) - y
+             (3, 1, 2, 1.), (3, 0, 3, -beta)]                       # dz = x y - beta z
+    coo = np.array([t[:3] for t in terms], dtype=np.int32)
+    val = np.array([t[3] for t in terms])
+    jterms = []
+    for i, j, k, v in terms:                                        # Jacobian tensor: T + T.swapaxes(1, 2)
+        jterms += [(i, j, k, v), (i, k, j, v)]
+    jcoo = np.array([t[:3] for t in jterms], dtype=np.int32)
+    jval = np.array([t[3] for t in jterms])
+    f, Df = tendencies_from_tensor(3, coo, val, jcoo, jval)
+    x = np.array([1., 2., 3.])
+    assert np.allclose(f(0., x), [sigma * (2. - 1.), 1. * (rho - 3.) - 2., 1. * 2. - beta * 3.], rtol=1e-15)
+    assert np.allclose(Df(0., x), [[-sigma, sigma, 0.], [rho - 3., -1., -1.], [2., 1., -beta]], rtol=1e-15)
+    ic = np.random.RandomState(0).rand(300, 3)
+    integ = RungeKuttaIntegrator()
+    integ.set_func(f)
+    integ.integrate(0., 1., 0.01, ic=ic, write_steps=10)
+    tt, traj = integ.get_trajectories()
+    ref = OracleModel(3, coo, val).integrate_runge_kutta_jit(np.concatenate((np.arange(0., 1., 0.01), [1.])), ic, 1, 10,
+                                                              integ.b, integ.c, integ.a, threads=4)
+    assert traj.shape == ref.shape and rel_err(traj, ref) < 1e-11        # chaotic system, 100 steps
+    integ.terminate()
+    f.operands.release()
