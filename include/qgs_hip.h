@@ -57,7 +57,12 @@ int qgs_model_destroy(qgs_model *m);
 int64_t qgs_model_info(const qgs_model *m, int which);
 
 /* Select the kernel family: 0 = automatic (specialised when available, else generic),
- * 1 = force generic (tensor streamed from memory, any ndim), 2 = force specialised. */
+ * 1 = force generic (tensor streamed from memory, any ndim), 2 = force specialised.
+ * Specialised = code generated from the tensor and compiled at run time (cached on disk): register-resident
+ * kernels up to 64 variables; beyond that (stage state <= 152 KB of LDS, i.e. ndim <= 304) the LDS-resident
+ * stepper serves the trajectory integrations, f / Df / the tangent pass stay generic.  In automatic mode
+ * the LDS-resident stepper is used when its code object is already cached or the run is long enough to pay for
+ * the ~20 s compilation. */
 int qgs_model_set_kernel(qgs_model *m, int kind);
 
 /* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) -------------- */

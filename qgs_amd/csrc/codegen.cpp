@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <functional>
 #include <map>
 #include <sstream>
@@ -30,9 +31,18 @@ struct KTable {
     size_t cursor = 0;
 };
 thread_local KTable *g_ktab = nullptr;
+thread_local bool g_asm_lit = false;      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
 
 std::string lit(double v)
 {
+    if (g_asm_lit) {
+        unsigned long long u;
+        static_assert(sizeof u == sizeof v, "");
+        std::memcpy(&u, &v, sizeof u);
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "QGS_LIT(0x%08x, 0x%08x)", (unsigned)(u >> 32), (unsigned)(u & 0xffffffffu));
+        return std::string(buf);
+    }
     if (!g_ktab) return hexlit(v);
     return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
 }
@@ -315,6 +325,10 @@ typedef const double __attribute__((address_space(4))) kf64;   // coefficient ta
 typedef double v8d __attribute__((ext_vector_type(8)));
 typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
 #define QGS_WAVE 64
+// fp64 coefficient materialised by two s_mov_b32 right where it is used: the instruction stream (sequentially
+// prefetched) carries the tensor, no scalar-cache traffic, and the compiler can neither hoist nor merge the constants
+#define QGS_LIT(hi, lo) ({ unsigned l_, h_; asm volatile("s_mov_b32 %0, " #lo "\n\ts_mov_b32 %1, " #hi : "=s"(l_), "=s"(h_)); \
+    __builtin_bit_cast(f64, ((unsigned long long)h_ << 32) | l_); })
 )";
 
 // Record bookkeeping shared by the steppers (reference integrate.py:190-223): record `iw` of the directed
@@ -328,6 +342,12 @@ __device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward
 // step in a counter instead of dividing every step
 #define QGS_REC_INIT i64 iw = 0, next_rec = -1; \
     if (write_steps > 0) { iw = (step_begin + write_steps - 1) / write_steps; next_rec = iw * write_steps; }
+// mask ? a : b on the bit patterns (mask is all ones or all zeros), branch-free
+__device__ __forceinline__ f64 qgs_bitsel(unsigned long long mask, f64 a, f64 b)
+{
+    const unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    return __builtin_bit_cast(f64, (ua & mask) | (ub & ~mask));
+}
 )";
 
 void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
@@ -807,6 +827,291 @@ void emit_tgl_split_kernel(std::ostringstream &out, int ndim, const std::vector<
     out << o.str();
 }
 
+
+// ---- LDS-resident stepper for systems that do not fit the register file (MAOOAM 6x6: ndim 228) ------------
+// A workgroup of W wavefronts advances 64 members; the stage state lives in LDS as xs[mode][member] and wave w
+// evaluates a contiguous block of rows.  The run-time-indexed generic kernel needs two LDS reads per tensor term
+// (LDS-bound: measured 21 % of the fp64 rate).  Here the (j,k) pattern is compile-time knowledge, so the terms of
+// a wave are reordered into "phases": a phase loads a small set of modes (<= cap) into registers once and then
+// executes every term of the wave whose two factors are both in the set.  On the MAOOAM 6x6 tensor that is
+// ~0.17 LDS reads per term instead of 2, and a product x_j*x_k needed by several rows of the wave is computed once
+// (1.6 fp64 instructions per term instead of 2).
+struct PTerm { int row, j, k; double c; };      // j <= k; j == 0: linear term c*x_k
+
+struct Phase {
+    std::vector<int> modes;                     // loaded at the head of the phase (ascending)
+    std::vector<PTerm> terms;                   // sorted by (j, k, row)
+};
+
+std::vector<Phase> build_phases(int ndim, const std::vector<PTerm> &terms, int cap)
+{
+    typedef std::pair<int, int> Edge;
+    std::map<Edge, std::vector<PTerm>> rem;
+    for (const PTerm &t : terms) rem[{t.j, t.k}].push_back(t);
+    std::vector<std::vector<int>> adj(ndim + 1);
+    for (auto &kv : rem) {
+        adj[kv.first.first].push_back(kv.first.second);
+        if (kv.first.second != kv.first.first) adj[kv.first.second].push_back(kv.first.first);
+    }
+    auto count = [&](int a, int b) -> int {
+        auto it = rem.find({std::min(a, b), std::max(a, b)});
+        return it == rem.end() ? 0 : (int)it->second.size();
+    };
+    std::vector<Phase> phases;
+    while (!rem.empty()) {
+        std::vector<int> deg(ndim + 1, 0), gain(ndim + 1, 0);
+        std::vector<char> in(ndim + 1, 0);
+        for (auto &kv : rem) {
+            deg[kv.first.first] += (int)kv.second.size();
+            if (kv.first.second != kv.first.first) deg[kv.first.second] += (int)kv.second.size();
+        }
+        in[0] = 1;                                              // x_0 = 1 needs no register
+        int n_in = 0;
+        auto add = [&](int m) {
+            in[m] = 1; ++n_in;
+            for (int o : adj[m]) if (!in[o]) gain[o] += count(m, o);
+        };
+        for (int o : adj[0]) if (!in[o]) gain[o] += count(0, o);
+        int seed = 0;
+        for (int m = 1; m <= ndim; ++m)
+            if (deg[m] > 0 && (seed == 0 || deg[m] > deg[seed])) seed = m;
+        if (seed == 0) break;                                   // cannot happen: every remaining edge has a mode >= 1
+        add(seed);
+        while (n_in < cap) {
+            int cand = 0, best = 0;
+            for (int m = 1; m <= ndim; ++m) {
+                if (in[m]) continue;
+                const int sc = gain[m] + count(m, m);
+                if (sc > best || (sc == best && sc > 0 && deg[m] > deg[cand])) { best = sc; cand = m; }
+            }
+            if (cand == 0 || best <= 0) break;
+            add(cand);
+        }
+        Phase ph;
+        for (int m = 1; m <= ndim; ++m) if (in[m]) ph.modes.push_back(m);
+        for (auto it = rem.begin(); it != rem.end();) {
+            if (in[it->first.first] && in[it->first.second]) {
+                for (const PTerm &t : it->second) ph.terms.push_back(t);
+                it = rem.erase(it);
+            } else ++it;
+        }
+        // drop modes that ended up unused (a seed whose partners did not fit)
+        std::vector<char> used(ndim + 1, 0);
+        for (const PTerm &t : ph.terms) { used[t.j] = 1; used[t.k] = 1; }
+        std::vector<int> keep;
+        for (int m : ph.modes) if (used[m]) keep.push_back(m);
+        ph.modes.swap(keep);
+        if (ph.terms.empty()) break;                            // cannot happen for cap >= 2 (seed + one partner completes an edge)
+        phases.push_back(std::move(ph));
+    }
+    return phases;
+}
+
+void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+{
+    const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
+    const std::string kname = "qgs_spec_rklds" + std::to_string(W);
+    // Row blocks: neighbouring rows share most of their factors, so blocks are contiguous in a row sequence and
+    // balanced by cost; cheap rows (MAOOAM: the ocean rows) are first spread evenly through that sequence, otherwise
+    // one wavefront would own all of them and need twice the registers for its row state.
+    std::vector<int64_t> cost(ndim + 1, 0);
+    int64_t total = 0;
+    for (int i = 1; i <= ndim; ++i) { cost[i] = 1 + (int64_t)rows[i].lin.size() + 2 * (int64_t)rows[i].bil.size(); total += cost[i]; }
+    std::vector<int> seq;
+    {
+        std::vector<int> heavy, light;
+        for (int i = 1; i <= ndim; ++i) ((cost[i] * 2 * ndim < total) ? light : heavy).push_back(i);
+        int64_t heavy_total = 0, run = 0;
+        for (int i : heavy) heavy_total += cost[i];
+        size_t nl = 0;
+        for (int i : heavy) {
+            seq.push_back(i);
+            run += cost[i];
+            while (nl < light.size() && run * (int64_t)light.size() >= heavy_total * (int64_t)(nl + 1)) seq.push_back(light[nl++]);
+        }
+        while (nl < light.size()) seq.push_back(light[nl++]);
+    }
+    std::vector<std::vector<int>> owns(W);
+    {
+        int w = 0;
+        int64_t run = 0;
+        for (size_t q = 0; q < seq.size(); ++q) {
+            owns[w].push_back(seq[q]);
+            run += cost[seq[q]];
+            const size_t left = seq.size() - 1 - q;
+            if (w + 1 < W && (run * W >= total * (w + 1) || left <= (size_t)(W - 1 - w))) ++w;
+        }
+        for (auto &v : owns) std::sort(v.begin(), v.end());
+    }
+    std::ostringstream o;
+    std::vector<KTable> tables(W);
+    o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members,\n"
+      << "// factors cached in registers per phase (cap " << cap << ")\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
+      << "    const f64* __restrict__ y_in,\n"
+      << "    f64* __restrict__ y_out,        // final state, X[mode][member] (may be null)\n"
+      << "    f64* __restrict__ ywork,        // private [workgroup][mode][64]: state at the start of the current step, re-read at\n"
+      << "                                    // the end of every stage instead of being held in registers\n"
+      << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S)\n{\n";
+    o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x & 63;\n"
+      << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+      << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
+      << "    const bool live = m0 < n_traj;\n"
+      << "    const i64 m = live ? m0 : (n_traj - 1);\n"
+      << "    f64* const yw = ywork + (i64)blockIdx.x * " << ndim * 64 << " + lane;   // row d of this member at yw[(d-1)*64]\n";
+    int64_t n_loads = 0, n_instr = 0, n_phases = 0, n_coef = 0;
+    for (int w = 0; w < W; ++w) {
+        const std::vector<int> &own = owns[w];
+        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
+        for (int i : own) o << " " << i;
+        o << "\n";
+        const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
+        // acc<r>: running y + dt*sum b_i k_i; equals the state y at every step boundary
+        for (int d : own) o << I2 << "f64 acc" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+        for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        o << I2 << "__syncthreads();\n";
+        o << I2 << "QGS_REC_INIT\n";
+        o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+        o << I3 << "if (ti == next_rec) {\n"
+          << I4 << "i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));   // keeps the row offsets out of the loop-invariant set\n"
+          << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ldr + m;\n"
+          << I4 << "++iw; next_rec += write_steps;\n"
+          << I4 << "if (live) {\n";
+        for (int d : own) o << I4 << "    p[" << (d - 1) << " * ldr] = acc" << d << ";\n";
+        o << I4 << "}\n" << I3 << "}\n";
+        o << "#pragma nounroll\n";
+        o << I3 << "for (int st = 0; st < S; ++st) {\n";
+        o << I4 << "const bool last = (st == S - 1);\n";
+        o << I4 << "const f64 hb = dt * tab[st];\n";
+        o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
+        // opaque per-stage values: the compiler must not hoist the re-reads of the step-start state out of the stage
+        // loop (they would occupy registers for the whole step), nor turn the last-stage select into a branch that
+        // sinks those loads to their use
+        o << I4 << "i64 yoff = 0; asm volatile(\"\" : \"+s\"(yoff));\n";
+        o << I4 << "unsigned long long lastmask = last ? ~0ull : 0ull; asm volatile(\"\" : \"+v\"(lastmask));\n";
+        o << I4 << "if (stages && live) {\n"
+          << I4 << "    i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
+          << I4 << "    f64* sp = stages + ((ti - step_begin) * S + st) * " << ndim << " * ldr + m;\n";
+        for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
+        o << I4 << "}\n";
+        const bool table = opt.lds_coeff_table;
+        if (table) {
+            g_ktab = &tables[w];
+            o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
+        } else g_asm_lit = true;
+        std::ostringstream so;
+        std::vector<PTerm> terms;
+        for (int i : own) {
+            const Row &r = rows[i];
+            if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << lit(r.c0) << ";\n";
+            else so << I4 << "f64 k" << i << " = 0.0;\n";
+            for (const Lin &l : r.lin) terms.push_back({i, 0, l.k, l.c});
+            for (const Bil &b : r.bil) terms.push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+        }
+        const std::vector<Phase> phases = build_phases(ndim, terms, cap);
+        int ph_id = 0, prod_id = 0;
+        const int y_load_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));   // == size(): after the last phase
+        for (const Phase &ph : phases) {
+            if (ph_id == y_load_phase)                 // step-start state of the own rows, consumed at the end of the stage
+                for (int d : own) so << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
+            const std::string sfx = "_" + std::to_string(ph_id++);
+            // opaque lane offset per phase: otherwise the compiler merges the reads of one mode in different phases
+            // and keeps the value in a register (or scratch) in between
+            // (ds_read offsets are 16-bit immediates: modes beyond 64 KB go through a second base register)
+            so << I4 << "unsigned lo" << sfx << " = lane8; asm volatile(\"\" : \"+v\"(lo" << sfx << "));\n";
+            bool high = false;
+            for (int mo : ph.modes) high = high || (mo - 1) * 512 >= 65536;
+            if (high) so << I4 << "unsigned lh" << sfx << " = lane8 + 65536u; asm volatile(\"\" : \"+v\"(lh" << sfx << "));\n";
+            for (int mo : ph.modes) {
+                const int off = (mo - 1) * 512;
+                if (off < 65536) so << I4 << "const f64 x" << mo << sfx << " = *(const f64*)((const char*)xs + " << off << " + lo" << sfx << ");\n";
+                else so << I4 << "const f64 x" << mo << sfx << " = *(const f64*)((const char*)xs + " << off - 65536 << " + lh" << sfx << ");\n";
+            }
+            n_loads += (int64_t)ph.modes.size();
+            ++n_phases;
+            // Bilinear terms of one row with equal |coefficient| that fall into this phase are summed first
+            // (c * (x_a x_b - x_c x_d ...): one fused multiply-add per term plus one for the coefficient); the
+            // remaining single terms share their product x_j x_k between the rows of the wave that need it.
+            std::map<std::pair<int, double>, std::vector<PTerm>> pieces;
+            std::vector<PTerm> singles;
+            for (const PTerm &t : ph.terms) {
+                if (t.j == 0 || !opt.lds_group) singles.push_back(t);
+                else pieces[{t.row, std::fabs(t.c)}].push_back(t);
+            }
+            for (auto &kv : pieces) {
+                const std::vector<PTerm> &g = kv.second;
+                if (g.size() == 1) { singles.push_back(g[0]); continue; }
+                const std::string gname = "g" + std::to_string(prod_id++);
+                const bool ref_neg = std::signbit(g[0].c);
+                std::vector<Prod> ps;
+                for (const PTerm &t : g)
+                    ps.push_back({std::signbit(t.c) != ref_neg, "x" + std::to_string(t.j) + sfx, "x" + std::to_string(t.k) + sfx});
+                emit_group(so, I4, gname, ps);
+                so << I4 << "k" << g[0].row << " = __builtin_fma(" << lit(g[0].c) << ", " << gname << ", k" << g[0].row << ");\n";
+                n_instr += (int64_t)g.size() + 1;
+                ++n_coef;
+            }
+            std::sort(singles.begin(), singles.end(), [](const PTerm &x, const PTerm &y) {
+                return x.j != y.j ? x.j < y.j : (x.k != y.k ? x.k < y.k : x.row < y.row);
+            });
+            size_t a = 0;
+            while (a < singles.size()) {
+                size_t b = a;
+                while (b < singles.size() && singles[b].j == singles[a].j && singles[b].k == singles[a].k) ++b;
+                const PTerm &t0 = singles[a];
+                std::string factor;
+                if (t0.j == 0) factor = "x" + std::to_string(t0.k) + sfx;
+                else {
+                    const std::string pr = "x" + std::to_string(t0.j) + sfx + " * x" + std::to_string(t0.k) + sfx;
+                    if (b - a > 1) {
+                        factor = "p" + std::to_string(prod_id++);
+                        so << I4 << "const f64 " << factor << " = " << pr << ";\n";
+                    } else factor = "(" + pr + ")";
+                    ++n_instr;
+                }
+                for (size_t q = a; q < b; ++q) {
+                    so << I4 << "k" << singles[q].row << " = __builtin_fma(" << lit(singles[q].c) << ", " << factor << ", k" << singles[q].row << ");\n";
+                    ++n_instr;
+                    ++n_coef;
+                }
+                a = b;
+            }
+        }
+        if (y_load_phase == (int)phases.size())
+            for (int d : own) so << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
+        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
+        g_ktab = nullptr;
+        g_asm_lit = false;
+        for (int d : own) {
+            o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
+            o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";
+        }
+        o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
+        for (int d : own) o << I4 << "xs[" << (d - 1) << "][lane] = k" << d << ";\n";
+        o << I4 << "__syncthreads();\n";
+        o << I3 << "}\n";
+        // the new state is the start of the next step (stored after the barriers: a barrier waits for outstanding stores)
+        for (int d : own) o << I3 << "yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        o << I2 << "}\n";
+        o << I2 << "if (live) {\n" << I3 << "if (y_out) {\n";
+        for (int d : own) o << I4 << "y_out[" << (d - 1) << " * ld + m] = acc" << d << ";\n";
+        o << I3 << "}\n" << I3 << "if (write_final) {\n"
+          << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
+        for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = acc" << d << ";\n";
+        o << I3 << "}\n" << I2 << "}\n    }\n";
+    }
+    o << "}\n";
+    out << "// per stage and 64 members: " << n_phases << " phases, " << n_loads << " LDS reads, " << n_instr << " fp64 instructions, " << n_coef << " coefficient fetches\n";
+    if (opt.lds_coeff_table)
+        for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    out << o.str();
+}
+
 }  // namespace
 
 bool tableau_is_subdiagonal(int s, const double *a)
@@ -827,6 +1132,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkStages: return "qgs_spec_rkstages_s" + std::to_string(S);
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::TglSplit: return "qgs_spec_tglsplit" + std::to_string(opt.tgl_split) + "_s" + std::to_string(S);
+    case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
     }
     return "";
 }
@@ -854,6 +1160,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
         emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
                               opt.tgl_split, opt);
         break;
+    case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt); break;
     }
     return o.str();
 }

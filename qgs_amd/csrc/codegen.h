@@ -30,6 +30,12 @@ struct CodegenOptions {
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
+    int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
+    int lds_cap = 24;          // ... and modes cached in registers per phase
+    bool lds_group = false;    // ... sum equal-|coefficient| terms of a row inside a phase first (fewer instructions and
+                               //     coefficient fetches, but measured 10 % slower at 16 waves: longer dependent chains, more spills)
+    bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
+    int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
 };
 
 // Classification of a Butcher tableau (reference: integrate.py:214-219 uses the full matrix `a`).
@@ -41,12 +47,14 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_jac             Df(x) for an ensemble                      (tendencies.py:117-121)
 //   qgs_spec_rk_s<S>         fused S-stage RK trajectory stepper        (integrate.py:182-223)
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
+//   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
+//                            registers phase by phase; run-time stage count, optional stage store
 //   qgs_spec_tgl_s<S>        tangent / adjoint propagation, one lane per (member, column)
 //                                                                       (integrate.py:226-231, 555-614)
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt);

@@ -27,6 +27,9 @@
 #include "codegen.h"
 #include "generic_kernels.h"
 
+#ifndef QGS_LDS_STATE_BYTES
+#define QGS_LDS_STATE_BYTES (152 * 1024)   // stage state of the LDS-resident stepper: ndim * 64 members * 8 B (160 KB LDS per CU)
+#endif
 #ifndef QGS_SPEC_MAX_NDIM
 #define QGS_SPEC_MAX_NDIM 64      // register-resident specialised kernels up to this many variables
 #endif
@@ -95,9 +98,9 @@ std::string target_arch(int device)
 std::vector<std::string> default_extra_flags() { return {}; }
 
 // source -> code object (hsaco), through the on-disk cache
-int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+// developer knob: extra compiler flags, e.g. QGS_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+std::vector<std::string> extra_flags()
 {
-    // developer knob: extra compiler flags, e.g. QGS_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
     std::vector<std::string> extra;
     if (const char *e = std::getenv("QGS_HIP_EXTRA_FLAGS")) {
         std::istringstream is(e);
@@ -105,11 +108,28 @@ int compile_source(const std::string &src, const std::string &arch, std::vector<
     } else {
         extra = default_extra_flags();
     }
+    return extra;
+}
+
+std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra)
+{
     std::string opts_key = arch + "|O3|c++17|v1";
     for (const auto &x : extra) opts_key += "|" + x;
     char name[64];
     std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
-    const std::string path = cache_dir() + "/" + name + ".hsaco";
+    return cache_dir() + "/" + name + ".hsaco";
+}
+
+bool source_is_cached(const std::string &src, const std::string &arch)
+{
+    std::ifstream f(cache_path(src, arch, extra_flags()), std::ios::binary);
+    return (bool)f;
+}
+
+int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+{
+    const std::vector<std::string> extra = extra_flags();
+    const std::string path = cache_path(src, arch, extra);
     {
         std::ifstream f(path, std::ios::binary);
         if (f) {
@@ -227,6 +247,8 @@ struct qgs_model {
     int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
+    bool lds_spec_possible = false;   // too large for the register file, stage state fits LDS: JIT LDS-resident stepper
+    mutable int lds_on_disk = -1;     // -1 not checked yet, 0 / 1: code object of that stepper is in the kernel cache
     qgs::CodegenOptions cg;
     // compiled specialised kernels, one module per kernel (keyed by the kernel name)
     std::map<std::string, hipModule_t> modules;
@@ -236,7 +258,7 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork;
     KernelInfo last;
 };
 
@@ -409,6 +431,11 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) cg.lds_cap = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
 }
 
 bool use_spec(const qgs_model *m, int s, const double *a)
@@ -439,11 +466,47 @@ bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
     return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
 
+// JIT LDS-resident stepper for systems beyond the register file (codegen.cpp emit_rk_lds_kernel).  Compiling it takes
+// about 20 s for MAOOAM 6x6 (once: the code object is cached on disk), so in auto mode it is used when the code object
+// is already there, for runs long enough to pay for the compilation, or when requested with qgs_model_set_kernel(m, 2).
+bool use_lds_spec(const qgs_model *m, int64_t n_traj, int64_t n_steps, int s, const double *a)
+{
+    if (m->kernel_kind == 1 || !m->lds_spec_possible) return false;
+    if (s < 1 || s > 64 || !qgs::tableau_is_subdiagonal(s, a)) return false;
+    if (const char *e = std::getenv("QGS_HIP_LDS")) return *e == '1';
+    if (m->kernel_kind == 2) return true;
+    if (m->functions.count(qgs::kernel_name(qgs::Kernel::RkLds, 0, m->cg))) return true;   // already loaded
+    if (m->lds_on_disk < 0)
+        m->lds_on_disk = source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::RkLds, 0, m->cg), m->arch) ? 1 : 0;
+    if (m->lds_on_disk == 1) return true;                                                   // built earlier (qgs_prebuild / a previous run)
+    return (double)n_traj * (double)n_steps * (double)s * (double)m->T.size() >= 2e12;      // ~10 s of the tiled generic kernel
+}
+
 // tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
 bool use_tiled(const qgs_model *m, int s, const double *a)
 {
     if (const char *e = std::getenv("QGS_HIP_GENERIC")) if (!std::strcmp(e, "simple")) return false;
     return s >= 1 && s <= 8 && qgs::tiled_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+}
+
+// LDS-resident JIT stepper launch (codegen.cpp emit_rk_lds_kernel): W wavefronts per 64 members
+int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, double *y_out, double *d_rec, double *stages,
+                  const double *d_time, const double *d_tab, int64_t step_begin, int64_t step_end, int64_t write_steps,
+                  int64_t n_records, int backward, int write_final, int s, hipStream_t st)
+{
+    hipFunction_t f;
+    std::string name;
+    if (get_function(m, qgs::Kernel::RkLds, 0, &f, &name)) return -1;
+    const int64_t blocks = (n_traj + 63) / 64;
+    if (m->b_ywork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)blocks)) return -1;
+    double *yw = m->b_ywork.f64();
+    long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
+    int bw = backward, wf = write_final, S = s;
+    void *args[] = {(void *)&y_in, &y_out, &yw, &d_rec, &stages, (void *)&d_time, (void *)&d_tab,
+                    &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S};
+    note_kernel(m, name, f);
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
+    return 0;
 }
 
 int check_common(const qgs_model *m, int64_t n_traj, int64_t ld)
@@ -536,6 +599,7 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
     HostCsr hJj = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.j; }, [&](const qgs::Term &t) { return pack(t.i, t.k); });
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j) || upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
     m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM);
+    m->lds_spec_possible = !m->spec_possible && (size_t)ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
     apply_env_options(m->cg);
     *out = m;
     return 0;
@@ -550,7 +614,7 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork})
         b->release();
     delete m;
     return 0;
@@ -564,7 +628,7 @@ int64_t qgs_model_info(const qgs_model *m, int which)
     case 1: return (int64_t)m->T.size();
     case 2: return (int64_t)m->J.size();
     case 3: return m->device;
-    case 4: return m->spec_possible ? 1 : 0;
+    case 4: return (m->spec_possible || m->lds_spec_possible) ? 1 : 0;
     default: return -1;
     }
 }
@@ -573,7 +637,7 @@ int qgs_model_set_kernel(qgs_model *m, int kind)
 {
     if (!m) return fail("null model");
     if (kind < 0 || kind > 2) return fail("kind must be 0, 1 or 2");
-    if (kind == 2 && !m->spec_possible) return fail("specialised kernels are not available for this ndim");
+    if (kind == 2 && !m->spec_possible && !m->lds_spec_possible) return fail("specialised kernels are not available for this ndim");
     m->kernel_kind = kind;
     return 0;
 }
@@ -720,6 +784,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, split ? 64 * R : 64, 1, 1, 0, st, args, nullptr));
         return 0;
     }
+    if (use_lds_spec(m, n_traj, n_time - 1, s, a))
+        return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
+                             n_records, backward, 1, s, st);
     qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
     if (use_tiled(m, s, a)) {
         HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
@@ -793,6 +860,9 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
             if (launch(f1, n_traj, st, a1)) return -1;
+        } else if (use_lds_spec(m, n_traj, n_steps, s, a)) {
+            if (launch_rk_lds(m, n_traj, ld, y_src, y_state, d_rec, stages, d_time, d_tab_spec, begin, end, write_steps, n_records,
+                              backward, final_chunk, s, st)) return -1;
         } else if (use_tiled(m, s, a)) {
             HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
         } else {
@@ -933,7 +1003,6 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
                  const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
 {
-    if (ndim > QGS_SPEC_MAX_NDIM) return 0;
     qgs_model m;
     m.ndim = ndim;
     m.arch = (arch && *arch) ? arch : target_arch(-1);
@@ -941,6 +1010,12 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, i
     for (int64_t e = 0; e < jnnz; ++e) m.J.push_back({jcoo[3 * e], jcoo[3 * e + 1], jcoo[3 * e + 2], jval[e]});
     apply_env_options(m.cg);
     std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
+    if (ndim > QGS_SPEC_MAX_NDIM) {
+        if ((size_t)ndim * 512 > (size_t)QGS_LDS_STATE_BYTES || m.T.size() > 200000) return 0;
+        std::vector<char> code;
+        bool cached;
+        return compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg), m.arch, code, &cached) ? -1 : 0;
+    }
     for (auto &ks : qgs::kernel_list(m.ndim, !m.J.empty(), stages, m.cg)) {
         std::vector<char> code;
         bool cached;

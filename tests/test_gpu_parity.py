@@ -98,6 +98,36 @@ def test_ragged_ensemble_sizes_vs_oracle(models, n_traj):
         assert rel_err(m.rk_integrate(t, ic, 1, 7, RK4['b'], RK4['c'], RK4['a']), ref) < 1e-12, kind
 
 
+@pytest.mark.parametrize('n_traj', [1, 65, 200])
+def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
+    """MAOOAM 6x6 (ndim 228): the JIT LDS-resident stepper (kind 2) and the generic tiled kernel (kind 1) against the
+    oracle: forward with records, backward, a 2-stage and a 3-stage sub-diagonal tableau (the stepper takes the stage
+    count at run time), and the trajectory pass of the tangent model (stage states stored by the same stepper)."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden('t228'), models('t228')
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    rng = np.random.RandomState(100 + n_traj)
+    ic = rng.rand(n_traj, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 1.2, 0.1), [1.2]))
+    b3, c3 = np.array([1. / 6, 2. / 3, 1. / 6]), np.array([0., .5, 1.])
+    a3 = np.zeros((3, 3)); a3[1, 0] = .5; a3[2, 1] = 1.          # sub-diagonal 3-stage scheme
+    b2, c2 = np.array([0., 1.]), np.array([0., .5])
+    a2 = np.zeros((2, 2)); a2[1, 0] = .5
+    cases = [(1, 5, RK4['b'], RK4['c'], RK4['a']), (-1, 1, RK4['b'], RK4['c'], RK4['a']), (1, 0, b2, c2, a2), (1, 4, b3, c3, a3)]
+    refs = [ora.integrate_runge_kutta_jit(t, ic, d, ws, b, c, a, threads=4) for d, ws, b, c, a in cases]
+    tg = rng.randn(min(n_traj, 3), g.ndim, 2)
+    rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    for kind, kname in ((1, 'gen_rk_tiled_kernel'), (2, 'qgs_spec_rklds16')):
+        m.set_kernel(kind)
+        for (d, ws, b, c, a), ref in zip(cases, refs):
+            out = m.rk_integrate(t, ic, d, ws, b, c, a)
+            assert m.last_kernel_info()['name'] == kname
+            assert out.shape == ref.shape and rel_err(out, ref) < 1e-12, (kind, d, ws, len(b))
+        tr, fm = m.rk_tgls_integrate(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
+    m.set_kernel(0)
+
+
 def test_zero_steps_and_single_step(models):
     """n_time == 1 (no step): the only record is the initial condition (integrate.py:221)."""
     g, m = load_golden('a36'), models('a36')
