@@ -65,6 +65,51 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group)
         *ok = (t.vals[t.cursor] == v);        // always true: every stage emits the same sequence
         return t.cursor++;
     };
+    if (group == 8) {
+        // block-granular pipeline: the load of block b+3 is issued right after the first statement that uses block b
+        // (four 8-double blocks live = 64 SGPRs, as in the group-of-16 scheme, but 24 coefficients of run-ahead
+        // instead of 16)
+        const int D = 3;
+        size_t total = 0;
+        for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
+        const size_t nblocks = (total + 7) / 8;
+        const char *ind = "                ";
+        auto load_block = [&](size_t b) {
+            if (b >= nblocks) return std::string();
+            return std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
+        };
+        for (int b = 0; b < D; ++b) out += load_block((size_t)b);
+        long opened = -1;
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t eol = text.find('\n', pos);
+            if (eol == std::string::npos) eol = text.size();
+            std::string line = text.substr(pos, eol - pos), res;
+            long last_block = -1;
+            size_t lp = 0;
+            while (true) {
+                size_t a = line.find("@K", lp);
+                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
+                size_t b = line.find('@', a + 2);
+                res.append(line, lp, a - lp);
+                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
+                bool ok;
+                const size_t n = next_ref(v, &ok);
+                res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
+                last_block = (long)(n / 8);
+                lp = b + 1;
+            }
+            out += res + "\n";
+            if (last_block > opened) {
+                std::string l;
+                for (long b = opened + 1; b <= last_block; ++b) l += load_block((size_t)(b + D));
+                opened = last_block;
+                if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
+            }
+            pos = eol + 1;
+        }
+        return out;
+    }
     if (group != 16) {
         size_t pos = 0;
         while (true) {
@@ -907,6 +952,35 @@ std::vector<Phase> build_phases(int ndim, const std::vector<PTerm> &terms, int c
     return phases;
 }
 
+// fp64 instructions one wavefront spends per stage on the rows `own` (same rules as the emitter below)
+int64_t lds_wave_instr(int ndim, const std::vector<Row> &rows, const std::vector<int> &own, int cap, bool group)
+{
+    std::vector<PTerm> terms;
+    for (int i : own) {
+        for (const Lin &l : rows[i].lin) terms.push_back({i, 0, l.k, l.c});
+        for (const Bil &b : rows[i].bil) terms.push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+    }
+    int64_t n = 3 * (int64_t)own.size();
+    for (const Phase &ph : build_phases(ndim, terms, cap)) {
+        std::map<std::pair<int, double>, int> pieces;
+        std::map<std::pair<int, int>, int> singles;
+        for (const PTerm &t : ph.terms) {
+            if (t.j == 0) { ++n; continue; }
+            if (group) ++pieces[{t.row, std::fabs(t.c)}];
+            else { ++singles[{t.j, t.k}]; ++n; }
+        }
+        if (group) {
+            for (const PTerm &t : ph.terms) {
+                if (t.j == 0) continue;
+                if (pieces[{t.row, std::fabs(t.c)}] == 1) { ++singles[{t.j, t.k}]; ++n; }
+            }
+            for (auto &kv : pieces) if (kv.second > 1) n += kv.second + 1;
+        }
+        n += (int64_t)singles.size();
+    }
+    return n;
+}
+
 void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
@@ -931,17 +1005,36 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         }
         while (nl < light.size()) seq.push_back(light[nl++]);
     }
-    std::vector<std::vector<int>> owns(W);
+    std::vector<std::vector<int>> owns;
     {
-        int w = 0;
-        int64_t run = 0;
-        for (size_t q = 0; q < seq.size(); ++q) {
-            owns[w].push_back(seq[q]);
-            run += cost[seq[q]];
-            const size_t left = seq.size() - 1 - q;
-            if (w + 1 < W && (run * W >= total * (w + 1) || left <= (size_t)(W - 1 - w))) ++w;
+        // The estimate does not know how many products a wavefront can share between its rows, so the split is refined:
+        // count the instructions each block really needs, rescale the cost of its rows accordingly, split again.
+        std::vector<double> c(cost.begin(), cost.end());
+        double best_max = 0.0;
+        for (int iter = 0; iter < 6; ++iter) {
+            double tot = 0.0;
+            for (int i = 1; i <= ndim; ++i) tot += c[i];
+            std::vector<std::vector<int>> cand(W);
+            int w = 0;
+            double run = 0.0;
+            for (size_t q = 0; q < seq.size(); ++q) {
+                cand[w].push_back(seq[q]);
+                run += c[seq[q]];
+                const size_t left = seq.size() - 1 - q;
+                if (w + 1 < W && (run * W >= tot * (w + 1) || left <= (size_t)(W - 1 - w))) ++w;
+            }
+            double worst = 0.0;
+            std::vector<double> actual(W, 0.0), est(W, 0.0);
+            for (int v = 0; v < W; ++v) {
+                std::sort(cand[v].begin(), cand[v].end());
+                actual[v] = (double)lds_wave_instr(ndim, rows, cand[v], cap, opt.lds_group);
+                for (int i : cand[v]) est[v] += c[i];
+                worst = std::max(worst, actual[v]);
+            }
+            if (owns.empty() || worst < best_max) { owns = cand; best_max = worst; }
+            for (int v = 0; v < W; ++v)
+                if (est[v] > 0.0) for (int i : cand[v]) c[i] *= actual[v] / est[v];
         }
-        for (auto &v : owns) std::sort(v.begin(), v.end());
     }
     std::ostringstream o;
     std::vector<KTable> tables(W);

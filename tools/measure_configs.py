@@ -93,6 +93,6 @@ if 't228' in which:
         ic = torch.from_numpy(np.random.RandomState(3).rand(ndim, ld) * 0.01).to(dev)
         rec = torch.empty((1, ndim, ld), dtype=torch.float64, device=dev)
         el = timeit(lambda: m.rk_integrate_device(n, ld, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), n=2)
-        print(json.dumps({'case': 'config3 MAOOAM-228 generic kernel, %d members x 100 steps' % n, 'seconds': el,
+        print(json.dumps({'case': 'config3 MAOOAM-228 (%s), %d members x 100 steps' % (m.last_kernel_info()['name'], n), 'seconds': el,
                           'traj_steps_per_s': n * steps / el, 'fp64_flop_frac': n * steps / el * 336336 / 78.6e12,
                           'hbm_frac_algorithmic': n * steps / el * 3648 / 8e12, 'kernel': m.last_kernel_info()}), flush=True)
