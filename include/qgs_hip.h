@@ -96,6 +96,14 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg,
                           int adjoint, double inverse,
                           double *traj, double *fmatrix);
 
+/* Same run as qgs_rk_integrate, but only the ensemble mean and variance of every variable at every record come back:
+ * mean, var are (ndim, n_records) row-major (var may be null); final_states (n_traj, ndim) may be null.
+ * Replaces integrate() + get_trajectories() + np.mean / np.var over the member axis
+ * (qgs/integrators/statistics.py:33-66) without moving the ensemble trajectories to the host. */
+int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
+                             int time_direction, int64_t write_steps, int s, const double *b, const double *c,
+                             const double *a, double *mean, double *var, double *final_states);
+
 /* ---- device-layout entry points (pointers are device pointers on the model's device; the work
  *      is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT synchronised) ------ */
 
@@ -122,6 +130,13 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
                                  int s, const double *b, const double *c, const double *a,
                                  int adjoint, double inverse,
                                  double *d_rec, double *d_rec_fm, void *stream);
+
+/* Mean and population variance (may be null) over the members of every row of X[row][member] (n_rows rows of
+ * leading dimension ld, e.g. the n_records*ndim rows of a device record): the ensemble averages of
+ * TrajectoriesStatistics.compute_stats (qgs/integrators/statistics.py:55-63) for the observables x and x^2,
+ * computed where the trajectories are. */
+int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_rows, const double *d_x,
+                                double *d_mean, double *d_var, void *stream);
 
 /* Batched QR of one (n_rows x n_cols) matrix per member, device layout A[row][col][member]: A is replaced by Q
  * (LAPACK Householder sign convention), d_rdiag[col][member] receives diag(R).  Replaces the per-trajectory

@@ -42,6 +42,8 @@ SIGNATURES = {
     'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
                                             _f64p, _int, _dbl, _vp, _vp, _vp]),
     'qgs_batched_qr_device': (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
+    'qgs_ensemble_moments_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'qgs_rk_integrate_moments': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p, _vp, _vp]),
     'qgs_last_kernel_info': (_int, [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
                                     ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
@@ -205,6 +207,22 @@ class HipModel(object):
         _check(lib().qgs_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
                                       len(b), b, c, a, traj))
         return traj
+
+    def rk_integrate_moments(self, time, ic, time_direction, write_steps, b, c, a, variance=True, final_states=False):
+        """Same run as `rk_integrate`; returns the ensemble mean and variance (n_dim, n_records) of every variable at every
+        record (and optionally the final states) -- the trajectories never leave the device."""
+        time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
+        nrec = n_records(time, write_steps)
+        mean = np.empty((self.ndim, nrec))
+        var = np.empty((self.ndim, nrec)) if variance else None
+        fin = np.empty((ic.shape[0], self.ndim)) if final_states else None
+        _check(lib().qgs_rk_integrate_moments(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
+                                              len(b), b, c, a, mean, var.ctypes.data if variance else None,
+                                              fin.ctypes.data if final_states else None))
+        return mean, var, fin
+
+    def ensemble_moments_device(self, n_traj, ld, n_rows, d_x, d_mean, d_var=0, stream=0):
+        _check(lib().qgs_ensemble_moments_device(self._h, n_traj, ld, int(n_rows), d_x, d_mean, d_var or None, stream or None))
 
     def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse):
         time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)

@@ -93,6 +93,10 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
 // rdiag[col][member] receives diag(R).  Used by the Benettin Lyapunov
 // estimator (reference: np.linalg.qr in qgs/toolbox/lyapunov.py:540-547, 599-628).
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st);
+// mean / variance over the members of every row of X[row][member]; `part` holds 2 * n_rows * moments_splits() doubles
+int moments_splits(int64_t n_rows, int64_t n_traj);
+void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x, double *part, double *mean, double *var,
+                    hipStream_t st);
 
 // Layout conversion kernels (host layout <-> device layout), see include/qgs_hip.h
 void launch_pack_states(int ndim, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);

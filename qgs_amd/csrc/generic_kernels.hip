@@ -740,6 +740,79 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
     return hipErrorInvalidValue;
 }
 
+// ---- ensemble moments: mean and variance over the members of every row of X[row][member] ----------------------
+// (reference: np.mean(f(traj), axis=0) in TrajectoriesStatistics.compute_stats, statistics.py:55-63, for the
+// observables x and x^2 -- the trajectories stay on the device, only the moments travel.)
+// Pass 1: grid (n_rows, n_split), every workgroup sums (x - shift) and (x - shift)^2 over its slice of the members;
+// shift = x[row][0] keeps the second moment well conditioned.  Pass 2: one thread per row combines the partial sums.
+constexpr int MOM_THREADS = 256;
+
+__global__ void __launch_bounds__(MOM_THREADS) moments_partial_kernel(const double *__restrict__ x, int64_t ld, int64_t n_traj,
+                                                                      int n_split, double *__restrict__ part)
+{
+    __shared__ double sh1[MOM_THREADS / WAVE], sh2[MOM_THREADS / WAVE];
+    const int64_t row = blockIdx.x;
+    const int split = blockIdx.y;
+    const double *xr = x + row * ld;
+    const double shift = xr[0];
+    // slices in units of 2 members (16-byte loads; ld is a multiple of 64 so every row is 512-byte aligned)
+    const int64_t pairs = n_traj / 2, per = (pairs + n_split - 1) / n_split;
+    const int64_t p0 = (int64_t)split * per, p1 = p0 + per < pairs ? p0 + per : pairs;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t q = p0 + threadIdx.x; q < p1; q += MOM_THREADS) {
+        const double2 v = *(const double2 *)(xr + 2 * q);
+        const double a = v.x - shift, b = v.y - shift;
+        s1 += a + b;
+        s2 = __builtin_fma(a, a, __builtin_fma(b, b, s2));
+    }
+    if (split == n_split - 1 && (n_traj & 1) && threadIdx.x == 0) {
+        const double a = xr[n_traj - 1] - shift;
+        s1 += a;
+        s2 = __builtin_fma(a, a, s2);
+    }
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) { s1 += __shfl_down(s1, off, WAVE); s2 += __shfl_down(s2, off, WAVE); }
+    const int wv = threadIdx.x / WAVE;
+    if ((threadIdx.x & (WAVE - 1)) == 0) { sh1[wv] = s1; sh2[wv] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int w = 0; w < MOM_THREADS / WAVE; ++w) { t1 += sh1[w]; t2 += sh2[w]; }
+        part[(row * n_split + split) * 2] = t1;
+        part[(row * n_split + split) * 2 + 1] = t2;
+    }
+}
+
+__global__ void moments_final_kernel(const double *__restrict__ x, int64_t ld, int64_t n_traj, int64_t n_rows, int n_split,
+                                     const double *__restrict__ part, double *__restrict__ mean, double *__restrict__ var)
+{
+    const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    double t1 = 0.0, t2 = 0.0;
+    for (int q = 0; q < n_split; ++q) { t1 += part[(row * n_split + q) * 2]; t2 += part[(row * n_split + q) * 2 + 1]; }
+    const double inv = 1.0 / (double)n_traj, d = t1 * inv;
+    mean[row] = x[row * ld] + d;
+    if (var) var[row] = __builtin_fma(-d, d, t2 * inv);      // population variance (ddof = 0), as np.var
+}
+
+int moments_splits(int64_t n_rows, int64_t n_traj)
+{
+    // enough workgroups to fill the chip (~8 per CU), at least 2048 members per workgroup
+    int64_t want = (2048 + n_rows - 1) / n_rows, cap = (n_traj + 2047) / 2048;
+    int64_t s = want < cap ? want : cap;
+    return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
+}
+
+void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x, double *part, double *mean, double *var,
+                    hipStream_t st)
+{
+    const int n_split = moments_splits(n_rows, n_traj);
+    hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)n_rows, (unsigned)n_split), dim3(MOM_THREADS), 0, st, x, ld, n_traj,
+                       n_split, part);
+    hipLaunchKernelGGL(moments_final_kernel, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, st, x, ld, n_traj, n_rows, n_split,
+                       part, mean, var);
+}
+
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (size_t)n_rows * QR_STRIDE;

@@ -258,7 +258,7 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_mom_part, b_mom_out;
     KernelInfo last;
 };
 
@@ -614,7 +614,7 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_mom_part, &m->b_mom_out})
         b->release();
     delete m;
     return 0;
@@ -909,6 +909,19 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     return 0;
 }
 
+int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_rows, const double *d_x, double *d_mean,
+                                double *d_var, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_rows < 1 || !d_x || !d_mean) return fail("bad arguments");
+    if (n_rows > 0x7fffffff) return fail("too many rows");
+    HIPCHK(hipSetDevice(m->device));
+    if (m->b_mom_part.ensure(sizeof(double) * 2 * (size_t)n_rows * (size_t)qgs::moments_splits(n_rows, n_traj))) return -1;
+    qgs::launch_moments(n_rows, n_traj, ld, d_x, m->b_mom_part.f64(), d_mean, d_var, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // ---- host-layout entry points -------------------------------------------------------------------
 
 static int64_t round_ld(int64_t n) { return (n + 63) / 64 * 64; }
@@ -963,6 +976,42 @@ int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const doubl
                                 m->b_rec_modes.f64(), nullptr)) return -1;
     if (qgs_unpack_records(m, n_traj, ld, m->ndim, n_records, m->b_rec_modes.f64(), m->b_rec_rows.f64(), nullptr)) return -1;
     HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
+                             int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
+                             double *mean, double *var, double *final_states)
+{
+    if (!m || !ic || !mean || n_traj < 1) return fail("bad arguments");
+    if (!time || n_time < 1) return fail("bad time grid");
+    HIPCHK(hipSetDevice(m->device));
+    const int64_t ld = round_ld(n_traj);
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const int64_t n_rows = n_records * m->ndim;
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
+        m->b_mom_out.ensure(sizeof(double) * 2 * (size_t)n_rows)) return -1;
+    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
+    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
+    if (qgs_rk_integrate_device(m, n_traj, ld, m->b_in_modes.f64(), time, n_time, time_direction, write_steps, s, b, c, a,
+                                m->b_rec_modes.f64(), nullptr)) return -1;
+    double *d_mean = m->b_mom_out.f64(), *d_var = d_mean + n_rows;
+    if (qgs_ensemble_moments_device(m, n_traj, ld, n_rows, m->b_rec_modes.f64(), d_mean, var ? d_var : nullptr, nullptr)) return -1;
+    // device rows are (record, mode); the reference's axis order is (mode, record)
+    std::vector<double> h((size_t)n_rows * 2);
+    HIPCHK(hipMemcpy(h.data(), d_mean, sizeof(double) * (size_t)n_rows * (var ? 2 : 1), hipMemcpyDeviceToHost));
+    for (int64_t r = 0; r < n_records; ++r)
+        for (int d = 0; d < m->ndim; ++d) {
+            mean[(int64_t)d * n_records + r] = h[(size_t)(r * m->ndim + d)];
+            if (var) var[(int64_t)d * n_records + r] = h[(size_t)(n_rows + r * m->ndim + d)];
+        }
+    if (final_states) {
+        // last record of the directed run = index n_records-1 (forward) or 0 (backward) in the stored order
+        const int64_t last = (time_direction == -1) ? 0 : n_records - 1;
+        if (qgs_unpack_states(m, n_traj, ld, m->b_rec_modes.f64() + (size_t)last * m->ndim * ld, m->b_in_rows.f64(), nullptr)) return -1;
+        HIPCHK(hipMemcpy(final_states, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 

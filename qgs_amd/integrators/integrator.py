@@ -170,6 +170,23 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
         self._recorded_traj = self._model.rk_integrate(self._time, self.ic, self._time_direction, write_steps,
                                                        self.b, self.c, self.a)
 
+    def integrate_moments(self, t0, t, dt, ic=None, forward=True, write_steps=1, variance=True):
+        """Integrate like `integrate`, but bring back only the ensemble mean and variance over the members:
+        returns ``(time, mean, var)`` with mean / var of shape (n_dim, n_records) (``var`` is None when
+        ``variance=False``); equal to ``np.mean(traj, axis=0)`` / ``np.var(traj, axis=0)`` of the (n_traj, n_dim,
+        n_records) array that `integrate` + `get_trajectories` would return, which here stays on the device.
+        (Device-side form of the member averages of qgs/integrators/statistics.py:55-63.)"""
+        if self.func is None:
+            print('No function to integrate defined!')
+            return 0
+        if self._model is None:
+            self.start()
+        self._prepare(t0, t, dt, ic, forward, write_steps)
+        mean, var, fin = self._model.rk_integrate_moments(self._time, self.ic, self._time_direction, write_steps,
+                                                          self.b, self.c, self.a, variance=variance, final_states=True)
+        self.last_final_states = fin                           # (n_traj, n_dim): e.g. the next window's initial conditions
+        return self._record_times(), mean, var
+
     def get_trajectories(self):
         """``(time, traj)``: traj is ``np.squeeze`` of (n_traj, n_dim, n_records); time is a scalar when the last
         integration used ``write_steps=0`` (integrator.py:397-424)."""

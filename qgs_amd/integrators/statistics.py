@@ -54,3 +54,25 @@ class TrajectoriesStatistics(object):
             for j, f in enumerate(self.func_list):
                 realizations[j, i] = np.mean(f(traj), axis=0)
         self.mean_func = np.mean(realizations, axis=1)
+
+    def compute_moments(self, t0, t, dt, ic=None, forward=True, write_steps=1, num=1):
+        """Ensemble mean and variance of the state at every record, reduced on the device: the same numbers as
+        `compute_stats` with ``func_list = [lambda x: x, lambda x: x**2]`` (variance = second moment - mean**2), without
+        moving the (n_traj, n_dim, n_records) trajectories to the host.  `num` batches as in `compute_stats`; the batch
+        moments are combined with their member counts.  Returns ``(time, mean, var)``, both (n_dim, n_records)."""
+        if ic is not None:
+            self.set_ic(ic)
+        n = self.ic.shape[0]
+        sub = n // num
+        bounds = [(i * sub, (i + 1) * sub if i < num - 1 else n) for i in range(num)]
+        m1 = m2 = None
+        times = None
+        for lo, hi in bounds:
+            if hi <= lo:
+                continue
+            times, mean, var = self.integrator.integrate_moments(t0, t, dt, ic=self.ic[lo:hi], forward=forward,
+                                                                 write_steps=write_steps)
+            w = (hi - lo) / n
+            m1 = w * mean if m1 is None else m1 + w * mean
+            m2 = w * (var + mean ** 2) if m2 is None else m2 + w * (var + mean ** 2)
+        return times, m1, m2 - m1 ** 2

@@ -186,3 +186,32 @@ def test_user_defined_quadratic_system_lorenz63():
     assert traj.shape == ref.shape and rel_err(traj, ref) < 1e-11        # chaotic system, 100 steps
     integ.terminate()
     f.operands.release()
+
+
+@pytest.mark.parametrize('n_traj,write_steps,forward', [(1, 1, True), (63, 3, True), (1000, 2, False), (5000, 0, True)])
+def test_ensemble_moments_match_numpy(n_traj, write_steps, forward):
+    """integrate_moments (device reduction) == np.mean / np.var over the member axis of the full trajectories."""
+    import model_configs
+    from qgs_amd.functions.tendencies import create_tendencies
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+    from qgs_amd.integrators.statistics import TrajectoriesStatistics
+    f, Df = create_tendencies(model_configs.params_m36())
+    integ = RungeKuttaIntegrator()
+    integ.set_func(f)
+    ic = np.random.RandomState(n_traj).rand(n_traj, f.ndim) * 0.01 + 0.02
+    integ.integrate(0., 2., 0.1, ic=ic, forward=forward, write_steps=write_steps)
+    tt, traj = integ.get_trajectories()
+    traj = np.reshape(traj, (n_traj, f.ndim, -1))
+    t2, mean, var = integ.integrate_moments(0., 2., 0.1, ic=ic, forward=forward, write_steps=write_steps)
+    assert np.array_equal(np.atleast_1d(t2), np.atleast_1d(tt))
+    assert mean.shape == traj.shape[1:] and rel_err(mean, traj.mean(axis=0)) < 1e-13
+    assert np.abs(var - traj.var(axis=0)).max() <= 1e-10 * traj.var(axis=0).max() + 1e-26
+    assert rel_err(integ.last_final_states, traj[:, :, 0 if not forward else -1]) < 1e-15
+    if n_traj >= 63:
+        stats = TrajectoriesStatistics()
+        stats.set_integrator(integ)
+        t3, m3, v3 = stats.compute_moments(0., 2., 0.1, ic=ic, forward=forward, write_steps=write_steps, num=3)
+        assert rel_err(m3, traj.mean(axis=0)) < 1e-13
+        assert np.abs(v3 - traj.var(axis=0)).max() <= 1e-10 * traj.var(axis=0).max() + 1e-26
+    integ.terminate()
+    f.operands.release()

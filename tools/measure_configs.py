@@ -18,7 +18,7 @@ import model_configs  # noqa: E402
 
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 dev = torch.device('cuda', 0)
-which = sys.argv[1:] or ['host', 'record', 'tgls', 't228']
+which = sys.argv[1:] or ['host', 'record', 'tgls', 't228', 'moments']
 
 
 def grid(steps, dt=0.1):
@@ -96,3 +96,18 @@ if 't228' in which:
         print(json.dumps({'case': 'config3 MAOOAM-228 (%s), %d members x 100 steps' % (m.last_kernel_info()['name'], n), 'seconds': el,
                           'traj_steps_per_s': n * steps / el, 'fp64_flop_frac': n * steps / el * 336336 / 78.6e12,
                           'hbm_frac_algorithmic': n * steps / el * 3648 / 8e12, 'kernel': m.last_kernel_info()}), flush=True)
+
+if 'moments' in which:
+    # ensemble mean + variance of a device-resident record: 65 536 members x 36 modes x 101 records (1.9 GB)
+    p = model_configs.params_m36()
+    f, Df = create_tendencies(p)
+    m = f.hip_model()
+    n, ndim, nrec = 65536, p.ndim, 101
+    rec = torch.rand((nrec * ndim, n), dtype=torch.float64, device=dev)
+    mean = torch.empty(nrec * ndim, dtype=torch.float64, device=dev)
+    var = torch.empty(nrec * ndim, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    el = timeit(lambda: m.ensemble_moments_device(n, n, nrec * ndim, rec.data_ptr(), mean.data_ptr(), var.data_ptr(), st), n=5)
+    ok = float((mean - rec.mean(dim=1)).abs().max()), float((var - rec.var(dim=1, unbiased=False)).abs().max())
+    print(json.dumps({'case': 'ensemble moments of a 65536 x 36 x 101 device record', 'seconds': el, 'GBs': rec.numel() * 8 / el / 1e9,
+                      'hbm_frac': rec.numel() * 8 / el / 8e12, 'max_abs_err_mean_var_vs_torch': ok}), flush=True)
