@@ -215,3 +215,22 @@ def test_ensemble_moments_match_numpy(n_traj, write_steps, forward):
         assert np.abs(v3 - traj.var(axis=0)).max() <= 1e-10 * traj.var(axis=0).max() + 1e-26
     integ.terminate()
     f.operands.release()
+
+
+def test_sparse_mul_entry_points_match_oracle():
+    """qgs.functions.sparse_mul.sparse_mul3 / sparse_mul2 as called from hand-written tendencies
+    (user_guide.rst:437-458): same signatures, evaluated on the device."""
+    from qgs_amd.functions.sparse_mul import sparse_mul2, sparse_mul3
+    from oracle import oracle
+    g = load_golden('a36')
+    x = g['fx_x'][5]
+    xx = np.concatenate(([1.], x))
+    r3 = sparse_mul3(g['coo'], g['val'], xx, xx)
+    assert r3.shape == (g.ndim + 1,) and r3[0] == 1. and rel_err(r3[1:], g['fx_f'][5]) < 1e-14
+    assert rel_err(r3, oracle.sparse_mul3(g['coo'], g['val'], xx, xx)) < 1e-14
+    r2 = sparse_mul2(g['jcoo'], g['jval'], xx)
+    ref2 = oracle.sparse_mul2(g['jcoo'], g['jval'], xx)
+    assert r2.shape == ref2.shape and np.abs(r2 - ref2).max() < 1e-14 * np.abs(ref2).max()
+    assert np.abs(ref2[1:, 0]).max() > 0                      # column 0 (linear part) is exercised
+    with pytest.raises(NotImplementedError):
+        sparse_mul3(g['coo'], g['val'], xx, 2. * xx)
