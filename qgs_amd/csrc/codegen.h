@@ -31,9 +31,9 @@ struct CodegenOptions {
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
-    int lds_cap = 24;          // ... and modes cached in registers per phase
-    bool lds_group = false;    // ... sum equal-|coefficient| terms of a row inside a phase first (fewer instructions and
-                               //     coefficient fetches, but measured 10 % slower at 16 waves: longer dependent chains, more spills)
+    int lds_cap = 20;          // ... and modes cached in registers per phase (24 spills at 128 VGPRs: 63.6 ms vs 55.6 ms)
+    bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
+                               //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
 };
