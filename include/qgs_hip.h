@@ -60,9 +60,10 @@ int64_t qgs_model_info(const qgs_model *m, int which);
  * 1 = force generic (tensor streamed from memory, any ndim), 2 = force specialised.
  * Specialised = code generated from the tensor and compiled at run time (cached on disk): register-resident
  * kernels up to 64 variables; beyond that (stage state <= 152 KB of LDS, i.e. ndim <= 304) the LDS-resident
- * stepper serves the trajectory integrations, f / Df / the tangent pass stay generic.  In automatic mode
- * the LDS-resident stepper is used when its code object is already cached or the run is long enough to pay for
- * the ~20 s compilation. */
+ * stepper serves the trajectory integrations and (ndim <= 243) LDS-resident tangent / adjoint kernels the tangent
+ * pass; f / Df stay generic.  In automatic mode
+ * these are used when their code objects are already cached or the run is long enough to pay for the 20-40 s
+ * compilation. */
 int qgs_model_set_kernel(qgs_model *m, int kind);
 
 /* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) -------------- */

@@ -952,16 +952,23 @@ std::vector<Phase> build_phases(int ndim, const std::vector<PTerm> &terms, int c
     return phases;
 }
 
-// fp64 instructions one wavefront spends per stage on the rows `own` (same rules as the emitter below)
-int64_t lds_wave_instr(int ndim, const std::vector<Row> &rows, const std::vector<int> &own, int cap, bool group)
+// ---- shared machinery of the LDS-resident kernels (stepper and tangent model) --------------------------------------
+// Terms live in "node space": a node is one LDS-resident value (stepper: node m = mode m; tangent model: node j = w_j,
+// node ndim + k = x_k); a term is c * node_j * node_k accumulated into row `row`, j == 0 meaning a single factor.
+typedef std::vector<std::vector<PTerm>> RowTerms;           // [row] -> its terms
+
+struct LdsStats { int64_t loads = 0, instr = 0, phases = 0, coef = 0; };
+
+struct LdsNode { int64_t offset; int lane_kind; };          // byte offset in LDS without the lane part; which lane-offset variable
+using NodeFn = std::function<LdsNode(int)>;
+
+// fp64 instructions one wavefront spends per stage on the rows `own` (same rules as emit_lds_phases)
+int64_t lds_wave_instr(int n_nodes, const RowTerms &rt, const std::vector<int> &own, int cap, bool group)
 {
     std::vector<PTerm> terms;
-    for (int i : own) {
-        for (const Lin &l : rows[i].lin) terms.push_back({i, 0, l.k, l.c});
-        for (const Bil &b : rows[i].bil) terms.push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
-    }
+    for (int i : own) terms.insert(terms.end(), rt[i].begin(), rt[i].end());
     int64_t n = 3 * (int64_t)own.size();
-    for (const Phase &ph : build_phases(ndim, terms, cap)) {
+    for (const Phase &ph : build_phases(n_nodes, terms, cap)) {
         std::map<std::pair<int, double>, int> pieces;
         std::map<std::pair<int, int>, int> singles;
         for (const PTerm &t : ph.terms) {
@@ -981,20 +988,24 @@ int64_t lds_wave_instr(int ndim, const std::vector<Row> &rows, const std::vector
     return n;
 }
 
-void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+// Row blocks: neighbouring rows share most of their factors, so blocks are contiguous in a row sequence and balanced by
+// cost; cheap rows (MAOOAM: the ocean rows) are first spread evenly through that sequence, otherwise one wavefront would
+// own all of them and need twice the registers for its row state.  The estimate does not know how many products a
+// wavefront can share between its rows, so the split is refined: count the instructions each block really needs,
+// rescale the cost of its rows accordingly, split again.
+std::vector<std::vector<int>> lds_partition(int n_rows, int n_nodes, const RowTerms &rt, int W, int cap, bool group)
 {
-    const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
-    const std::string kname = "qgs_spec_rklds" + std::to_string(W);
-    // Row blocks: neighbouring rows share most of their factors, so blocks are contiguous in a row sequence and
-    // balanced by cost; cheap rows (MAOOAM: the ocean rows) are first spread evenly through that sequence, otherwise
-    // one wavefront would own all of them and need twice the registers for its row state.
-    std::vector<int64_t> cost(ndim + 1, 0);
+    std::vector<int64_t> cost(n_rows + 1, 0);
     int64_t total = 0;
-    for (int i = 1; i <= ndim; ++i) { cost[i] = 1 + (int64_t)rows[i].lin.size() + 2 * (int64_t)rows[i].bil.size(); total += cost[i]; }
+    for (int i = 1; i <= n_rows; ++i) {
+        cost[i] = 1;
+        for (const PTerm &t : rt[i]) cost[i] += (t.j == 0) ? 1 : 2;
+        total += cost[i];
+    }
     std::vector<int> seq;
     {
         std::vector<int> heavy, light;
-        for (int i = 1; i <= ndim; ++i) ((cost[i] * 2 * ndim < total) ? light : heavy).push_back(i);
+        for (int i = 1; i <= n_rows; ++i) ((cost[i] * 2 * n_rows < total) ? light : heavy).push_back(i);
         int64_t heavy_total = 0, run = 0;
         for (int i : heavy) heavy_total += cost[i];
         size_t nl = 0;
@@ -1006,36 +1017,128 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         while (nl < light.size()) seq.push_back(light[nl++]);
     }
     std::vector<std::vector<int>> owns;
-    {
-        // The estimate does not know how many products a wavefront can share between its rows, so the split is refined:
-        // count the instructions each block really needs, rescale the cost of its rows accordingly, split again.
-        std::vector<double> c(cost.begin(), cost.end());
-        double best_max = 0.0;
-        for (int iter = 0; iter < 6; ++iter) {
-            double tot = 0.0;
-            for (int i = 1; i <= ndim; ++i) tot += c[i];
-            std::vector<std::vector<int>> cand(W);
-            int w = 0;
-            double run = 0.0;
-            for (size_t q = 0; q < seq.size(); ++q) {
-                cand[w].push_back(seq[q]);
-                run += c[seq[q]];
-                const size_t left = seq.size() - 1 - q;
-                if (w + 1 < W && (run * W >= tot * (w + 1) || left <= (size_t)(W - 1 - w))) ++w;
+    std::vector<double> c(cost.begin(), cost.end());
+    double best_max = 0.0;
+    for (int iter = 0; iter < 6; ++iter) {
+        double tot = 0.0;
+        for (int i = 1; i <= n_rows; ++i) tot += c[i];
+        std::vector<std::vector<int>> cand(W);
+        int w = 0;
+        double run = 0.0;
+        for (size_t q = 0; q < seq.size(); ++q) {
+            cand[w].push_back(seq[q]);
+            run += c[seq[q]];
+            const size_t left = seq.size() - 1 - q;
+            if (w + 1 < W && (run * W >= tot * (w + 1) || left <= (size_t)(W - 1 - w))) ++w;
+        }
+        double worst = 0.0;
+        std::vector<double> actual(W, 0.0), est(W, 0.0);
+        for (int v = 0; v < W; ++v) {
+            std::sort(cand[v].begin(), cand[v].end());
+            actual[v] = (double)lds_wave_instr(n_nodes, rt, cand[v], cap, group);
+            for (int i : cand[v]) est[v] += c[i];
+            worst = std::max(worst, actual[v]);
+        }
+        if (owns.empty() || worst < best_max) { owns = cand; best_max = worst; }
+        for (int v = 0; v < W; ++v)
+            if (est[v] > 0.0) for (int i : cand[v]) c[i] *= actual[v] / est[v];
+    }
+    return owns;
+}
+
+// The phases of one wavefront as straight-line code accumulating into k<row>.  `hook` is emitted in front of phase
+// `hook_phase` (== phases.size(): behind the last one).
+void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<Phase> &phases, const NodeFn &node,
+                     const std::vector<std::string> &lane_vars, const std::string &lds_ptr, bool group, int hook_phase,
+                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st)
+{
+    int ph_id = 0, prod_id = 0;
+    for (const Phase &ph : phases) {
+        if (ph_id == hook_phase) hook(so);
+        const std::string sfx = "_" + std::to_string(ph_id++);
+        // Opaque lane offset per phase: otherwise the compiler merges the reads of one value in different phases and keeps
+        // it in a register (or scratch) in between.  ds_read offsets are 16-bit immediates, so every 64 KB window of the
+        // LDS (and every lane-offset kind) gets its own base register.
+        std::map<std::pair<int, int>, std::string> bases;
+        for (int mo : ph.modes) {
+            const LdsNode nd = node(mo);
+            const std::pair<int, int> key{nd.lane_kind, (int)(nd.offset >> 16)};
+            if (bases.count(key)) continue;
+            const std::string name = "lb" + std::to_string(key.first) + "w" + std::to_string(key.second) + sfx;
+            so << ind << "unsigned " << name << " = " << lane_vars[key.first];
+            if (key.second) so << " + " << (int64_t)key.second * 65536 << "u";
+            so << "; asm volatile(\"\" : \"+v\"(" << name << "));\n";
+            bases[key] = name;
+        }
+        for (int mo : ph.modes) {
+            const LdsNode nd = node(mo);
+            so << ind << "const f64 x" << mo << sfx << " = *(const f64*)(" << lds_ptr << " + " << (nd.offset & 65535) << " + "
+               << bases[{nd.lane_kind, (int)(nd.offset >> 16)}] << ");\n";
+        }
+        st.loads += (int64_t)ph.modes.size();
+        ++st.phases;
+        // Terms of one row with equal |coefficient| that fall into this phase are summed first
+        // (c * (x_a x_b - x_c x_d ...): one fused multiply-add per term plus one for the coefficient); the
+        // remaining single terms share their product between the rows of the wave that need it.
+        std::map<std::pair<int, double>, std::vector<PTerm>> pieces;
+        std::vector<PTerm> singles;
+        for (const PTerm &t : ph.terms) {
+            if (t.j == 0 || !group) singles.push_back(t);
+            else pieces[{t.row, std::fabs(t.c)}].push_back(t);
+        }
+        for (auto &kv : pieces) {
+            const std::vector<PTerm> &g = kv.second;
+            if (g.size() == 1) { singles.push_back(g[0]); continue; }
+            const std::string gname = "g" + std::to_string(prod_id++);
+            const bool ref_neg = std::signbit(g[0].c);
+            std::vector<Prod> ps;
+            for (const PTerm &t : g)
+                ps.push_back({std::signbit(t.c) != ref_neg, "x" + std::to_string(t.j) + sfx, "x" + std::to_string(t.k) + sfx});
+            emit_group(so, ind, gname, ps);
+            so << ind << "k" << g[0].row << " = __builtin_fma(" << lit(g[0].c) << ", " << gname << ", k" << g[0].row << ");\n";
+            st.instr += (int64_t)g.size() + 1;
+            ++st.coef;
+        }
+        std::sort(singles.begin(), singles.end(), [](const PTerm &x, const PTerm &y) {
+            return x.j != y.j ? x.j < y.j : (x.k != y.k ? x.k < y.k : x.row < y.row);
+        });
+        size_t a = 0;
+        while (a < singles.size()) {
+            size_t b = a;
+            while (b < singles.size() && singles[b].j == singles[a].j && singles[b].k == singles[a].k) ++b;
+            const PTerm &t0 = singles[a];
+            std::string factor;
+            if (t0.j == 0) factor = "x" + std::to_string(t0.k) + sfx;
+            else {
+                const std::string pr = "x" + std::to_string(t0.j) + sfx + " * x" + std::to_string(t0.k) + sfx;
+                if (b - a > 1) {
+                    factor = "p" + std::to_string(prod_id++);
+                    so << ind << "const f64 " << factor << " = " << pr << ";\n";
+                } else factor = "(" + pr + ")";
+                ++st.instr;
             }
-            double worst = 0.0;
-            std::vector<double> actual(W, 0.0), est(W, 0.0);
-            for (int v = 0; v < W; ++v) {
-                std::sort(cand[v].begin(), cand[v].end());
-                actual[v] = (double)lds_wave_instr(ndim, rows, cand[v], cap, opt.lds_group);
-                for (int i : cand[v]) est[v] += c[i];
-                worst = std::max(worst, actual[v]);
+            for (size_t q = a; q < b; ++q) {
+                so << ind << "k" << singles[q].row << " = __builtin_fma(" << lit(singles[q].c) << ", " << factor << ", k" << singles[q].row << ");\n";
+                ++st.instr;
+                ++st.coef;
             }
-            if (owns.empty() || worst < best_max) { owns = cand; best_max = worst; }
-            for (int v = 0; v < W; ++v)
-                if (est[v] > 0.0) for (int i : cand[v]) c[i] *= actual[v] / est[v];
+            a = b;
         }
     }
+    if (hook_phase >= (int)phases.size()) hook(so);
+}
+
+void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+{
+    const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
+    const std::string kname = "qgs_spec_rklds" + std::to_string(W);
+    RowTerms rt(ndim + 1);
+    for (int i = 1; i <= ndim; ++i) {
+        for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
+        for (const Bil &b : rows[i].bil) rt[i].push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+    }
+    const std::vector<std::vector<int>> owns = lds_partition(ndim, ndim, rt, W, cap, opt.lds_group);
+    const NodeFn node = [](int m) { return LdsNode{(int64_t)(m - 1) * 512, 0}; };
     std::ostringstream o;
     std::vector<KTable> tables(W);
     o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members,\n"
@@ -1056,7 +1159,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);\n"
       << "    f64* const yw = ywork + (i64)blockIdx.x * " << ndim * 64 << " + lane;   // row d of this member at yw[(d-1)*64]\n";
-    int64_t n_loads = 0, n_instr = 0, n_phases = 0, n_coef = 0;
+    LdsStats stats;
     for (int w = 0; w < W; ++w) {
         const std::vector<int> &own = owns[w];
         o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
@@ -1103,80 +1206,15 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
             const Row &r = rows[i];
             if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << lit(r.c0) << ";\n";
             else so << I4 << "f64 k" << i << " = 0.0;\n";
-            for (const Lin &l : r.lin) terms.push_back({i, 0, l.k, l.c});
-            for (const Bil &b : r.bil) terms.push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+            terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
         const std::vector<Phase> phases = build_phases(ndim, terms, cap);
-        int ph_id = 0, prod_id = 0;
-        const int y_load_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));   // == size(): after the last phase
-        for (const Phase &ph : phases) {
-            if (ph_id == y_load_phase)                 // step-start state of the own rows, consumed at the end of the stage
-                for (int d : own) so << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
-            const std::string sfx = "_" + std::to_string(ph_id++);
-            // opaque lane offset per phase: otherwise the compiler merges the reads of one mode in different phases
-            // and keeps the value in a register (or scratch) in between
-            // (ds_read offsets are 16-bit immediates: modes beyond 64 KB go through a second base register)
-            so << I4 << "unsigned lo" << sfx << " = lane8; asm volatile(\"\" : \"+v\"(lo" << sfx << "));\n";
-            bool high = false;
-            for (int mo : ph.modes) high = high || (mo - 1) * 512 >= 65536;
-            if (high) so << I4 << "unsigned lh" << sfx << " = lane8 + 65536u; asm volatile(\"\" : \"+v\"(lh" << sfx << "));\n";
-            for (int mo : ph.modes) {
-                const int off = (mo - 1) * 512;
-                if (off < 65536) so << I4 << "const f64 x" << mo << sfx << " = *(const f64*)((const char*)xs + " << off << " + lo" << sfx << ");\n";
-                else so << I4 << "const f64 x" << mo << sfx << " = *(const f64*)((const char*)xs + " << off - 65536 << " + lh" << sfx << ");\n";
-            }
-            n_loads += (int64_t)ph.modes.size();
-            ++n_phases;
-            // Bilinear terms of one row with equal |coefficient| that fall into this phase are summed first
-            // (c * (x_a x_b - x_c x_d ...): one fused multiply-add per term plus one for the coefficient); the
-            // remaining single terms share their product x_j x_k between the rows of the wave that need it.
-            std::map<std::pair<int, double>, std::vector<PTerm>> pieces;
-            std::vector<PTerm> singles;
-            for (const PTerm &t : ph.terms) {
-                if (t.j == 0 || !opt.lds_group) singles.push_back(t);
-                else pieces[{t.row, std::fabs(t.c)}].push_back(t);
-            }
-            for (auto &kv : pieces) {
-                const std::vector<PTerm> &g = kv.second;
-                if (g.size() == 1) { singles.push_back(g[0]); continue; }
-                const std::string gname = "g" + std::to_string(prod_id++);
-                const bool ref_neg = std::signbit(g[0].c);
-                std::vector<Prod> ps;
-                for (const PTerm &t : g)
-                    ps.push_back({std::signbit(t.c) != ref_neg, "x" + std::to_string(t.j) + sfx, "x" + std::to_string(t.k) + sfx});
-                emit_group(so, I4, gname, ps);
-                so << I4 << "k" << g[0].row << " = __builtin_fma(" << lit(g[0].c) << ", " << gname << ", k" << g[0].row << ");\n";
-                n_instr += (int64_t)g.size() + 1;
-                ++n_coef;
-            }
-            std::sort(singles.begin(), singles.end(), [](const PTerm &x, const PTerm &y) {
-                return x.j != y.j ? x.j < y.j : (x.k != y.k ? x.k < y.k : x.row < y.row);
-            });
-            size_t a = 0;
-            while (a < singles.size()) {
-                size_t b = a;
-                while (b < singles.size() && singles[b].j == singles[a].j && singles[b].k == singles[a].k) ++b;
-                const PTerm &t0 = singles[a];
-                std::string factor;
-                if (t0.j == 0) factor = "x" + std::to_string(t0.k) + sfx;
-                else {
-                    const std::string pr = "x" + std::to_string(t0.j) + sfx + " * x" + std::to_string(t0.k) + sfx;
-                    if (b - a > 1) {
-                        factor = "p" + std::to_string(prod_id++);
-                        so << I4 << "const f64 " << factor << " = " << pr << ";\n";
-                    } else factor = "(" + pr + ")";
-                    ++n_instr;
-                }
-                for (size_t q = a; q < b; ++q) {
-                    so << I4 << "k" << singles[q].row << " = __builtin_fma(" << lit(singles[q].c) << ", " << factor << ", k" << singles[q].row << ");\n";
-                    ++n_instr;
-                    ++n_coef;
-                }
-                a = b;
-            }
-        }
-        if (y_load_phase == (int)phases.size())
-            for (int d : own) so << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
+        // step-start state of the own rows, consumed at the end of the stage
+        const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
+        emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
+                        [&](std::ostringstream &h) {
+                            for (int d : own) h << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
+                        }, stats);
         o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;
@@ -1199,7 +1237,137 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         o << I3 << "}\n" << I2 << "}\n    }\n";
     }
     o << "}\n";
-    out << "// per stage and 64 members: " << n_phases << " phases, " << n_loads << " LDS reads, " << n_instr << " fp64 instructions, " << n_coef << " coefficient fetches\n";
+    out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
+        << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
+    if (opt.lds_coeff_table)
+        for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    out << o.str();
+}
+
+// LDS-resident tangent / adjoint model for large systems (same idea as the stepper above).  A workgroup of W wavefronts
+// propagates 64 (member, column) pairs arranged as 16 members x 4 columns, so that the stage state of the 16 members
+// (xs[mode][16], 28.5 KB at ndim 228) AND the tangent stage vector of the 64 pairs (ws[mode][64], 114 KB) fit the 160 KB
+// LDS together (64 members x 1 column would need 2 x 114 KB).  Each wavefront owns a block of output rows of J w (or
+// J^T w); its terms c * x_k * w_j are ordered into phases that cache <= cap LDS values in registers.
+//   tangent  (J w)_i   = sum_{j,k} Tj_ijk x_k w_j        adjoint  (J^T w)_j = sum_{i,k} Tj_ijk x_k w_i
+void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &wx, bool adjoint,
+                         const CodegenOptions &opt)
+{
+    const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
+    const std::string kname = std::string(adjoint ? "qgs_spec_adjlds" : "qgs_spec_tgllds") + std::to_string(W);
+    const int64_t xs_bytes = (int64_t)ndim * 16 * 8;
+    RowTerms rt(ndim + 1);
+    for (int i = 1; i <= ndim; ++i)
+        for (const WX &t : wx[i]) {
+            if (t.x == 0) rt[i].push_back({i, 0, t.w, t.c});                 // x_0 = 1: c * w_j
+            else rt[i].push_back({i, t.w, ndim + t.x, t.c});                 // node w_j < node x_k
+        }
+    const std::vector<std::vector<int>> owns = lds_partition(ndim, 2 * ndim, rt, W, cap, opt.lds_group);
+    const NodeFn node = [ndim, xs_bytes](int n) {
+        return n <= ndim ? LdsNode{xs_bytes + (int64_t)(n - 1) * 512, 0} : LdsNode{(int64_t)(n - ndim - 1) * 128, 1};
+    };
+    std::ostringstream o;
+    std::vector<KTable> tables(W);
+    o << "\n// " << (adjoint ? "adjoint" : "tangent") << " model, run-time stage count, 16 members x 4 columns per workgroup of " << W
+      << " wavefronts,\n// stage state and tangent stage vector in LDS, factors cached in registers per phase (cap " << cap << ")\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
+      << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
+      << "    f64* __restrict__ w_out_p,       // after step `step_end-1` (may be null)\n"
+      << "    f64* __restrict__ vwork,         // private [workgroup][mode][64]: tangent state at the start of the current step\n"
+      << "    f64* __restrict__ rec,           // F[record][mode][col][member]\n"
+      << "    const f64* __restrict__ stages,  // S[(step-step_begin)*S+stage][mode][member]\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
+      << "    int backward, int write_final, f64 inverse, int S)\n{\n";
+    o << "    __shared__ f64 lds_all[" << ndim * 16 + ndim * 64 << "];\n"
+      << "    f64 (*xs)[16] = (f64 (*)[16])lds_all;                       // stage state of the 16 members\n"
+      << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << ndim * 16 << ");   // tangent stage vector of the 64 pairs\n";
+    o << "    const int lane = threadIdx.x & 63;\n"
+      << "    const unsigned lane8 = (unsigned)lane * 8u, xl8 = (unsigned)(lane & 15) * 8u;\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+      << "    const i64 L = n_tg * ld;\n"
+      << "    const i64 mt = (i64)blockIdx.x * 16, m0 = mt + (lane & 15), c0 = (i64)blockIdx.y * 4 + (lane >> 4);\n"
+      << "    const bool live = (m0 < n_traj) && (c0 < n_tg);\n"
+      << "    const i64 m = m0 < n_traj ? m0 : (n_traj - 1), col = c0 < n_tg ? c0 : (n_tg - 1);\n"
+      << "    const i64 l = col * ld + m;                                  // this pair's lane of F[mode][col][member]\n"
+      << "    f64* const vw = vwork + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * " << ndim * 64 << " + lane;\n"
+      << "    // stage-state tile of the 16 members, loaded by the whole workgroup: element e -> (mode e / 16, member e % 16)\n"
+      << "    i64 xm = mt + (threadIdx.x & 15); if (xm >= n_traj) xm = n_traj - 1;\n"
+      << "#define QGS_LOAD_XS(sp) do { const f64* sp_ = (sp); \\\n"
+      << "        for (int e = threadIdx.x; e < " << ndim * 16 << "; e += " << 64 * W << ") xs[e >> 4][e & 15] = sp_[(i64)(e >> 4) * ld + xm]; } while (0)\n";
+    LdsStats stats;
+    for (int w = 0; w < W; ++w) {
+        const std::vector<int> &own = owns[w];
+        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
+        for (int i : own) o << " " << i;
+        o << "\n";
+        const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
+        for (int d : own) o << I2 << "f64 acc" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
+        for (int d : own) o << I2 << "ws[" << (d - 1) << "][lane] = acc" << d << "; vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        o << I2 << "if (step_begin < step_end) QGS_LOAD_XS(stages);\n";
+        o << I2 << "__syncthreads();\n";
+        o << I2 << "QGS_REC_INIT\n";
+        o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+        o << I3 << "if (ti == next_rec) {\n"
+          << I4 << "i64 Lr = L; asm volatile(\"\" : \"+s\"(Lr));   // keeps the row offsets out of the loop-invariant set\n"
+          << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * Lr + l;\n"
+          << I4 << "++iw; next_rec += write_steps;\n"
+          << I4 << "if (live) {\n";
+        for (int d : own) o << I4 << "    p[" << (d - 1) << " * Lr] = acc" << d << ";\n";
+        o << I4 << "}\n" << I3 << "}\n";
+        o << "#pragma nounroll\n";
+        o << I3 << "for (int st = 0; st < S; ++st) {\n";
+        o << I4 << "const bool last = (st == S - 1);\n";
+        o << I4 << "const f64 hb = dt * tab[st] * inverse;\n";                      // inverse = +-1: exact
+        o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st] * inverse;\n";
+        o << I4 << "i64 yoff = 0; asm volatile(\"\" : \"+s\"(yoff));\n";
+        o << I4 << "unsigned long long lastmask = last ? ~0ull : 0ull; asm volatile(\"\" : \"+v\"(lastmask));\n";
+        const bool table = opt.lds_coeff_table;
+        if (table) {
+            g_ktab = &tables[w];
+            o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
+        } else g_asm_lit = true;
+        std::ostringstream so;
+        std::vector<PTerm> terms;
+        for (int i : own) {
+            so << I4 << "f64 k" << i << " = 0.0;\n";
+            terms.insert(terms.end(), rt[i].begin(), rt[i].end());
+        }
+        const std::vector<Phase> phases = build_phases(2 * ndim, terms, cap);
+        const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
+        emit_lds_phases(so, I4, phases, node, {"lane8", "xl8"}, "(const char*)lds_all", opt.lds_group, hook_phase,
+                        [&](std::ostringstream &h) {
+                            for (int d : own) h << I4 << "const f64 yg" << d << " = vw[yoff + " << (d - 1) * 64 << "];\n";
+                        }, stats);
+        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
+        g_ktab = nullptr;
+        g_asm_lit = false;
+        for (int d : own) {
+            o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
+            o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";
+        }
+        o << I4 << "__syncthreads();          // every wavefront is done reading xs and ws\n";
+        for (int d : own) o << I4 << "ws[" << (d - 1) << "][lane] = k" << d << ";\n";
+        // stage state of the next stage (or of the first stage of the next step)
+        o << I4 << "{\n"
+          << I4 << "    const i64 nxt = (ti - step_begin) * S + st + 1;\n"
+          << I4 << "    if (nxt < (step_end - step_begin) * S) QGS_LOAD_XS(stages + nxt * " << ndim << " * ld);\n"
+          << I4 << "}\n";
+        o << I4 << "__syncthreads();\n";
+        o << I3 << "}\n";
+        for (int d : own) o << I3 << "vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        o << I2 << "}\n";
+        o << I2 << "if (live) {\n" << I3 << "if (w_out_p) {\n";
+        for (int d : own) o << I4 << "w_out_p[" << (d - 1) << " * L + l] = acc" << d << ";\n";
+        o << I3 << "}\n" << I3 << "if (write_final) {\n"
+          << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
+        for (int d : own) o << I4 << "p[" << (d - 1) << " * L] = acc" << d << ";\n";
+        o << I3 << "}\n" << I2 << "}\n    }\n";
+    }
+    o << "#undef QGS_LOAD_XS\n}\n";
+    out << "// per stage and 64 (member, column) pairs: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
+        << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
     if (opt.lds_coeff_table)
         for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
@@ -1226,6 +1394,8 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::TglSplit: return "qgs_spec_tglsplit" + std::to_string(opt.tgl_split) + "_s" + std::to_string(S);
     case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
+    case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves);
+    case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves);
     }
     return "";
 }
@@ -1254,6 +1424,8 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
                               opt.tgl_split, opt);
         break;
     case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt); break;
+    case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt); break;
+    case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt); break;
     }
     return o.str();
 }

@@ -248,7 +248,7 @@ struct qgs_model {
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
     bool lds_spec_possible = false;   // too large for the register file, stage state fits LDS: JIT LDS-resident stepper
-    mutable int lds_on_disk = -1;     // -1 not checked yet, 0 / 1: code object of that stepper is in the kernel cache
+    mutable std::map<std::string, bool> lds_on_disk;   // kernel name -> code object found in the kernel cache (checked once)
     qgs::CodegenOptions cg;
     // compiled specialised kernels, one module per kernel (keyed by the kernel name)
     std::map<std::string, hipModule_t> modules;
@@ -258,7 +258,7 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_mom_part, b_mom_out;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out;
     KernelInfo last;
 };
 
@@ -456,6 +456,14 @@ bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
     return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
 
+// below this many (member, column) pairs the wavefront-per-pair kernel would be preferred to the LDS-resident tangent
+// kernel; measured (tools/tgls228.py): the LDS-resident one wins at every size (1 x 228 pairs: 3.8 vs 5.5 ms per 10 steps)
+int64_t lds_tgl_min_pairs()
+{
+    if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MIN_PAIRS")) return std::atoll(e);
+    return 0;
+}
+
 // wavefront-per-(member, column) tangent kernel: against the specialised lane kernel it wins below 4096 pairs,
 // against the simple generic kernel (large ndim, latency-bound at ~350 ms per 10 steps) up to ~16k pairs
 bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
@@ -469,17 +477,35 @@ bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
 // JIT LDS-resident stepper for systems beyond the register file (codegen.cpp emit_rk_lds_kernel).  Compiling it takes
 // about 20 s for MAOOAM 6x6 (once: the code object is cached on disk), so in auto mode it is used when the code object
 // is already there, for runs long enough to pay for the compilation, or when requested with qgs_model_set_kernel(m, 2).
+bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work)
+{
+    if (const char *e = std::getenv("QGS_HIP_LDS")) return *e == '1';
+    if (m->kernel_kind == 2) return true;
+    const std::string name = qgs::kernel_name(k, 0, m->cg);
+    if (m->functions.count(name)) return true;                                              // already loaded
+    auto it = m->lds_on_disk.find(name);
+    if (it == m->lds_on_disk.end())
+        it = m->lds_on_disk.emplace(name, source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, k, 0, m->cg), m->arch)).first;
+    if (it->second) return true;                                                            // built earlier (qgs_prebuild / a previous run)
+    return work >= 2e12;                                                                    // ~10 s of the generic kernels
+}
+
 bool use_lds_spec(const qgs_model *m, int64_t n_traj, int64_t n_steps, int s, const double *a)
 {
     if (m->kernel_kind == 1 || !m->lds_spec_possible) return false;
     if (s < 1 || s > 64 || !qgs::tableau_is_subdiagonal(s, a)) return false;
-    if (const char *e = std::getenv("QGS_HIP_LDS")) return *e == '1';
-    if (m->kernel_kind == 2) return true;
-    if (m->functions.count(qgs::kernel_name(qgs::Kernel::RkLds, 0, m->cg))) return true;   // already loaded
-    if (m->lds_on_disk < 0)
-        m->lds_on_disk = source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::RkLds, 0, m->cg), m->arch) ? 1 : 0;
-    if (m->lds_on_disk == 1) return true;                                                   // built earlier (qgs_prebuild / a previous run)
-    return (double)n_traj * (double)n_steps * (double)s * (double)m->T.size() >= 2e12;      // ~10 s of the tiled generic kernel
+    return lds_kernel_wanted(m, qgs::Kernel::RkLds, (double)n_traj * (double)n_steps * (double)s * (double)m->T.size());
+}
+
+// LDS-resident tangent / adjoint kernel (codegen.cpp emit_tgl_lds_kernel): stage state of 16 members + tangent vector of
+// 64 pairs in LDS, i.e. ndim * 640 B
+bool use_lds_tgl(const qgs_model *m, int64_t pairs, int64_t n_steps, int s, const double *a, int adjoint)
+{
+    if (m->kernel_kind == 1 || !m->lds_spec_possible || m->J.empty()) return false;
+    if ((size_t)m->ndim * 640 > (size_t)QGS_LDS_STATE_BYTES) return false;
+    if (s < 1 || s > 64 || !qgs::tableau_is_subdiagonal(s, a)) return false;
+    return lds_kernel_wanted(m, adjoint ? qgs::Kernel::AdjLds : qgs::Kernel::TglLds,
+                             (double)pairs * (double)n_steps * (double)s * (double)m->J.size());
 }
 
 // tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
@@ -506,6 +532,29 @@ int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, 
                     &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S};
     note_kernel(m, name, f);
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
+    return 0;
+}
+
+// LDS-resident tangent / adjoint launch: one workgroup per tile of 16 members x 4 columns
+int launch_tgl_lds(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *w_in, double *w_out, double *d_rec_fm,
+                   const double *stages, const double *d_time, const double *d_tab, int64_t step_begin, int64_t step_end,
+                   int64_t write_steps, int64_t n_records, int backward, int write_final, int adjoint, double inverse, int s,
+                   hipStream_t st)
+{
+    hipFunction_t f;
+    std::string name;
+    if (get_function(m, adjoint ? qgs::Kernel::AdjLds : qgs::Kernel::TglLds, 0, &f, &name)) return -1;
+    const int64_t bx = (n_traj + 15) / 16, by = (n_tg + 3) / 4;
+    if (by > 65535) return fail("too many tangent columns for the LDS-resident tangent kernel");
+    if (m->b_vwork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)(bx * by))) return -1;
+    double *vw = m->b_vwork.f64();
+    long long nt = n_traj, l = ld, ntg = n_tg, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
+    int bw = backward, wf = write_final, S = s;
+    double inv = inverse;
+    void *args[] = {(void *)&w_in, &w_out, &vw, &d_rec_fm, (void *)&stages, (void *)&d_time, (void *)&d_tab,
+                    &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &inv, &S};
+    note_kernel(m, name, f);
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)bx, (unsigned)by, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
     return 0;
 }
 
@@ -614,7 +663,7 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_mom_part, &m->b_mom_out})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out})
         b->release();
     delete m;
     return 0;
@@ -869,7 +918,11 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             qgs::launch_gen_rk(m->dT.view(), pa, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
         }
         // --- tangent / adjoint pass ---
-        if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
+        const bool lds_tgl = !spec && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
+        if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs())) {
+            if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
+                               n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
+        } else if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
             HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
                                             d_tab_spec, st));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
@@ -1063,7 +1116,11 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, i
         if ((size_t)ndim * 512 > (size_t)QGS_LDS_STATE_BYTES || m.T.size() > 200000) return 0;
         std::vector<char> code;
         bool cached;
-        return compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg), m.arch, code, &cached) ? -1 : 0;
+        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg), m.arch, code, &cached)) return -1;
+        if (!m.J.empty() && (size_t)ndim * 640 <= (size_t)QGS_LDS_STATE_BYTES)
+            for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
+                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg), m.arch, code, &cached)) return -1;
+        return 0;
     }
     for (auto &ks : qgs::kernel_list(m.ndim, !m.J.empty(), stages, m.cg)) {
         std::vector<char> code;

@@ -125,6 +125,32 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
             assert out.shape == ref.shape and rel_err(out, ref) < 1e-12, (kind, d, ws, len(b))
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
+        if kind == 2:
+            assert m.last_kernel_info()['name'] == 'qgs_spec_tgllds16'
+    m.set_kernel(0)
+
+
+@pytest.mark.parametrize('n_traj,n_tg', [(1, 5), (17, 4), (40, 7)])
+def test_lds_resident_tangent_ndim228_vs_oracle(models, n_traj, n_tg):
+    """MAOOAM 6x6: the JIT LDS-resident tangent and adjoint kernels (16 members x 4 columns per workgroup; ragged
+    member and column tiles) against the oracle: tangent forward with records, adjoint backward with `inverse`."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden('t228'), models('t228')
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    rng = np.random.RandomState(7 * n_traj + n_tg)
+    ic = rng.rand(n_traj, g.ndim) * 0.01
+    tg = rng.randn(n_traj, g.ndim, n_tg)
+    t = np.concatenate((np.arange(0., 0.6, 0.1), [0.6]))
+    b2, c2 = np.array([0., 1.]), np.array([0., .5])
+    a2 = np.zeros((2, 2)); a2[1, 0] = .5
+    cases = [(1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.), (-1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.),
+             (1, 0, b2, c2, a2, True, 1.)]
+    m.set_kernel(2)
+    for d, ws, b, c, a, adj, inv in cases:
+        rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t, ic, tg, d, ws, b, c, a, adj, inv)
+        tr, fm = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
+        assert m.last_kernel_info()['name'] == ('qgs_spec_adjlds16' if adj else 'qgs_spec_tgllds16')
+        assert fm.shape == rfm.shape and rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (d, ws, adj, inv)
     m.set_kernel(0)
 
 

@@ -10,7 +10,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s tensor.txt tend|rk|rksplit|rkstages|rklds [S]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s tensor.txt tend|rk|rksplit|rkstages|rklds|tgllds|adjlds [S]\n", argv[0]); return 2; }
     FILE *f = std::fopen(argv[1], "r");
     if (!f) { std::perror(argv[1]); return 1; }
     int ndim; long nnz;
@@ -36,6 +36,11 @@ int main(int argc, char **argv)
     else if (!std::strcmp(argv[2], "rksplit")) k = qgs::Kernel::RkSplit;
     else if (!std::strcmp(argv[2], "rkstages")) k = qgs::Kernel::RkStages;
     else if (!std::strcmp(argv[2], "rklds")) k = qgs::Kernel::RkLds;
-    std::cout << qgs::generate_kernel(ndim, T, {}, k, S, opt);
+    else if (!std::strcmp(argv[2], "tgllds")) k = qgs::Kernel::TglLds;
+    else if (!std::strcmp(argv[2], "adjlds")) k = qgs::Kernel::AdjLds;
+    std::vector<qgs::Term> J;                       // Jacobian tensor = T + T.swapaxes(1, 2) (qgtensor.py:700-722)
+    if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds)
+        for (const qgs::Term &t : T) { J.push_back(t); J.push_back({t.i, t.k, t.j, t.v}); }
+    std::cout << qgs::generate_kernel(ndim, T, J, k, S, opt);
     return 0;
 }

@@ -10,7 +10,10 @@ p = model_configs.params_t228(); f, Df = create_tendencies(p); m = f.hip_model()
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 t = np.concatenate((np.arange(0., 0.1, 0.01), [0.1]))
 dev = torch.device('cuda', 0); st = torch.cuda.current_stream().cuda_stream
-for n, nv in ((1, 228), (1, 20), (64, 8), (1024, 4), (4096, 8)):
+shapes = ((1, 228), (1, 20), (64, 8), (1024, 4), (4096, 8), (16384, 8), (1024, 228))
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]]
+for n, nv in shapes:
     ld = (n + 63) // 64 * 64
     ic = torch.from_numpy(np.random.RandomState(2).rand(ndim, ld) * 0.01).to(dev)
     q = torch.randn((ndim, nv, ld), dtype=torch.float64, device=dev)
@@ -19,4 +22,6 @@ for n, nv in ((1, 228), (1, 20), (64, 8), (1024, 4), (4096, 8)):
     fn = lambda: m.rk_tgls_integrate_device(n, ld, nv, ic.data_ptr(), q.data_ptr(), t, 1, 0, b, c, a, False, 1., yend.data_ptr(), qn.data_ptr(), st)
     fn(); torch.cuda.synchronize()
     t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); el = time.perf_counter() - t0
-    print('n=%5d n_tg=%3d 10 steps: %9.3f ms  %s' % (n, nv, el * 1e3, m.last_kernel_info()['name']), flush=True)
+    # 4 stages x 55 522 Jacobian-tensor terms x 3 flop per (member, column) pair and step
+    print('n=%5d n_tg=%3d 10 steps: %9.3f ms  %s  %.3e pair-steps/s  %.2f TFLOP/s' % (n, nv, el * 1e3, m.last_kernel_info()['name'], n * nv * 10 / el,
+                                                                                   n * nv * 10 / el * 4 * 55522 * 3 / 1e12), flush=True)
