@@ -55,3 +55,13 @@ def params_g30():
 
 
 MAKERS = {'rp20': params_rp20, 'a36': params_a36, 'm36': params_m36, 't228': params_t228, 'g30': params_g30}
+
+
+def params_a72():
+    """Atmosphere only, 4x4 modes with orography (ndim 72): between the register-resident kernels (ndim <= 64) and the
+    MAOOAM 6x6 case, served by the LDS-resident JIT kernels; not a golden configuration (checked against the oracle)."""
+    p = QgParams({'phi0_npi': np.deg2rad(50.) / np.pi, 'hd': 0.1})
+    p.set_atmospheric_channel_fourier_modes(4, 4)
+    p.ground_params.set_orography(0.2, 1)
+    p.atemperature_params.set_thetas(0.2, 0)
+    return p

@@ -261,3 +261,32 @@ def test_kernel_variants_agree_with_oracle(monkeypatch, env):
         tr, fm = m.rk_tgls_integrate(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (env, kind)
     m.close()
+
+
+def test_lds_resident_kernels_on_a_second_tensor_ndim72():
+    """The LDS-resident generators on another tensor: atmosphere 4x4 with orography (ndim 72, between the
+    register-resident limit of 64 and MAOOAM 6x6).  Stepper, tangent and adjoint against the oracle."""
+    import model_configs
+    from qgs_amd.functions.tendencies import create_tendencies
+    from oracle.oracle import OracleModel
+    f, Df = create_tendencies(model_configs.params_a72())
+    assert f.ndim == 72
+    m = f.hip_model()
+    ora = OracleModel(f.ndim, f.coo, f.val, Df.coo, Df.val)
+    rng = np.random.RandomState(72)
+    ic = rng.rand(70, f.ndim) * 0.05
+    t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
+    ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
+    tg = rng.randn(9, f.ndim, 6)
+    for kind, names in ((1, ('gen_rk_tiled_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16'))):
+        m.set_kernel(kind)
+        out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
+        assert m.last_kernel_info()['name'] == names[0]
+        assert rel_err(out, ref) < 1e-12, kind
+        for adj in (False, True):
+            rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
+            tr, fm = m.rk_tgls_integrate(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
+            assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (kind, adj)
+        if names[1]:
+            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16'
+    f.operands.release()
