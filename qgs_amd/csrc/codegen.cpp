@@ -466,7 +466,10 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
       << "            ++iw; next_rec += write_steps;\n"
       << "            if (live) {\n";
-    for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    for (int d = 1; d <= ndim; ++d) {
+        if (opt.nt_record) o << "                __builtin_nontemporal_store(y" << d << ", p + " << (d - 1) << " * ld);\n";
+        else o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    }
     o << "            }\n        }\n";
     o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
@@ -1150,7 +1153,8 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "                                    // the end of every stage instead of being held in registers\n"
       << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
-      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S)\n{\n";
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S,\n"
+      << "    int tend_only)                   // 1: evaluate f(y_in) once into y_out and return (one step, one stage requested)\n{\n";
     o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
     o << "    const int lane = threadIdx.x & 63;\n"
       << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
@@ -1218,6 +1222,10 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;
+        o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"
+          << I4 << "    if (live) {\n";
+        for (int d : own) o << I4 << "        y_out[" << (d - 1) << " * ld + m] = k" << d << ";\n";
+        o << I4 << "    }\n" << I4 << "    return;\n" << I4 << "}\n";
         for (int d : own) {
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
             o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";

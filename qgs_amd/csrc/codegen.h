@@ -29,6 +29,7 @@ struct CodegenOptions {
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
+    bool nt_record = false;    // plain stepper: non-temporal stores for the records
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
     int lds_cap = 20;          // ... and modes cached in registers per phase (24 spills at 128 VGPRs: 63.6 ms vs 55.6 ms)

@@ -258,7 +258,7 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit;
     KernelInfo last;
 };
 
@@ -433,6 +433,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) cg.lds_cap = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_NT_RECORD")) cg.nt_record = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
@@ -518,7 +519,7 @@ bool use_tiled(const qgs_model *m, int s, const double *a)
 // LDS-resident JIT stepper launch (codegen.cpp emit_rk_lds_kernel): W wavefronts per 64 members
 int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, double *y_out, double *d_rec, double *stages,
                   const double *d_time, const double *d_tab, int64_t step_begin, int64_t step_end, int64_t write_steps,
-                  int64_t n_records, int backward, int write_final, int s, hipStream_t st)
+                  int64_t n_records, int backward, int write_final, int s, hipStream_t st, int tend_only = 0)
 {
     hipFunction_t f;
     std::string name;
@@ -527,9 +528,9 @@ int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, 
     if (m->b_ywork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)blocks)) return -1;
     double *yw = m->b_ywork.f64();
     long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
-    int bw = backward, wf = write_final, S = s;
+    int bw = backward, wf = write_final, S = s, to = tend_only;
     void *args[] = {(void *)&y_in, &y_out, &yw, &d_rec, &stages, (void *)&d_time, (void *)&d_tab,
-                    &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S};
+                    &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S, &to};
     note_kernel(m, name, f);
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
     return 0;
@@ -663,7 +664,7 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out, &m->b_unit})
         b->release();
     delete m;
     return 0;
@@ -759,6 +760,17 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
         void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
         note_kernel(m, "qgs_spec_tend", f);
         return launch(f, n_traj, st, args);
+    }
+    if (m->kernel_kind != 1 && m->lds_spec_possible &&
+        lds_kernel_wanted(m, qgs::Kernel::RkLds, (double)n_traj * (double)m->T.size())) {
+        // one stage of the LDS-resident stepper with `tend_only`: the tendencies land in d_dx
+        if (!m->b_unit.p) {
+            const double unit[4] = {0.0, 1.0, 1.0, 0.0};                      // time grid {0, 1}; tableau b = {1}
+            if (m->b_unit.ensure(sizeof unit)) return -1;
+            HIPCHK(hipMemcpy(m->b_unit.p, unit, sizeof unit, hipMemcpyHostToDevice));
+        }
+        return launch_rk_lds(m, n_traj, ld, d_x, d_dx, nullptr, nullptr, m->b_unit.f64(), m->b_unit.f64() + 2, 0, 1, 0, 1, 0, 0, 1,
+                             st, 1);
     }
     qgs::launch_gen_tend(m->dT.view(), m->ndim, n_traj, ld, d_x, d_dx, st);
     note_kernel(m, "gen_tend_kernel", nullptr);
