@@ -51,17 +51,27 @@ int qgs_model_create(int device, int ndim,
                      int64_t nnz, const int32_t *coo, const double *val,
                      int64_t jnnz, const int32_t *jcoo, const double *jval,
                      qgs_model **out);
+/* Same for a tensor of rank 3 or 5: coo is (nnz, rank), jcoo (jnnz, rank).  Rank 5 is the tensor of the dynamic-
+ * temperature and T^4 models (QgsTensorDynamicT / QgsTensorT4, qgs/tensors/qgtensor.py:843-1363), whose closures
+ * contract it with sparse_mul5 / sparse_mul4 (qgs/functions/tendencies.py:98-109, sparse_mul.py:84-158):
+ *     f_i = sum T_ijklm x_j x_k x_l x_m ,   Df_ij = sum Tj_ijklm x_k x_l x_m     (index 0 = the constant slot).
+ * Every other entry point works on such a model unchanged. */
+int qgs_model_create_rank(int device, int ndim, int rank,
+                          int64_t nnz, const int32_t *coo, const double *val,
+                          int64_t jnnz, const int32_t *jcoo, const double *jval,
+                          qgs_model **out);
 int qgs_model_destroy(qgs_model *m);
 
-/* Model properties: which=0 ndim, 1 nnz, 2 jnnz, 3 device, 4 specialised-kernel available (0/1). */
+/* Model properties: which=0 ndim, 1 nnz, 2 jnnz, 3 device, 4 specialised-kernel available (0/1), 5 tensor rank,
+ * 6 / 7 number of derived monomials of the tendencies / Jacobian code (rank 5). */
 int64_t qgs_model_info(const qgs_model *m, int which);
 
 /* Select the kernel family: 0 = automatic (specialised when available, else generic),
  * 1 = force generic (tensor streamed from memory, any ndim), 2 = force specialised.
  * Specialised = code generated from the tensor and compiled at run time (cached on disk): register-resident
  * kernels up to 64 variables; beyond that (stage state <= 152 KB of LDS, i.e. ndim <= 304) the LDS-resident
- * stepper serves the trajectory integrations and (ndim <= 243) LDS-resident tangent / adjoint kernels the tangent
- * pass; f / Df stay generic.  In automatic mode
+ * stepper serves the trajectory integrations and f, and (ndim <= 243) LDS-resident tangent / adjoint kernels the
+ * tangent pass; Df stays generic.  Rank-5 models have the register-resident kernels only.  In automatic mode
  * these are used when their code objects are already cached or the run is long enough to pay for the 20-40 s
  * compilation. */
 int qgs_model_set_kernel(qgs_model *m, int kind);
@@ -156,6 +166,10 @@ int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val,
                  int64_t jnnz, const int32_t *jcoo, const double *jval,
                  int n_stage_counts, const int *stage_counts, const char *arch);
+
+int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val,
+                      int64_t jnnz, const int32_t *jcoo, const double *jval,
+                      int n_stage_counts, const int *stage_counts, const char *arch);
 
 /* Generated HIP source of the specialised kernels of this model (debugging / inspection).
  * Returns the length; copies at most buflen-1 bytes. */

@@ -33,18 +33,20 @@ def lib():
         L = ctypes.CDLL(build())
         L.oracle_sparse_mul3.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p]
         L.oracle_sparse_mul2.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p]
-        L.oracle_tendencies.argtypes = [_i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
-        L.oracle_jacobian.argtypes = [_i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
+        L.oracle_sparse_mul5.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p, _f64p]
+        L.oracle_sparse_mul4.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p]
+        L.oracle_tendencies_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
+        L.oracle_jacobian_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
         L.oracle_n_records.argtypes = [_f64p, _i64, _i64]
         L.oracle_n_records.restype = _i64
-        L.oracle_rk_integrate.argtypes = [_i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p, _i64, ctypes.c_int, _i64,
-                                          ctypes.c_int, _f64p, _f64p, _f64p, _i64, _f64p, ctypes.c_int]
-        L.oracle_rk_tgls_integrate.argtypes = [_i64, _i64, _i32p, _f64p, _i64, _i32p, _f64p, _i64, _i64, _f64p, _f64p,
+        L.oracle_rk_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p, _i64, ctypes.c_int, _i64,
+                                            ctypes.c_int, _f64p, _f64p, _f64p, _i64, _f64p, ctypes.c_int]
+        L.oracle_rk_tgls_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _i32p, _f64p, _i64, _i64, _f64p, _f64p,
                                                _f64p, _i64, ctypes.c_int, _i64, ctypes.c_int, _f64p, _f64p, _f64p,
                                                ctypes.c_int, ctypes.c_double, _i64, _f64p, _f64p, ctypes.c_int]
         L.oracle_max_threads.restype = ctypes.c_int
-        for fn in (L.oracle_sparse_mul3, L.oracle_sparse_mul2, L.oracle_tendencies, L.oracle_jacobian,
-                   L.oracle_rk_integrate, L.oracle_rk_tgls_integrate):
+        for fn in (L.oracle_sparse_mul3, L.oracle_sparse_mul2, L.oracle_sparse_mul5, L.oracle_sparse_mul4,
+                   L.oracle_tendencies_r, L.oracle_jacobian_r, L.oracle_rk_integrate_r, L.oracle_rk_tgls_integrate_r):
             fn.restype = None
         _LIB = L
     return _LIB
@@ -72,12 +74,31 @@ def sparse_mul2(coo, value, vec):
     return res
 
 
+def sparse_mul5(coo, value, vec_a, vec_b, vec_c, vec_d):
+    coo, value = _c(coo, np.int32), _c(value)
+    vec_a, vec_b, vec_c, vec_d = _c(vec_a), _c(vec_b), _c(vec_c), _c(vec_d)
+    res = np.empty_like(vec_a)
+    lib().oracle_sparse_mul5(len(value), coo, value, len(vec_a), vec_a, vec_b, vec_c, vec_d, res)
+    return res
+
+
+def sparse_mul4(coo, value, vec_a, vec_b, vec_c):
+    coo, value, vec_a, vec_b, vec_c = _c(coo, np.int32), _c(value), _c(vec_a), _c(vec_b), _c(vec_c)
+    res = np.empty((len(vec_a), len(vec_a)))
+    lib().oracle_sparse_mul4(len(value), coo, value, len(vec_a), vec_a, vec_b, vec_c, res)
+    return res
+
+
 class OracleModel(object):
-    """Holds the COO operands the reference's `f`/`Df` closures capture (tendencies.py:92-96)."""
+    """Holds the COO operands the reference's `f`/`Df` closures capture (tendencies.py:92-96).  The rank of the
+    tensor is the width of `coo`: 3 (QgsTensor: sparse_mul3 / sparse_mul2) or 5 (QgsTensorDynamicT / QgsTensorT4:
+    sparse_mul5 / sparse_mul4, tendencies.py:98-109)."""
 
     def __init__(self, ndim, coo, val, jcoo=None, jval=None):
         self.ndim = int(ndim)
         self.coo, self.val = _c(coo, np.int32), _c(val)
+        self.rank = int(self.coo.shape[1])
+        assert self.rank in (3, 5)
         self.jcoo = _c(jcoo, np.int32) if jcoo is not None else None
         self.jval = _c(jval) if jval is not None else None
 
@@ -86,14 +107,14 @@ class OracleModel(object):
         x = _c(x)
         xb = x.reshape(-1, self.ndim)
         out = np.empty_like(xb)
-        lib().oracle_tendencies(self.ndim, len(self.val), self.coo, self.val, xb.shape[0], xb, out)
+        lib().oracle_tendencies_r(self.rank, self.ndim, len(self.val), self.coo, self.val, xb.shape[0], xb, out)
         return out.reshape(x.shape)
 
     def Df(self, t, x):
         x = _c(x)
         xb = x.reshape(-1, self.ndim)
         out = np.empty((xb.shape[0], self.ndim, self.ndim))
-        lib().oracle_jacobian(self.ndim, len(self.jval), self.jcoo, self.jval, xb.shape[0], xb, out)
+        lib().oracle_jacobian_r(self.rank, self.ndim, len(self.jval), self.jcoo, self.jval, xb.shape[0], xb, out)
         return out[0] if x.ndim == 1 else out
 
     @staticmethod
@@ -107,7 +128,7 @@ class OracleModel(object):
         n_traj = ic.shape[0]
         nrec = self.n_records(time, write_steps)
         rec = np.zeros((n_traj, self.ndim, nrec))
-        lib().oracle_rk_integrate(self.ndim, len(self.val), self.coo, self.val, n_traj, ic, time, len(time),
+        lib().oracle_rk_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, n_traj, ic, time, len(time),
                                   int(time_direction), int(write_steps), len(b), b, c, a, nrec, rec, int(threads))
         return rec
 
@@ -119,7 +140,7 @@ class OracleModel(object):
         nrec = self.n_records(time, write_steps)
         rec = np.zeros((n_traj, self.ndim, nrec))
         recm = np.zeros((n_traj, self.ndim, n_tg, nrec))
-        lib().oracle_rk_tgls_integrate(self.ndim, len(self.val), self.coo, self.val, len(self.jval), self.jcoo,
+        lib().oracle_rk_tgls_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, len(self.jval), self.jcoo,
                                        self.jval, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
                                        int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
                                        nrec, rec, recm, int(threads))

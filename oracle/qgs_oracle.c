@@ -51,10 +51,43 @@ void oracle_sparse_mul2(int64_t nnz, const int32_t *coo, const double *value,
         res[(int64_t)coo[3 * e + 0] * n + coo[3 * e + 1]] += vec[coo[3 * e + 2]] * value[e];
 }
 
+/* qgs/functions/sparse_mul.py:123-158  sparse_mul5
+ *   res[coo[n,0]] += vec_a[coo[n,1]] * vec_b[coo[n,2]] * vec_c[coo[n,3]] * vec_d[coo[n,4]] * value[n]; res[0] = 1.
+ * coo is (nnz,5) row-major int32 (left-to-right products, like the Python expression). */
+void oracle_sparse_mul5(int64_t nnz, const int32_t *coo, const double *value, int64_t n,
+                        const double *vec_a, const double *vec_b, const double *vec_c, const double *vec_d, double *res)
+{
+    for (int64_t i = 0; i < n; ++i) res[i] = 0.0;
+    for (int64_t e = 0; e < nnz; ++e) {
+        double prod = vec_a[coo[5 * e + 1]] * vec_b[coo[5 * e + 2]];
+        prod = prod * vec_c[coo[5 * e + 3]];
+        prod = prod * vec_d[coo[5 * e + 4]];
+        prod = prod * value[e];
+        res[coo[5 * e + 0]] += prod;
+    }
+    res[0] = 1.0;
+}
+
+/* qgs/functions/sparse_mul.py:84-120  sparse_mul4
+ *   res[coo[n,0], coo[n,1]] += vec_a[coo[n,2]] * vec_b[coo[n,3]] * vec_c[coo[n,4]] * value[n] */
+void oracle_sparse_mul4(int64_t nnz, const int32_t *coo, const double *value, int64_t n,
+                        const double *vec_a, const double *vec_b, const double *vec_c, double *res /* n*n row-major */)
+{
+    for (int64_t i = 0; i < n * n; ++i) res[i] = 0.0;
+    for (int64_t e = 0; e < nnz; ++e) {
+        double prod = vec_a[coo[5 * e + 2]] * vec_b[coo[5 * e + 3]];
+        prod = prod * vec_c[coo[5 * e + 4]];
+        prod = prod * value[e];
+        res[(int64_t)coo[5 * e + 0] * n + coo[5 * e + 1]] += prod;
+    }
+}
+
 typedef struct {
     int64_t ndim;
     int64_t nnz;  const int32_t *coo;  const double *val;
     int64_t jnnz; const int32_t *jcoo; const double *jval;
+    int rank;     /* 3: QgsTensor (sparse_mul3 / sparse_mul2); 5: QgsTensorDynamicT / QgsTensorT4 (sparse_mul5 / sparse_mul4),
+                     qgs/functions/tendencies.py:98-121 */
 } oracle_model;
 
 /* qgs/functions/tendencies.py:111-115  f(t, x): xx = concat(([1.], x)); xr = sparse_mul3(coo,val,xx,xx); return xr[1:]
@@ -65,7 +98,8 @@ static void model_f(const oracle_model *m, const double *x, double *out, double 
     double *xx = work, *xr = work + n;
     xx[0] = 1.0;
     memcpy(xx + 1, x, sizeof(double) * m->ndim);
-    oracle_sparse_mul3(m->nnz, m->coo, m->val, n, xx, xx, xr);
+    if (m->rank == 5) oracle_sparse_mul5(m->nnz, m->coo, m->val, n, xx, xx, xx, xx, xr);   /* tendencies.py:100-103 */
+    else oracle_sparse_mul3(m->nnz, m->coo, m->val, n, xx, xx, xr);
     memcpy(out, xr + 1, sizeof(double) * m->ndim);
 }
 
@@ -77,27 +111,40 @@ static void model_Df(const oracle_model *m, const double *x, double *out, double
     double *xx = work, *full = work + n;
     xx[0] = 1.0;
     memcpy(xx + 1, x, sizeof(double) * nd);
-    oracle_sparse_mul2(m->jnnz, m->jcoo, m->jval, n, xx, full);
+    if (m->rank == 5) oracle_sparse_mul4(m->jnnz, m->jcoo, m->jval, n, xx, xx, xx, full);     /* tendencies.py:105-109 */
+    else oracle_sparse_mul2(m->jnnz, m->jcoo, m->jval, n, xx, full);
     for (int64_t i = 0; i < nd; ++i)
         memcpy(out + i * nd, full + (i + 1) * n + 1, sizeof(double) * nd);
 }
 
-void oracle_tendencies(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
-                       int64_t n_traj, const double *x /* n_traj*ndim */, double *out)
+void oracle_tendencies_r(int rank, int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                         int64_t n_traj, const double *x /* n_traj*ndim */, double *out)
 {
-    oracle_model m = {ndim, nnz, coo, val, 0, NULL, NULL};
+    oracle_model m = {ndim, nnz, coo, val, 0, NULL, NULL, rank};
     double *work = (double *)malloc(sizeof(double) * 2 * (ndim + 1));
     for (int64_t t = 0; t < n_traj; ++t) model_f(&m, x + t * ndim, out + t * ndim, work);
     free(work);
 }
 
-void oracle_jacobian(int64_t ndim, int64_t jnnz, const int32_t *jcoo, const double *jval,
-                     int64_t n_traj, const double *x, double *out /* n_traj*ndim*ndim */)
+void oracle_tendencies(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                       int64_t n_traj, const double *x, double *out)
 {
-    oracle_model m = {ndim, 0, NULL, NULL, jnnz, jcoo, jval};
+    oracle_tendencies_r(3, ndim, nnz, coo, val, n_traj, x, out);
+}
+
+void oracle_jacobian_r(int rank, int64_t ndim, int64_t jnnz, const int32_t *jcoo, const double *jval,
+                       int64_t n_traj, const double *x, double *out /* n_traj*ndim*ndim */)
+{
+    oracle_model m = {ndim, 0, NULL, NULL, jnnz, jcoo, jval, rank};
     double *work = (double *)malloc(sizeof(double) * ((ndim + 1) + (ndim + 1) * (ndim + 1)));
     for (int64_t t = 0; t < n_traj; ++t) model_Df(&m, x + t * ndim, out + t * ndim * ndim, work);
     free(work);
+}
+
+void oracle_jacobian(int64_t ndim, int64_t jnnz, const int32_t *jcoo, const double *jval,
+                     int64_t n_traj, const double *x, double *out)
+{
+    oracle_jacobian_r(3, ndim, jnnz, jcoo, jval, n_traj, x, out);
 }
 
 /* Number of records, qgs/integrators/integrate.py:190-196 (and integrator.py:378-384):
@@ -115,14 +162,14 @@ int64_t oracle_n_records(const double *time, int64_t n_time, int64_t write_steps
  * time (n_time), ic (n_traj,n_dim), b (s), c (s), a (s,s) -> recorded_traj (n_traj,n_dim,n_records),
  * already reversed along the record axis when time_direction == -1 (:223).
  * `threads` > 1 parallelises the (independent) trajectory loop (:204) with OpenMP. */
-void oracle_rk_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
-                         int64_t n_traj, const double *ic,
-                         const double *time, int64_t n_time, int time_direction, int64_t write_steps,
-                         int s, const double *b, const double *c, const double *a,
-                         int64_t n_records, double *recorded, int threads)
+void oracle_rk_integrate_r(int rank, int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                           int64_t n_traj, const double *ic,
+                           const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                           int s, const double *b, const double *c, const double *a,
+                           int64_t n_records, double *recorded, int threads)
 {
     (void)c; /* autonomous system: f ignores t (tendencies.py:112) */
-    oracle_model m = {ndim, nnz, coo, val, 0, NULL, NULL};
+    oracle_model m = {ndim, nnz, coo, val, 0, NULL, NULL, rank};
     /* directed_time = reverse(time) if backward (:199-202) */
     double *dtime = (double *)malloc(sizeof(double) * n_time);
     for (int64_t i = 0; i < n_time; ++i) dtime[i] = (time_direction == -1) ? time[n_time - 1 - i] : time[i];
@@ -178,20 +225,30 @@ void oracle_rk_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, const do
     free(dtime);
 }
 
+void oracle_rk_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                         int64_t n_traj, const double *ic,
+                         const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                         int s, const double *b, const double *c, const double *a,
+                         int64_t n_records, double *recorded, int threads)
+{
+    oracle_rk_integrate_r(3, ndim, nnz, coo, val, n_traj, ic, time, n_time, time_direction, write_steps, s, b, c, a,
+                          n_records, recorded, threads);
+}
+
 /* qgs/integrators/integrate.py:555-614  _integrate_runge_kutta_tgls_jit, with
  * _tangent_linear_system (:226-231) and boundary = _zeros_func (:235-237).
  * tg_ic (n_traj, n_dim, n_tg) -> recorded_traj (n_traj,n_dim,n_records),
  * recorded_fmatrix (n_traj, n_dim, n_tg, n_records); `inverse` is the +-1.0 multiplier. */
-void oracle_rk_tgls_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
-                              int64_t jnnz, const int32_t *jcoo, const double *jval,
-                              int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
-                              const double *time, int64_t n_time, int time_direction, int64_t write_steps,
-                              int s, const double *b, const double *c, const double *a,
-                              int adjoint, double inverse,
-                              int64_t n_records, double *recorded, double *recorded_fm, int threads)
+void oracle_rk_tgls_integrate_r(int rank, int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                                int64_t jnnz, const int32_t *jcoo, const double *jval,
+                                int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                                const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                                int s, const double *b, const double *c, const double *a,
+                                int adjoint, double inverse,
+                                int64_t n_records, double *recorded, double *recorded_fm, int threads)
 {
     (void)c;
-    oracle_model m = {ndim, nnz, coo, val, jnnz, jcoo, jval};
+    oracle_model m = {ndim, nnz, coo, val, jnnz, jcoo, jval, rank};
     const int64_t nm = ndim * n_tg;
     double *dtime = (double *)malloc(sizeof(double) * n_time);
     for (int64_t i = 0; i < n_time; ++i) dtime[i] = (time_direction == -1) ? time[n_time - 1 - i] : time[i];
@@ -276,6 +333,18 @@ void oracle_rk_tgls_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, con
         free(y); free(ys); free(k); free(fm); free(kms); free(km); free(J); free(work);
     }
     free(dtime);
+}
+
+void oracle_rk_tgls_integrate(int64_t ndim, int64_t nnz, const int32_t *coo, const double *val,
+                              int64_t jnnz, const int32_t *jcoo, const double *jval,
+                              int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                              const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                              int s, const double *b, const double *c, const double *a,
+                              int adjoint, double inverse,
+                              int64_t n_records, double *recorded, double *recorded_fm, int threads)
+{
+    oracle_rk_tgls_integrate_r(3, ndim, nnz, coo, val, jnnz, jcoo, jval, n_traj, n_tg, ic, tg_ic, time, n_time, time_direction,
+                               write_steps, s, b, c, a, adjoint, inverse, n_records, recorded, recorded_fm, threads);
 }
 
 int oracle_max_threads(void)

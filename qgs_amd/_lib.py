@@ -25,6 +25,7 @@ SIGNATURES = {
     'qgs_last_error': (ctypes.c_char_p, []),
     'qgs_backend_info': (_int, [ctypes.POINTER(_int), ctypes.c_char_p, _int]),
     'qgs_model_create': (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
+    'qgs_model_create_rank': (_int, [_int, _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
     'qgs_model_destroy': (_int, [_vp]),
     'qgs_model_info': (_i64, [_vp, _int]),
     'qgs_model_set_kernel': (_int, [_vp, _int]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     'qgs_last_kernel_info': (_int, [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
                                     ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
+    'qgs_prebuild_rank': (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
     'qgs_model_kernel_source': (_i64, [_vp, ctypes.c_char_p, _i64]),
 }
 
@@ -122,14 +124,23 @@ def _ptr(a):
     return a.ctypes.data_as(_vp) if a is not None else None
 
 
+def _tensor_rank(coo, jcoo=None):
+    """3 for the (nnz, 3) coordinate lists of QgsTensor, 5 for the (nnz, 5) ones of QgsTensorDynamicT / QgsTensorT4."""
+    rank = int(coo.shape[1]) if coo.ndim == 2 else 0
+    if rank not in (3, 5) or (jcoo is not None and jcoo.ndim == 2 and jcoo.shape[0] and jcoo.shape[1] != rank):
+        raise ValueError("tensor coordinates must be (nnz, 3) or (nnz, 5) and of the same rank for the Jacobian tensor")
+    return rank
+
+
 def prebuild(ndim, coo, val, jcoo, jval, stage_counts=(4,), arch=None):
     """Compile + cache the specialised kernels of a tensor without a GPU (see qgs_prebuild)."""
     coo, val = _c(coo, np.int32), _c(val)
     jcoo = _c(jcoo, np.int32) if jcoo is not None else None
     jval = _c(jval) if jval is not None else None
     sc = (_int * len(stage_counts))(*stage_counts)
-    _check(lib().qgs_prebuild(int(ndim), len(val), _ptr(coo), _ptr(val), 0 if jval is None else len(jval), _ptr(jcoo),
-                              _ptr(jval), len(stage_counts), sc, arch.encode() if arch else None))
+    _check(lib().qgs_prebuild_rank(int(ndim), _tensor_rank(coo, jcoo), len(val), _ptr(coo), _ptr(val),
+                                   0 if jval is None else len(jval), _ptr(jcoo), _ptr(jval), len(stage_counts), sc,
+                                   arch.encode() if arch else None))
 
 
 class HipModel(object):
@@ -137,7 +148,9 @@ class HipModel(object):
 
     coo/val, jcoo/jval are the arrays the reference's closures capture
     (qgs/functions/tendencies.py:92-96): `tensor.coords.T`, `tensor.data`, and the same for
-    `jacobian_tensor`.
+    `jacobian_tensor`.  (nnz, 3) coordinates: the rank-3 tensor contracted by sparse_mul3 / sparse_mul2;
+    (nnz, 5): the rank-5 tensor of the dynamic-T / T4 models contracted by sparse_mul5 / sparse_mul4
+    (tendencies.py:98-109).
     """
 
     KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALISED = 0, 1, 2
@@ -148,10 +161,11 @@ class HipModel(object):
         self.coo, self.val = _c(coo, np.int32), _c(val)
         self.jcoo = _c(jcoo, np.int32) if jcoo is not None else None
         self.jval = _c(jval) if jval is not None else None
+        self.rank = _tensor_rank(self.coo, self.jcoo)
         h = _vp()
-        _check(lib().qgs_model_create(self.device, self.ndim, len(self.val), _ptr(self.coo), _ptr(self.val),
-                                      0 if self.jval is None else len(self.jval), _ptr(self.jcoo), _ptr(self.jval),
-                                      ctypes.byref(h)))
+        _check(lib().qgs_model_create_rank(self.device, self.ndim, self.rank, len(self.val), _ptr(self.coo), _ptr(self.val),
+                                           0 if self.jval is None else len(self.jval), _ptr(self.jcoo), _ptr(self.jval),
+                                           ctypes.byref(h)))
         self._h = h
 
     def close(self):
@@ -171,6 +185,11 @@ class HipModel(object):
     @property
     def specialised_available(self):
         return bool(lib().qgs_model_info(self._h, 4))
+
+    @property
+    def n_derived(self):
+        """Derived monomials of the generated tendencies / Jacobian code (rank-5 tensors; (0, 0) for rank 3)."""
+        return int(lib().qgs_model_info(self._h, 6)), int(lib().qgs_model_info(self._h, 7))
 
     def last_kernel_info(self):
         name = ctypes.create_string_buffer(128)

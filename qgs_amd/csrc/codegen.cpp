@@ -347,9 +347,20 @@ void emit_wx_row(std::ostringstream &o, const char *indent, const std::vector<WX
     acc.finish();
 }
 
+// Derived monomials (rank-5 tensors, see reduce_polynomial in codegen.h): indices above the model's ndim name
+// products of two earlier variables, `q<idx>`, defined at the head of the block that evaluates a stage.
+thread_local int g_ext_base = 1 << 30;
+
 NameFn names(const std::string &prefix)
 {
-    return [prefix](int k) { return prefix + std::to_string(k); };
+    const int base = g_ext_base;
+    return [prefix, base](int k) { return (k > base ? std::string("q") : prefix) + std::to_string(k); };
+}
+
+void emit_derived(std::ostringstream &o, const char *indent, int ndim, const std::vector<std::pair<int, int>> &der, const NameFn &X)
+{
+    for (size_t n = 0; n < der.size(); ++n)
+        o << indent << "const f64 q" << (ndim + 1 + (int)n) << " = " << X(der[n].first) << " * " << X(der[n].second) << ";\n";
 }
 
 std::string decl_list(const std::string &prefix, int ndim)
@@ -395,12 +406,14 @@ __device__ __forceinline__ f64 qgs_bitsel(unsigned long long mask, f64 a, f64 b)
 }
 )";
 
-void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
+                      const std::vector<std::pair<int, int>> &der)
 {
     o << "\n// f(t,x) for an ensemble: x, dx are X[mode][member] with leading dimension ld\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_tend(const f64* __restrict__ x, f64* __restrict__ dx, i64 n_traj, i64 ld)\n{\n";
     o << "    const i64 m = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n    if (m >= n_traj) return;\n";
     for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
+    emit_derived(o, "    ", ndim, der, names("x"));
     for (int i = 1; i <= ndim; ++i) {
         o << "    {\n";
         emit_tend_row(o, "        ", rows[i], "r", names("x"), opt, i);
@@ -409,7 +422,7 @@ void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &r
     o << "}\n";
 }
 
-void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &jac)
+void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &jac, const std::vector<std::pair<int, int>> &der)
 {
     // J[i][j] = sum_k Tj_ijk x_k  (sparse_mul2, sparse_mul.py:40-45); only structural entries are
     // stored, the caller zero-fills the output.  Output layout: Jm[(i-1)*ndim + (j-1)][member].
@@ -420,6 +433,8 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
     o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_jac(const f64* __restrict__ x, f64* __restrict__ jm, i64 n_traj, i64 ld)\n{\n";
     o << "    const i64 m = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n    if (m >= n_traj) return;\n";
     for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
+    emit_derived(o, "    ", ndim, der, names("x"));
+    const NameFn X = names("x");
     for (auto &kv : ent) {
         o << "    {\n";
         std::ostringstream &oo = o;
@@ -427,7 +442,7 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
         double c0 = 0.0; bool has = false;
         for (const Lin &l : kv.second) if (l.k == 0) { c0 += l.c; has = true; }
         if (has) acc.set_const(c0);
-        for (const Lin &l : kv.second) if (l.k != 0) acc.add(lit(l.c), "x" + std::to_string(l.k));
+        for (const Lin &l : kv.second) if (l.k != 0) acc.add(lit(l.c), X(l.k));
         acc.finish();
         o << "        jm[(i64)" << ((kv.first.first - 1) * ndim + (kv.first.second - 1)) << " * ld + m] = e;\n    }\n";
     }
@@ -438,7 +453,7 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // registers for the whole run.  Storage: y (step start), acc (running y + dt*sum b_i k_i),
 // xa/xb (ping-pong stage inputs).  k_i is consumed row by row as it is produced.
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
-                    const CodegenOptions &opt)
+                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der)
 {
     std::ostringstream o;
     KTable table;
@@ -486,6 +501,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
             o << "            }\n";
         }
+        emit_derived(o, "            ", ndim, der, names(in));
         if (opt.const_table) {
             g_ktab = &table;
             o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
@@ -549,7 +565,7 @@ std::vector<int> partition_rows(int ndim, const std::vector<Row> &rows, int R, c
 }
 
 void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, int R,
-                          const CodegenOptions &opt)
+                          const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der)
 {
     const std::vector<int> owner = partition_rows(ndim, rows, R, opt);
     const std::string kname = "qgs_spec_rksplit" + std::to_string(R) + "_s" + std::to_string(S);
@@ -599,6 +615,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
             o << "                const f64 hb = dt * tb" << st << ";\n";
             if (!last) o << "                const f64 ha = dt * ta" << st << ";\n";
             o << "                const int pb = (par0 + " << st << ") & 1;\n";
+            emit_derived(o, "                ", ndim, der, names(in));      // unused ones are dead code in this wavefront's branch
             if (opt.const_table) {
                 o << "                kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
             }
@@ -652,7 +669,8 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
 // Tangent-linear / adjoint propagation along stored stage states.  One lane per (member, column):
 // lane l = col*ld + member; tangent arrays are F[mode][col][member] = element d*(n_tg*ld) + l.
 void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
-                     const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt)
+                     const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt,
+                     const std::vector<std::pair<int, int>> &der)
 {
     std::ostringstream o;
     KTable tables[2];
@@ -704,6 +722,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         if (!last) o << "            const f64 ha = dt * ta" << st << " * inverse;\n";
         o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
         for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+        emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
             o << "            if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
             if (opt.const_table) {
@@ -1412,20 +1431,22 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
 // perturb each other (the plain stepper went from 276 to 324 VGPRs and 4.6 -> 4.7 ms when a 4-way split
 // sibling was added to its module), so every kernel is generated, compiled and cached on its own.
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
-                            const CodegenOptions &opt)
+                            const CodegenOptions &opt, const Derived &der)
 {
     std::ostringstream o;
     o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
     o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
+    if (!der.empty()) o << "// derived monomials: " << der.t.size() << " (tendencies), " << der.j.size() << " (Jacobian)\n";
     const std::vector<Row> rows = build_rows(ndim, tensor);
+    struct BaseGuard { int old; BaseGuard(int b) : old(g_ext_base) { g_ext_base = b; } ~BaseGuard() { g_ext_base = old; } } guard(ndim);
     switch (k) {
-    case Kernel::Tend: emit_tend_kernel(o, ndim, rows, opt); break;
-    case Kernel::Jac: emit_jac_kernel(o, ndim, jac_tensor); break;
-    case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt); break;
-    case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt); break;
-    case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt); break;
+    case Kernel::Tend: emit_tend_kernel(o, ndim, rows, opt, der.t); break;
+    case Kernel::Jac: emit_jac_kernel(o, ndim, jac_tensor, der.j); break;
+    case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t); break;
+    case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt, der.t); break;
+    case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
     case Kernel::Tgl:
-        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt);
+        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;
     case Kernel::TglSplit:
         emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
@@ -1458,12 +1479,87 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
 }
 
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
-                            const std::vector<int> &stages, const CodegenOptions &opt)
+                            const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der)
 {
     std::string all;
     for (auto &ks : kernel_list(ndim, !jac_tensor.empty(), stages, opt))
-        all += generate_kernel(ndim, tensor, jac_tensor, ks.first, ks.second, opt) + "\n";
+        all += generate_kernel(ndim, tensor, jac_tensor, ks.first, ks.second, opt, der) + "\n";
     return all;
+}
+
+// Greedy common-subexpression reduction of a set of monomials: while some monomial is longer than `target`, the pair
+// of variables that occurs in most of them becomes a new variable (index ndim + 1 + n) and replaces one occurrence
+// of the pair in each.  [a,a,a,m] for many m -> p = a*a, q = p*a, [q,m]: two products shared by all terms.
+static void reduce_monomials(int ndim, std::vector<std::vector<int>> &mono, size_t target, std::vector<std::pair<int, int>> &derived)
+{
+    while (true) {
+        std::map<std::pair<int, int>, int> count;
+        for (const auto &f : mono) {
+            if (f.size() <= target) continue;
+            std::vector<std::pair<int, int>> seen;
+            for (size_t a = 0; a < f.size(); ++a)
+                for (size_t b = a + 1; b < f.size(); ++b) {
+                    const std::pair<int, int> pr(f[a], f[b]);                 // f is sorted: f[a] <= f[b]
+                    if (std::find(seen.begin(), seen.end(), pr) == seen.end()) { seen.push_back(pr); ++count[pr]; }
+                }
+        }
+        if (count.empty()) break;
+        std::pair<int, int> best = count.begin()->first;
+        int best_n = 0;
+        for (const auto &kv : count) if (kv.second > best_n) { best_n = kv.second; best = kv.first; }
+        const int id = ndim + 1 + (int)derived.size();
+        derived.push_back(best);
+        for (auto &f : mono) {
+            while (f.size() > target) {
+                auto ia = std::find(f.begin(), f.end(), best.first);
+                if (ia == f.end()) break;
+                auto ib = std::find(best.first == best.second ? ia + 1 : f.begin(), f.end(), best.second);
+                if (ib == f.end()) break;
+                if (ib < ia) std::swap(ia, ib);
+                f.erase(ib);
+                f.erase(ia);
+                f.insert(std::upper_bound(f.begin(), f.end(), id), id);
+            }
+        }
+    }
+}
+
+void reduce_polynomial(int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val, bool jacobian,
+                       std::vector<Term> &out, std::vector<std::pair<int, int>> &derived)
+{
+    out.clear();
+    derived.clear();
+    const int first = jacobian ? 2 : 1;              // Jacobian entries: (i, j | k, l, m): the monomial starts at column 2
+    if (rank == 3) {                                 // nothing to reduce: the entries are the terms, in the caller's order
+        for (int64_t e = 0; e < nnz; ++e) out.push_back({coo[3 * e], coo[3 * e + 1], coo[3 * e + 2], val[e]});
+        return;
+    }
+    // merge entries with equal (row, column, monomial): the Jacobian tensor holds every permutation separately
+    std::map<std::vector<int>, size_t> where;
+    std::vector<std::vector<int>> mono;
+    std::vector<std::pair<int, int>> head;           // (i, j) -- j only for the Jacobian
+    std::vector<double> v;
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int32_t *c = coo + (int64_t)rank * e;
+        if (c[0] < 1 || (jacobian && c[1] < 1)) continue;   // row 0 is the constant slot; Df drops row and column 0
+        std::vector<int> f;
+        for (int q = first; q < rank; ++q) if (c[q] != 0) f.push_back(c[q]);
+        std::sort(f.begin(), f.end());
+        std::vector<int> key = {c[0], jacobian ? c[1] : 0};
+        key.insert(key.end(), f.begin(), f.end());
+        auto it = where.find(key);
+        if (it != where.end()) { v[it->second] += val[e]; continue; }
+        where[key] = mono.size();
+        mono.push_back(f);
+        head.push_back({c[0], jacobian ? c[1] : 0});
+        v.push_back(val[e]);
+    }
+    reduce_monomials(ndim, mono, jacobian ? 1 : 2, derived);
+    for (size_t n = 0; n < mono.size(); ++n) {
+        const auto &f = mono[n];
+        if (jacobian) out.push_back({head[n].first, head[n].second, f.empty() ? 0 : f[0], v[n]});
+        else out.push_back({head[n].first, f.size() == 2 ? f[0] : 0, f.empty() ? 0 : f.back(), v[n]});
+    }
 }
 
 int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, const CodegenOptions &opt)

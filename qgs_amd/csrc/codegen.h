@@ -39,6 +39,20 @@ struct CodegenOptions {
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
 };
 
+// Rank-5 tensors (QgsTensorDynamicT / QgsTensorT4, qgs/tensors/qgtensor.py:843-1363; contracted by sparse_mul5 /
+// sparse_mul4, qgs/functions/sparse_mul.py:84-158): dx_i = sum T_ijklm x_j x_k x_l x_m.  The generated code keeps
+// the bilinear form of every emitter: products of two variables that many monomials share become *derived
+// variables* (index ndim+1+n = product of two earlier indices, evaluated once per tendency evaluation), until every
+// tendency monomial has at most two factors and every Jacobian monomial at most one.
+struct Derived {
+    std::vector<std::pair<int, int>> t, j;     // for the tendencies tensor / for the Jacobian tensor
+    bool empty() const { return t.empty() && j.empty(); }
+};
+// coo is (nnz, rank) row-major, rank 3 or 5.  `out` receives (i, j, k, v) terms over the extended index space
+// (Jacobian: i, j = column, k = the single remaining x index), `derived` the products to evaluate first.
+void reduce_polynomial(int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val, bool jacobian,
+                       std::vector<Term> &out, std::vector<std::pair<int, int>> &derived);
+
 // Classification of a Butcher tableau (reference: integrate.py:214-219 uses the full matrix `a`).
 // The register-resident kernels need a[i][j] != 0 only for j == i-1 (RK4, Heun, midpoint, Euler ...).
 bool tableau_is_subdiagonal(int s, const double *a);
@@ -60,10 +74,10 @@ bool tableau_is_subdiagonal(int s, const double *a);
 enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
-                            const CodegenOptions &opt);
+                            const CodegenOptions &opt, const Derived &der = Derived());
 std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const std::vector<int> &stages, const CodegenOptions &opt);
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
-                            const std::vector<int> &stages, const CodegenOptions &opt);
+                            const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der = Derived());
 
 // Rough count of fp64 VALU instructions of one tendency evaluation in the generated code
 // (used for the roofline note in the bench output and DESIGN.md).

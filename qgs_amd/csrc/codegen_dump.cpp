@@ -1,5 +1,6 @@
 // codegen_dump -- developer tool: print the specialised kernel source for a tensor given as text
-// (lines "T i j k value" for the tendencies tensor and "J i j k value" for the Jacobian tensor).
+// (lines "T i j k value" for the tendencies tensor and "J i j k value" for the Jacobian tensor; rank-5 tensors:
+// "T5 i j k l m value" / "J5 i j k l m value").
 #include "codegen.h"
 #include <cstdio>
 #include <cstdlib>
@@ -11,9 +12,23 @@ int main(int argc, char **argv)
     std::vector<qgs::Term> T, J;
     FILE *f = std::fopen(argv[2], "r");
     if (!f) { std::perror("open"); return 1; }
-    char kind; int i, j, k; double v;
-    while (std::fscanf(f, " %c %d %d %d %la", &kind, &i, &j, &k, &v) == 5) (kind == 'T' ? T : J).push_back({i, j, k, v});
+    char kind[8]; int c[5]; double v;
+    std::vector<int32_t> coo[2];
+    std::vector<double> val[2];
+    int rank = 3;
+    while (std::fscanf(f, " %7s", kind) == 1) {
+        const int r = kind[1] == '5' ? 5 : 3;
+        rank = r;
+        for (int q = 0; q < r; ++q) if (std::fscanf(f, "%d", &c[q]) != 1) return 1;
+        if (std::fscanf(f, "%la", &v) != 1) return 1;
+        const int w = kind[0] == 'T' ? 0 : 1;
+        coo[w].insert(coo[w].end(), c, c + r);
+        val[w].push_back(v);
+    }
     std::fclose(f);
+    qgs::Derived der;
+    qgs::reduce_polynomial(ndim, rank, (int64_t)val[0].size(), coo[0].data(), val[0].data(), false, T, der.t);
+    qgs::reduce_polynomial(ndim, rank, (int64_t)val[1].size(), coo[1].data(), val[1].data(), true, J, der.j);
     qgs::CodegenOptions opt;
     std::vector<int> stages = {4};
     for (int a = 3; a < argc; ++a) {
@@ -27,8 +42,9 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "tsplit=", 7)) opt.tgl_split = std::atoi(argv[a] + 7);
         if (!std::strncmp(argv[a], "ilv=", 4)) opt.interleave = std::atoi(argv[a] + 4);
     }
-    std::fprintf(stderr, "ndim %d nnz %zu jnnz %zu tendency fp64 instr %lld\n", ndim, T.size(), J.size(),
-                 (long long)qgs::count_tendency_flops_instr(ndim, T, opt));
-    std::fputs(qgs::generate_source(ndim, T, J, stages, opt).c_str(), stdout);
+    if (rank == 5) opt.row_split = 1;
+    std::fprintf(stderr, "ndim %d rank %d terms %zu jac terms %zu derived %zu / %zu tendency fp64 instr %lld\n", ndim, rank, T.size(),
+                 J.size(), der.t.size(), der.j.size(), (long long)qgs::count_tendency_flops_instr(ndim, T, opt) + (long long)der.t.size());
+    std::fputs(qgs::generate_source(ndim, T, J, stages, opt, der).c_str(), stdout);
     return 0;
 }

@@ -16,10 +16,14 @@ namespace qgs {
 
 // Row-grouped tensor on the device: entries e in [rowptr[i], rowptr[i+1]) belong to output row i
 // (i in 0..ndim, row 0 unused).  idx packs the two remaining coordinates: (a << 16) | b.
+// Rank-5 tensors (sparse_mul5 / sparse_mul4, qgs/functions/sparse_mul.py:84-158) carry the two further coordinates
+// in idx2 = (c << 16) | d (null for rank 3): an entry then stands for val * x_a * x_b * x_c * x_d.  Only the simple
+// one-lane-per-member kernels (gen_tend / gen_jac / gen_rk / gen_tgl) read idx2.
 struct DevTensor {
     const int32_t *rowptr;   // ndim + 2
     const uint32_t *idx;     // nnz
     const double *val;       // nnz
+    const uint32_t *idx2;    // nnz or null
 };
 
 struct RkArgs {

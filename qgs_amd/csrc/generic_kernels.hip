@@ -20,7 +20,14 @@ __device__ __forceinline__ double row_dot2(const DevTensor &T, int i, const doub
         const uint32_t j = jk >> 16, k = jk & 0xffffu;
         const double xj = j ? x[(int64_t)(j - 1) * ld + m] : 1.0;
         const double xk = k ? x[(int64_t)(k - 1) * ld + m] : 1.0;
-        r = __builtin_fma(xj * xk, T.val[e], r);
+        double prod = xj * xk;
+        if (T.idx2) {                                               // rank 5 (sparse_mul.py:155-157): two more factors
+            const uint32_t cd = T.idx2[e];
+            const uint32_t c = cd >> 16, d = cd & 0xffffu;
+            if (c) prod *= x[(int64_t)(c - 1) * ld + m];
+            if (d) prod *= x[(int64_t)(d - 1) * ld + m];
+        }
+        r = __builtin_fma(prod, T.val[e], r);
     }
     return r;
 }
@@ -46,7 +53,13 @@ __global__ void __launch_bounds__(WAVE) gen_jac_kernel(DevTensor Jt, int ndim, i
             const uint32_t jk = Jt.idx[e];
             const uint32_t j = jk >> 16, k = jk & 0xffffu;
             if (j == 0) continue;                                   // column 0 is dropped (tendencies.py:121)
-            const double xk = k ? x[(int64_t)(k - 1) * ld + m] : 1.0;
+            double xk = k ? x[(int64_t)(k - 1) * ld + m] : 1.0;
+            if (Jt.idx2) {                                          // rank 5 (sparse_mul4, sparse_mul.py:117-119)
+                const uint32_t cd = Jt.idx2[e];
+                const uint32_t c = cd >> 16, d = cd & 0xffffu;
+                if (c) xk *= x[(int64_t)(c - 1) * ld + m];
+                if (d) xk *= x[(int64_t)(d - 1) * ld + m];
+            }
             double *p = jm + ((int64_t)(i - 1) * ndim + (j - 1)) * ld + m;
             *p = __builtin_fma(xk, Jt.val[e], *p);
         }
@@ -138,7 +151,13 @@ __global__ void __launch_bounds__(WAVE) gen_tgl_kernel(DevTensor Jr, RkArgs p, i
                 for (int e = Jr.rowptr[r]; e < e1; ++e) {
                     const uint32_t wx = Jr.idx[e];
                     const uint32_t wi = wx >> 16, xi = wx & 0xffffu;
-                    const double xv = xi ? x[(int64_t)(xi - 1) * ld + m] : 1.0;
+                    double xv = xi ? x[(int64_t)(xi - 1) * ld + m] : 1.0;
+                    if (Jr.idx2) {
+                        const uint32_t cd = Jr.idx2[e];
+                        const uint32_t c = cd >> 16, d = cd & 0xffffu;
+                        if (c) xv *= x[(int64_t)(c - 1) * ld + m];
+                        if (d) xv *= x[(int64_t)(d - 1) * ld + m];
+                    }
                     acc = __builtin_fma(xv * ws[(int64_t)(wi - 1) * L + l], Jr.val[e], acc);
                 }
                 kmi[(int64_t)(r - 1) * L + l] = inverse * acc;

@@ -174,11 +174,18 @@ struct HostCsr {          // row-grouped tensor on the host, see generic_kernels
     std::vector<int32_t> rowptr;
     std::vector<uint32_t> idx;
     std::vector<double> val;
+    std::vector<uint32_t> idx2;   // rank 5 only
+};
+
+// One entry of the caller's tensor, rank 3 (l = m = 0) or rank 5: coordinates (i, j, k, l, m)
+struct Entry {
+    int i, j, k, l, m;
+    double v;
 };
 
 // group entries by `row(t)`, keep the incoming (reference) order inside a row
 template <class RowFn, class IdxFn>
-HostCsr build_csr(int ndim, const std::vector<qgs::Term> &ts, RowFn row, IdxFn idx)
+HostCsr build_csr(int ndim, const std::vector<Entry> &ts, bool rank5, RowFn row, IdxFn idx)
 {
     HostCsr c;
     c.rowptr.assign(ndim + 2, 0);
@@ -186,11 +193,13 @@ HostCsr build_csr(int ndim, const std::vector<qgs::Term> &ts, RowFn row, IdxFn i
     for (int i = 0; i <= ndim; ++i) c.rowptr[i + 1] += c.rowptr[i];
     c.idx.resize(ts.size());
     c.val.resize(ts.size());
+    if (rank5) c.idx2.resize(ts.size());
     std::vector<int32_t> pos(c.rowptr.begin(), c.rowptr.end() - 1);
     for (const auto &t : ts) {
         int p = pos[row(t)]++;
         c.idx[p] = idx(t);
         c.val[p] = t.v;
+        if (rank5) c.idx2[p] = ((uint32_t)t.l << 16) | (uint32_t)t.m;
     }
     return c;
 }
@@ -199,7 +208,8 @@ struct DevCsr {
     int32_t *rowptr = nullptr;
     uint32_t *idx = nullptr;
     double *val = nullptr;
-    qgs::DevTensor view() const { return qgs::DevTensor{rowptr, idx, val}; }
+    uint32_t *idx2 = nullptr;
+    qgs::DevTensor view() const { return qgs::DevTensor{rowptr, idx, val, idx2}; }
 };
 
 struct Buffer {           // grow-only device scratch
@@ -229,8 +239,11 @@ struct KernelInfo {
 struct qgs_model {
     int device = 0;
     int ndim = 0;
+    int rank = 3;                 // 3: QgsTensor; 5: QgsTensorDynamicT / QgsTensorT4 (sparse_mul5 / sparse_mul4 path)
     std::string arch;
-    std::vector<qgs::Term> T, J;
+    std::vector<qgs::Term> T, J;  // terms of the specialised kernels; rank 5: over the derived-monomial index space (codegen.h)
+    qgs::Derived der;
+    int64_t nnz_in = 0, jnnz_in = 0;
     DevCsr dT, dJ_by_i, dJ_by_j;
     // regrouped tendencies tensor for the tiled generic stepper (generic_kernels.h TiledTensor)
     int32_t *t_row_term = nullptr;
@@ -274,6 +287,10 @@ int upload_csr(const HostCsr &h, DevCsr &d)
         HIPCHK(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
     }
+    if (!h.idx2.empty()) {
+        HIPCHK(hipMalloc((void **)&d.idx2, sizeof(uint32_t) * h.idx2.size()));
+        HIPCHK(hipMemcpy(d.idx2, h.idx2.data(), sizeof(uint32_t) * h.idx2.size(), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -287,10 +304,10 @@ int upload_vec(const std::vector<T> &h, T **d)
 
 // rows -> flat term stream (reference (j,k) order kept), each row padded to a multiple of 4 terms with
 // zero-coefficient terms that read slot 0; offsets are LDS byte offsets (generic_kernels.h TiledTensor)
-int upload_tiled(qgs_model *m, const std::vector<qgs::Term> &Tr)
+int upload_tiled(qgs_model *m, const std::vector<Entry> &Tr)
 {
     const int ndim = m->ndim;
-    std::vector<std::vector<const qgs::Term *>> by_row(ndim + 2);
+    std::vector<std::vector<const Entry *>> by_row(ndim + 2);
     for (const auto &t : Tr) by_row[t.i].push_back(&t);
     std::vector<int32_t> row_term(ndim + 2, 0);
     std::vector<uint32_t> joff, koff;
@@ -301,7 +318,7 @@ int upload_tiled(qgs_model *m, const std::vector<qgs::Term> &Tr)
     else m->t_terms_per_trip = (int)pad;
     for (int i = 0; i <= ndim; ++i) {
         row_term[i] = (int32_t)c.size();
-        for (const qgs::Term *t : by_row[i]) {
+        for (const Entry *t : by_row[i]) {
             joff.push_back((uint32_t)t->j * 512u);
             koff.push_back((uint32_t)t->k * 512u);
             c.push_back(t->v);
@@ -342,6 +359,7 @@ void free_csr(DevCsr &d)
     if (d.rowptr) (void)hipFree(d.rowptr);
     if (d.idx) (void)hipFree(d.idx);
     if (d.val) (void)hipFree(d.val);
+    if (d.idx2) (void)hipFree(d.idx2);
     d = DevCsr();
 }
 
@@ -352,7 +370,7 @@ int get_function(qgs_model *m, qgs::Kernel k, int S, hipFunction_t *fn, std::str
     if (name_out) *name_out = fname;
     auto it = m->functions.find(fname);
     if (it != m->functions.end()) { *fn = it->second; return 0; }
-    const std::string src = qgs::generate_kernel(m->ndim, m->T, m->J, k, S, m->cg);
+    const std::string src = qgs::generate_kernel(m->ndim, m->T, m->J, k, S, m->cg, m->der);
     std::vector<char> code;
     bool cached = false;
     if (compile_source(src, m->arch, code, &cached)) return -1;
@@ -451,7 +469,7 @@ bool use_spec(const qgs_model *m, int s, const double *a)
 // DESIGN.md 3.5) it beats one-member-per-lane because the lanes of the few wavefronts would do all rows serially
 bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
 {
-    if (m->kernel_kind != 0) return false;                 // explicit generic / specialised request
+    if (m->kernel_kind != 0 || m->rank != 3) return false;  // explicit generic / specialised request; rank-3 tensors only
     int64_t limit = (m->max_row_terms <= 16) ? 2048 : 256;   // measured crossovers (tools/latency_bench.py)
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
     return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
@@ -469,7 +487,7 @@ int64_t lds_tgl_min_pairs()
 // against the simple generic kernel (large ndim, latency-bound at ~350 ms per 10 steps) up to ~16k pairs
 bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
 {
-    if (m->kernel_kind != 0) return false;
+    if (m->kernel_kind != 0 || m->rank != 3) return false;
     int64_t limit = m->spec_possible ? 4096 : 16384;
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
     return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
@@ -486,7 +504,7 @@ bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work)
     if (m->functions.count(name)) return true;                                              // already loaded
     auto it = m->lds_on_disk.find(name);
     if (it == m->lds_on_disk.end())
-        it = m->lds_on_disk.emplace(name, source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, k, 0, m->cg), m->arch)).first;
+        it = m->lds_on_disk.emplace(name, source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, k, 0, m->cg, m->der), m->arch)).first;
     if (it->second) return true;                                                            // built earlier (qgs_prebuild / a previous run)
     return work >= 2e12;                                                                    // ~10 s of the generic kernels
 }
@@ -513,6 +531,7 @@ bool use_lds_tgl(const qgs_model *m, int64_t pairs, int64_t n_steps, int s, cons
 bool use_tiled(const qgs_model *m, int s, const double *a)
 {
     if (const char *e = std::getenv("QGS_HIP_GENERIC")) if (!std::strcmp(e, "simple")) return false;
+    if (m->rank != 3) return false;                                   // the tiled stream holds two factors per term
     return s >= 1 && s <= 8 && qgs::tiled_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
 
@@ -600,13 +619,44 @@ int64_t qgs_n_records(const double *time, int64_t n_time, int64_t write_steps)
     return n;
 }
 
-int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz,
-                     const int32_t *jcoo, const double *jval, qgs_model **out)
+// Reads the caller's COO arrays (rank 3 or 5) into the model: validated entries for the generic kernels and the
+// reduced term lists (+ derived monomials) the code generator works on.
+static int load_tensors(qgs_model *m, int rank, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz,
+                        const int32_t *jcoo, const double *jval, std::vector<Entry> *Tr, std::vector<Entry> *Jr)
+{
+    const int ndim = m->ndim;
+    auto read = [&](int64_t n, const int32_t *c, const double *v, std::vector<Entry> &out, bool jac) {
+        for (int64_t e = 0; e < n; ++e) {
+            const int32_t *q = c + (int64_t)rank * e;
+            for (int r = 0; r < rank; ++r) if (q[r] < 0 || q[r] > ndim) return false;
+            Entry t{q[0], q[1], q[2], rank == 5 ? q[3] : 0, rank == 5 ? q[4] : 0, v[e]};
+            // generic-kernel tensors: row 0 is the constant slot (res[0] = 1), Df drops row / column 0
+            if (t.i >= 1 && (!jac || t.j >= 1)) out.push_back(t);
+        }
+        return true;
+    };
+    std::vector<Entry> tr, jr;
+    if (!read(nnz, coo, val, tr, false)) return fail("tensor coordinate out of range");
+    if (!read(jnnz, jcoo, jval, jr, true)) return fail("jacobian coordinate out of range");
+    qgs::reduce_polynomial(ndim, rank, nnz, coo, val, false, m->T, m->der.t);
+    qgs::reduce_polynomial(ndim, rank, jnnz, jcoo, jval, true, m->J, m->der.j);
+    m->rank = rank;
+    m->nnz_in = nnz;
+    m->jnnz_in = jnnz;
+    if (Tr) Tr->swap(tr);
+    if (Jr) Jr->swap(jr);
+    return 0;
+}
+
+int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz,
+                          const int32_t *jcoo, const double *jval, qgs_model **out)
 {
     if (!out) return fail("out is null");
     *out = nullptr;
+    if (rank != 3 && rank != 5) return fail("tensor rank must be 3 or 5");
     if (ndim < 1 || ndim > 65534) return fail("ndim out of range");
     if (nnz < 0 || (nnz > 0 && (!coo || !val))) return fail("bad tensor arguments");
+    if (jnnz < 0 || (jnnz > 0 && (!jcoo || !jval))) return fail("bad jacobian tensor arguments");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail("no HIP device visible; libqgs_hip has no CPU path");
     if (device < 0 || device >= n) return fail("device index out of range");
@@ -620,20 +670,9 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             m->n_simd = 4 * prop.multiProcessorCount;
     }
-    for (int64_t e = 0; e < nnz; ++e) {
-        const int i = coo[3 * e], j = coo[3 * e + 1], k = coo[3 * e + 2];
-        if (i < 0 || j < 0 || k < 0 || i > ndim || j > ndim || k > ndim) { delete m; return fail("tensor coordinate out of range"); }
-        m->T.push_back({i, j, k, val[e]});
-    }
-    for (int64_t e = 0; e < jnnz; ++e) {
-        const int i = jcoo[3 * e], j = jcoo[3 * e + 1], k = jcoo[3 * e + 2];
-        if (i < 0 || j < 0 || k < 0 || i > ndim || j > ndim || k > ndim) { delete m; return fail("jacobian coordinate out of range"); }
-        m->J.push_back({i, j, k, jval[e]});
-    }
-    // generic-kernel tensors (row 0 entries are kept out: res[0] = 1 is the constant slot)
-    std::vector<qgs::Term> Tr, Jr;
-    for (const auto &t : m->T) if (t.i >= 1) Tr.push_back(t);
-    for (const auto &t : m->J) if (t.i >= 1 && t.j >= 1) Jr.push_back(t);
+    std::vector<Entry> Tr, Jr;
+    if (load_tensors(m, rank, nnz, coo, val, jnnz, jcoo, jval, &Tr, &Jr)) { delete m; return -1; }
+    const bool r5 = rank == 5;
     auto pack = [](int a, int b) { return ((uint32_t)a << 16) | (uint32_t)b; };
     {
         std::vector<int> cnt(ndim + 2, 0);
@@ -643,16 +682,25 @@ int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, cons
         std::vector<int> ci(ndim + 2, 0), cj(ndim + 2, 0);
         for (const auto &t : Jr) m->max_jrow_terms = std::max(m->max_jrow_terms, std::max(++ci[t.i], ++cj[t.j]));
     }
-    HostCsr hT = build_csr(ndim, Tr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
+    HostCsr hT = build_csr(ndim, Tr, r5, [](const Entry &t) { return t.i; }, [&](const Entry &t) { return pack(t.j, t.k); });
     // Jacobian kernel wants (j,k) per row i; tangent model wants (w=j, x=k) per row i; adjoint (w=i, x=k) per row j
-    HostCsr hJi = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.i; }, [&](const qgs::Term &t) { return pack(t.j, t.k); });
-    HostCsr hJj = build_csr(ndim, Jr, [](const qgs::Term &t) { return t.j; }, [&](const qgs::Term &t) { return pack(t.i, t.k); });
-    if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j) || upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
-    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM);
-    m->lds_spec_possible = !m->spec_possible && (size_t)ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
+    HostCsr hJi = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.i; }, [&](const Entry &t) { return pack(t.j, t.k); });
+    HostCsr hJj = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.j; }, [&](const Entry &t) { return pack(t.i, t.k); });
+    if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
+    if (!r5 && upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
+    // register-resident specialised kernels: the state and (rank 5) the derived monomials of a stage must fit the file
+    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM) && m->der.t.size() <= 256 && m->der.j.size() <= 256;
+    m->lds_spec_possible = !r5 && !m->spec_possible && (size_t)ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
     apply_env_options(m->cg);
+    if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
     *out = m;
     return 0;
+}
+
+int qgs_model_create(int device, int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz,
+                     const int32_t *jcoo, const double *jval, qgs_model **out)
+{
+    return qgs_model_create_rank(device, ndim, 3, nnz, coo, val, jnnz, jcoo, jval, out);
 }
 
 int qgs_model_destroy(qgs_model *m)
@@ -675,10 +723,13 @@ int64_t qgs_model_info(const qgs_model *m, int which)
     if (!m) return -1;
     switch (which) {
     case 0: return m->ndim;
-    case 1: return (int64_t)m->T.size();
-    case 2: return (int64_t)m->J.size();
+    case 1: return m->nnz_in;
+    case 2: return m->jnnz_in;
     case 3: return m->device;
     case 4: return (m->spec_possible || m->lds_spec_possible) ? 1 : 0;
+    case 5: return m->rank;
+    case 6: return (int64_t)m->der.t.size();
+    case 7: return (int64_t)m->der.j.size();
     default: return -1;
     }
 }
@@ -708,7 +759,7 @@ int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen)
 {
     if (!m) return -1;
     std::string src = m->source_all;
-    if (src.empty() && m->spec_possible) src = qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::Tend, 0, m->cg);
+    if (src.empty() && m->spec_possible) src = qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::Tend, 0, m->cg, m->der);
     if (buf && buflen > 0) {
         const size_t n = std::min<size_t>(src.size(), (size_t)buflen - 1);
         std::memcpy(buf, src.data(), n);
@@ -1114,18 +1165,19 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
 
 // Compile (and cache) the specialised kernels of a model without touching a device: used by
 // __graft_entry__.build() on the GPU-less build host so that the code objects travel with the tree.
-int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
-                 const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
+int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
+                      const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
 {
+    if (rank != 3 && rank != 5) return fail("tensor rank must be 3 or 5");
     qgs_model m;
     m.ndim = ndim;
     m.arch = (arch && *arch) ? arch : target_arch(-1);
-    for (int64_t e = 0; e < nnz; ++e) m.T.push_back({coo[3 * e], coo[3 * e + 1], coo[3 * e + 2], val[e]});
-    for (int64_t e = 0; e < jnnz; ++e) m.J.push_back({jcoo[3 * e], jcoo[3 * e + 1], jcoo[3 * e + 2], jval[e]});
+    if (load_tensors(&m, rank, nnz, coo, val, jnnz, jcoo, jval, nullptr, nullptr)) return -1;
     apply_env_options(m.cg);
+    if (rank == 5) m.cg.row_split = 1;
     std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
     if (ndim > QGS_SPEC_MAX_NDIM) {
-        if ((size_t)ndim * 512 > (size_t)QGS_LDS_STATE_BYTES || m.T.size() > 200000) return 0;
+        if (rank != 3 || (size_t)ndim * 512 > (size_t)QGS_LDS_STATE_BYTES || m.T.size() > 200000) return 0;
         std::vector<char> code;
         bool cached;
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg), m.arch, code, &cached)) return -1;
@@ -1134,12 +1186,19 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, i
                 if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg), m.arch, code, &cached)) return -1;
         return 0;
     }
+    if (m.der.t.size() > 256 || m.der.j.size() > 256) return 0;
     for (auto &ks : qgs::kernel_list(m.ndim, !m.J.empty(), stages, m.cg)) {
         std::vector<char> code;
         bool cached;
-        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg), m.arch, code, &cached)) return -1;
+        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
     return 0;
+}
+
+int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
+                 const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
+{
+    return qgs_prebuild_rank(ndim, 3, nnz, coo, val, jnnz, jcoo, jval, n_stage_counts, stage_counts, arch);
 }
 
 }  // extern "C"

@@ -20,6 +20,10 @@ Configs
     t228  : model_test/test_aotensor_6x6.py:42-47 parameters (MAOOAM 6x6/6x6, ndim 228)
     g30   : 2x2 atmosphere + ground temperature on the atmospheric modes (ndim 30), parameters in the
             style of notebooks/ground_heat.ipynb
+    d38   : notebooks/maooam_dynamic_temperature.ipynb parameters (MAOOAM 2x2/2x4 with dynamic reference
+            temperatures, ndim 38, RANK-5 tensor: sparse_mul5 / sparse_mul4 path); the reference computes the
+            inner products of this model by numerical quadrature (symbolic mode), ~1 min
+    q38   : notebooks/maooam_T4.ipynb parameters (same modes, full T^4 radiative terms, ndim 38, rank-5 tensor)
 """
 import gzip
 import json
@@ -95,12 +99,40 @@ def params_g30():
     return p
 
 
+def _params_notebook_T(**flags):
+    p = QgParams({'n': 1.5}, **flags)
+    p.set_atmospheric_channel_fourier_modes(2, 2, mode="symbolic")
+    p.set_oceanic_basin_fourier_modes(2, 4, mode="symbolic")
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'hlambda': 15.06})
+    p.gotemperature_params.set_params({'gamma': 5.6e8})
+    p.atemperature_params.set_insolation(103., 0)
+    p.atemperature_params.set_insolation(103., 1)
+    p.gotemperature_params.set_insolation(310., 0)
+    p.gotemperature_params.set_insolation(310., 1)
+    return p
+
+
+def params_d38():
+    return _params_notebook_T(dynamic_T=True)
+
+
+def params_q38():
+    return _params_notebook_T(T4=True)
+
+
+# reference temperatures of the dynamic-T / T4 models sit at O(1) non-dimensional values (the notebooks set
+# ic[10] = 1.5, ic[29] = 3.): without them the quartic terms are numerically invisible
+T_REF_IC = {10: 1.5, 29: 3.}
+
 CONFIGS = {
     'rp20': dict(make=params_rp20, ic_scale=0.1, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     'a36': dict(make=params_a36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     'm36': dict(make=params_m36, ic_scale=0.01, n_x=64, n_jac=64, long_steps=(100, 1000), n_traj=8),
     't228': dict(make=params_t228, ic_scale=0.01, n_x=8, n_jac=2, long_steps=(10,), n_traj=2),
     'g30': dict(make=params_g30, ic_scale=0.01, n_x=16, n_jac=8, long_steps=(100,), n_traj=4),
+    'd38': dict(make=params_d38, ic_scale=0.01, n_x=16, n_jac=8, long_steps=(100,), n_traj=4, ic_fix=T_REF_IC),
+    'q38': dict(make=params_q38, ic_scale=0.01, n_x=8, n_jac=4, long_steps=(100,), n_traj=4, ic_fix=T_REF_IC),
 }
 
 RK4 = dict(c=np.array([0., 0.5, 0.5, 1.]), b=np.array([1. / 6, 1. / 3, 1. / 3, 1. / 6]),
@@ -150,12 +182,12 @@ def derived_params(p):
 def inner_products(aip, oip):
     out = {}
     if aip is not None:
-        for nm in ('a', 'u', 'c', 'b', 'g', 's', 'd'):
+        for nm in ('a', 'u', 'c', 'b', 'g', 's', 'd', 'z', 'v'):
             t = getattr(aip, '_' + nm, None)
             if t is not None:
                 out['aip_' + nm] = t.todense()
     if oip is not None:
-        for nm in ('M', 'U', 'N', 'O', 'C', 'K', 'W'):
+        for nm in ('M', 'U', 'N', 'O', 'C', 'K', 'W', 'Z', 'V'):
             t = getattr(oip, '_' + nm, None)
             if t is not None:
                 out['oip_' + nm] = t.todense()
@@ -189,6 +221,8 @@ def gen(name):
     # (ii) f(x), Df(x) on seeded states
     scale = cfg['ic_scale']
     X = np.stack([np.random.RandomState(s).rand(ndim) * scale for s in range(cfg['n_x'])])
+    for k, v in cfg.get('ic_fix', {}).items():
+        X[:, k] += v
     out['fx_x'] = X
     out['fx_f'] = np.stack([f(0., x) for x in X])
     out['fx_Df'] = np.stack([Df(0., x) for x in X[:cfg['n_jac']]])
@@ -197,6 +231,8 @@ def gen(name):
     n_traj = cfg['n_traj']
     rng = np.random.RandomState(21217)
     ic = rng.rand(n_traj, ndim) * scale
+    for k, v in cfg.get('ic_fix', {}).items():
+        ic[:, k] += v
     out['rk_ic'] = ic
     dt = 0.1
     meta = {'rk_cases': [], 'tgls_cases': [], 'api_cases': []}

@@ -42,7 +42,7 @@ def test_backend_is_gfx950():
     assert n >= 1 and arch.startswith('gfx950'), arch
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
 def test_f_and_Df_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):
@@ -55,7 +55,7 @@ def test_f_and_Df_vs_golden(models, name):
         assert m.jacobian(g['fx_x'][0]).shape == (g.ndim, g.ndim)
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
 def test_rk_cases_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):
@@ -69,7 +69,7 @@ def test_rk_cases_vs_golden(models, name):
             assert rel_err(rec, g['rk_%s_traj' % t]) < tol, (kind, t)
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
 def test_tgls_cases_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from conftest import rel_err
-from oracle.oracle import OracleModel, sparse_mul2, sparse_mul3
+from oracle.oracle import OracleModel, sparse_mul2, sparse_mul3, sparse_mul4, sparse_mul5
 
 
 def _model(g):
@@ -34,6 +34,21 @@ def test_sparse_mul_direct(golden_small):
     assert np.array_equal(r3[1:], g['fx_f'][0])
     r2 = sparse_mul2(g['jcoo'], g['jval'], x)
     assert np.array_equal(r2[1:, 1:], g['fx_Df'][0])
+
+
+def test_sparse_mul_rank5_direct():
+    """sparse_mul5 / sparse_mul4 (sparse_mul.py:84-158) on the dynamic-T tensor, as the rank-5 closures call them
+    (tendencies.py:98-109)."""
+    from conftest import load_golden
+    g = load_golden('d38')
+    assert g['coo'].shape[1] == 5 and g['jcoo'].shape[1] == 5
+    for n in range(3):
+        x = np.concatenate(([1.], g['fx_x'][n]))
+        r5 = sparse_mul5(g['coo'], g['val'], x, x, x, x)
+        assert r5[0] == 1.0                                      # sparse_mul.py:157
+        assert np.array_equal(r5[1:], g['fx_f'][n])
+        r4 = sparse_mul4(g['jcoo'], g['jval'], x, x, x)
+        assert np.array_equal(r4[1:, 1:], g['fx_Df'][n])
 
 
 def test_known_answers_survey():
