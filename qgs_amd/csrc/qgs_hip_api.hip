@@ -33,6 +33,9 @@
 #ifndef QGS_SPEC_MAX_NDIM
 #define QGS_SPEC_MAX_NDIM 64      // register-resident specialised kernels up to this many variables
 #endif
+#ifndef QGS_SPEC_MAX_DERIVED
+#define QGS_SPEC_MAX_DERIVED 256  // ... and (rank-5 tensors) this many derived monomials per tendency evaluation
+#endif
 
 namespace {
 
@@ -260,6 +263,7 @@ struct qgs_model {
     int kernel_kind = 0;          // 0 auto, 1 generic, 2 specialised
     int n_simd = 1024;            // SIMDs on the device (CUs x 4)
     bool spec_possible = false;
+    bool spec_jac_possible = false;   // ... and the Jacobian / tangent kernels too (rank 5: their derived monomials fit as well)
     bool lds_spec_possible = false;   // too large for the register file, stage state fits LDS: JIT LDS-resident stepper
     mutable std::map<std::string, bool> lds_on_disk;   // kernel name -> code object found in the kernel cache (checked once)
     qgs::CodegenOptions cg;
@@ -689,7 +693,8 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
     if (!r5 && upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
     // register-resident specialised kernels: the state and (rank 5) the derived monomials of a stage must fit the file
-    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM) && m->der.t.size() <= 256 && m->der.j.size() <= 256;
+    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM) && m->der.t.size() <= QGS_SPEC_MAX_DERIVED;
+    m->spec_jac_possible = m->spec_possible && m->der.j.size() <= QGS_SPEC_MAX_DERIVED;
     m->lds_spec_possible = !r5 && !m->spec_possible && (size_t)ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
     apply_env_options(m->cg);
     if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
@@ -833,7 +838,7 @@ static int jacobian_device(qgs_model *m, int64_t n_traj, int64_t ld, const doubl
 {
     if (m->J.empty()) return fail("model was created without a Jacobian tensor");
     HIPCHK(hipMemsetAsync(d_jm, 0, sizeof(double) * (size_t)m->ndim * m->ndim * ld, st));
-    if (use_spec(m, 1, nullptr)) {
+    if (use_spec(m, 1, nullptr) && m->spec_jac_possible) {
         hipFunction_t f;
         if (get_function(m, qgs::Kernel::Jac, 0, &f)) return -1;
         long long nt = n_traj, l = ld;
@@ -944,7 +949,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
     if (m->stages.ensure(stage_bytes_per_step * (size_t)chunk)) return -1;
     if (m->b_state2.ensure(sizeof(double) * (size_t)A)) return -1;
     if (m->b_tg2.ensure(sizeof(double) * (size_t)m->ndim * L)) return -1;
-    if (!spec) {
+    if (!spec || !m->spec_jac_possible) {
         if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * std::max<int64_t>(ld, L))) return -1;
     }
     double *y_state = m->b_state2.f64();
@@ -989,7 +994,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
                                             d_tab_spec, st));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
-        } else if (spec) {
+        } else if (spec && m->spec_jac_possible) {
             // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
             bool tgl_split = m->cg.tgl_split > 1 && m->ndim >= 2 * m->cg.tgl_split;
             if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
@@ -1186,8 +1191,12 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
                 if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg), m.arch, code, &cached)) return -1;
         return 0;
     }
-    if (m.der.t.size() > 256 || m.der.j.size() > 256) return 0;
-    for (auto &ks : qgs::kernel_list(m.ndim, !m.J.empty(), stages, m.cg)) {
+    if (m.der.t.size() > QGS_SPEC_MAX_DERIVED) return 0;
+    const bool jac_spec = !m.J.empty() && m.der.j.size() <= QGS_SPEC_MAX_DERIVED;
+    auto list = qgs::kernel_list(m.ndim, jac_spec, stages, m.cg);
+    if (!m.J.empty() && !jac_spec)                       // the trajectory pass of the tangent model is still specialised
+        for (int S : stages) list.push_back({qgs::Kernel::RkStages, S});
+    for (auto &ks : list) {
         std::vector<char> code;
         bool cached;
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;

@@ -83,19 +83,26 @@ def tendencies_from_tensor(ndim, coo, val, jcoo=None, jval=None, device=0):
 def create_tendencies(params, return_inner_products=False, return_qgtensor=False):
     """Build inner products -> tendencies tensor -> `[f, Df, (aip, oip, gip)?, qgtensor?]`.
 
-    Mirrors qgs/functions/tendencies.py:20-130 for models with analytic inner products and the stored
-    (non dynamic-T, non T4) tensor.  Returns a **list**, like the reference.
+    Mirrors qgs/functions/tendencies.py:20-130: analytic inner products for models configured from spectral
+    blocks, quadrature ("symbolic"-mode) ones for models configured from bases; `QgsTensor`, or the rank-5
+    `QgsTensorDynamicT` / `QgsTensorT4` whose closures the reference evaluates with sparse_mul5 / sparse_mul4
+    (tendencies.py:98-109) -- here the same `f` / `Df` objects on a rank-5 device model.  Returns a **list**, like
+    the reference.
     """
     from qgs_amd.inner_products.analytic import (AtmosphericAnalyticInnerProducts, OceanicAnalyticInnerProducts,
                                                    GroundAnalyticInnerProducts)
-    from qgs_amd.tensors.qgtensor import QgsTensor
+    from qgs_amd.inner_products.symbolic import (AtmosphericSymbolicInnerProducts, OceanicSymbolicInnerProducts,
+                                                   GroundSymbolicInnerProducts)
+    from qgs_amd.tensors.qgtensor import QgsTensor, QgsTensorDynamicT, QgsTensorT4
 
-    if getattr(params, 'T4', False) or getattr(params, 'dynamic_T', False):
-        raise NotImplementedError('T4 / dynamic_T (rank-5 tensor) models are outside the scope of this build')
+    def pick(blocks, basis, analytic, symbolic):
+        if blocks is not None:
+            return analytic(params)
+        return symbolic(params) if basis is not None else None
 
-    aip = AtmosphericAnalyticInnerProducts(params) if params.ablocks is not None else None
-    oip = OceanicAnalyticInnerProducts(params) if params.oblocks is not None else None
-    gip = GroundAnalyticInnerProducts(params) if params.gblocks is not None else None
+    aip = pick(params.ablocks, params.atmospheric_basis, AtmosphericAnalyticInnerProducts, AtmosphericSymbolicInnerProducts)
+    oip = pick(params.oblocks, params.oceanic_basis, OceanicAnalyticInnerProducts, OceanicSymbolicInnerProducts)
+    gip = pick(params.gblocks, params.ground_basis, GroundAnalyticInnerProducts, GroundSymbolicInnerProducts)
     if aip is not None and oip is not None:
         if not aip.connected_to_ocean:
             aip.connect_to_ocean(oip)
@@ -103,7 +110,12 @@ def create_tendencies(params, return_inner_products=False, return_qgtensor=False
         if not aip.connected_to_ground:
             aip.connect_to_ground(gip)
 
-    agotensor = QgsTensor(params, aip, oip, gip)
+    if params.T4:
+        agotensor = QgsTensorT4(params, aip, oip, gip)
+    elif params.dynamic_T:
+        agotensor = QgsTensorDynamicT(params, aip, oip, gip)
+    else:
+        agotensor = QgsTensor(params, aip, oip, gip)
     ops = TensorOperands(params.ndim, agotensor.tensor.coords.T, agotensor.tensor.data,
                          agotensor.jacobian_tensor.coords.T, agotensor.jacobian_tensor.data)
     ret = [TendenciesFunction(ops), JacobianFunction(ops)]

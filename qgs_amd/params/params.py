@@ -296,8 +296,6 @@ class QgParams(Params):
                  oceanic_params=None, otemperature_params=None, ground_params=True, gtemperature_params=None,
                  dynamic_T=False, T4=False):
         Params.__init__(self, dic)
-        if dynamic_T or T4:
-            raise NotImplementedError('dynamic_T / T4 temperature schemes (rank-5 tensor) are outside the scope of this build')
         self.scale_params = ScaleParams(dic) if scale_params is None else scale_params
         sp = self.scale_params
         self.atmospheric_params = AtmosphericParams(sp, dic=dic) if atmospheric_params is True else atmospheric_params
@@ -319,8 +317,10 @@ class QgParams(Params):
         self._ams = None
         self._oms = None
         self._gms = None
-        self.dynamic_T = False
-        self.T4 = False
+        # dynamic reference temperatures (a 0-th, constant mode in the temperature fields) and the full T^4 radiative
+        # terms: both lead to the rank-5 tensor; T4 forces dynamic_T (params.py:919-923)
+        self.dynamic_T = bool(dynamic_T) or bool(T4)
+        self.T4 = bool(T4)
         self._atmospheric_var_string = list()
         self._oceanic_var_string = list()
         self._ground_var_string = list()
@@ -387,6 +387,8 @@ class QgParams(Params):
 
     @property
     def sbpgo(self):
+        if self.dynamic_T:
+            return None
         gotp, scp = self.gotemperature_params, self.scale_params
         if gotp is None:
             return None
@@ -394,6 +396,8 @@ class QgParams(Params):
 
     @property
     def sbpa(self):
+        if self.dynamic_T:
+            return None
         atp, gotp, scp = self.atemperature_params, self.gotemperature_params, self.scale_params
         if gotp is None or atp is None:
             return None
@@ -401,6 +405,8 @@ class QgParams(Params):
 
     @property
     def LSBpgo(self):
+        if self.dynamic_T:
+            return None
         atp, gotp, scp = self.atemperature_params, self.gotemperature_params, self.scale_params
         if gotp is None or atp is None:
             return None
@@ -408,10 +414,47 @@ class QgParams(Params):
 
     @property
     def LSBpa(self):
+        if self.dynamic_T:
+            return None
         atp, scp = self.atemperature_params, self.scale_params
         if atp is None:
             return None
         return self._try(lambda: 8 * float(atp.eps) * float(self.sb) * float(atp.T0) ** 3 / (float(atp.gamma) * float(scp.f0)))
+
+    # T^4 / dynamic-T radiative coefficients (params.py:1078-1129)
+    def _t4_coefficient(self, factor, gamma):
+        scp = self.scale_params
+        return self._try(lambda: factor * float(self.sb) * float(scp.L) ** 6 * float(scp.f0) ** 5
+                         / (float(gamma()) * float(self.rr) ** 3))
+
+    @property
+    def T4sbpgo(self):
+        gotp = self.gotemperature_params
+        return None if gotp is None else self._t4_coefficient(1., lambda: gotp.gamma)
+
+    @property
+    def T4sbpa(self):
+        atp, gotp = self.atemperature_params, self.gotemperature_params
+        if gotp is None or atp is None:
+            return None
+        return self._try(lambda: 16 * float(atp.eps) * float(self.sb) * float(self.scale_params.L) ** 6
+                         * float(self.scale_params.f0) ** 5 / (float(gotp.gamma) * float(self.rr) ** 3))
+
+    @property
+    def T4LSBpgo(self):
+        atp = self.atemperature_params
+        if atp is None:
+            return None
+        return self._try(lambda: 0.5 * float(atp.eps) * float(self.sb) * float(self.scale_params.L) ** 6
+                         * float(self.scale_params.f0) ** 5 / (float(atp.gamma) * float(self.rr) ** 3))
+
+    @property
+    def T4LSBpa(self):
+        atp = self.atemperature_params
+        if atp is None:
+            return None
+        return self._try(lambda: 16 * float(atp.eps) * float(self.sb) * float(self.scale_params.L) ** 6
+                         * float(self.scale_params.f0) ** 5 / (float(atp.gamma) * float(self.rr) ** 3))
 
     @property
     def streamfunction_scaling(self):
@@ -464,11 +507,13 @@ class QgParams(Params):
     @property
     def variables_range(self):
         natm, ngoc = self.nmod
-        vr = [natm, 2 * natm]
+        extra = 1 if self.dynamic_T else 0            # the 0-th temperature modes (params.py:1268-1275)
+        vr = [natm, 2 * natm + extra]
         if ngoc > 0:
             vr.append(vr[-1] + ngoc)
             if self._oceanic_basis is not None:
                 vr.append(vr[-1] + ngoc)
+            vr[-1] += extra
         return vr
 
     @property
@@ -485,12 +530,126 @@ class QgParams(Params):
         return list(self._atmospheric_var_string + self._oceanic_var_string + self._ground_var_string)
 
     # ---- bases ---------------------------------------------------------------------------------------------
-    atmospheric_basis = property(lambda self: self._atmospheric_basis)
-    oceanic_basis = property(lambda self: self._oceanic_basis)
-    ground_basis = property(lambda self: self._ground_basis)
+    # `mode='symbolic'`: the model is configured from basis objects instead of spectral blocks; the spectral-block
+    # tables stay None, which is what selects the quadrature inner products in create_tendencies
+    # (tendencies.py:57-76).  Required for dynamic_T / T4 (the constant mode has no closed-form inner products).
+    @property
+    def atmospheric_basis(self):
+        return self._atmospheric_basis
+
+    @atmospheric_basis.setter
+    def atmospheric_basis(self, basis):
+        """params.py:1383-1399"""
+        self._ams = self._oms = self._gms = None
+        self._atmospheric_basis = basis
+        self._number_of_atmospheric_modes = len(basis)
+        if self.ground_params is not None and self.ground_params.orographic_basis == "atmospheric":
+            self.ground_params.set_orography(self._number_of_atmospheric_modes * [0.e0])
+        if self.atemperature_params is not None:
+            self.atemperature_params.set_thetas(self._number_of_atmospheric_modes * [0.e0])
+
+    @property
+    def oceanic_basis(self):
+        return self._oceanic_basis
+
+    @oceanic_basis.setter
+    def oceanic_basis(self, basis):
+        """params.py:1406-1460"""
+        self._ams = self._oms = self._gms = None
+        self._oceanic_basis = basis
+        self._number_of_ground_modes = 0
+        self._number_of_oceanic_modes = len(basis)
+        self._heat_exchange_defaults()
+        self._surface_insolation_defaults()
+        if self.gotemperature_params is not None and self.ground_params is not None:
+            self.ground_params.hk = None
+
+    @property
+    def ground_basis(self):
+        return self._ground_basis
+
+    @ground_basis.setter
+    def ground_basis(self, basis):
+        """params.py:1467-1527"""
+        self._ams = self._oms = self._gms = None
+        self._ground_basis = basis
+        self._number_of_ground_modes = len(basis)
+        self._number_of_oceanic_modes = 0
+        self._heat_exchange_defaults()
+        if self.gotemperature_params is not None:
+            gp = self.ground_params
+            if gp is not None and gp.hk is None:
+                n = self._number_of_atmospheric_modes if gp.orographic_basis == 'atmospheric' else self._number_of_ground_modes
+                gp.set_orography(n * [0.e0], basis=gp.orographic_basis)
+                gp.set_orography(0.1, 1, basis=gp.orographic_basis)
+        self._surface_insolation_defaults()
+
+    def _surface_insolation_defaults(self):
+        gotp = self.gotemperature_params
+        if gotp is None:
+            return
+        if self.dynamic_T:
+            gotp.set_insolation((self.nmod[0] + 1) * [0.e0], None, True)
+            gotp.set_insolation(350.0, 0, True)
+            gotp.set_insolation(350.0, 1, True)
+        else:
+            gotp.set_insolation(self.nmod[0] * [0.e0])
+            gotp.set_insolation(350.0, 0)
+            gotp.T0 = Parameter(285.0, units='[K]', scale_object=self.scale_params, return_dimensional=True,
+                                description="stationary solution for the 0-th order oceanic temperature")
+
+    def set_atmospheric_modes(self, basis, auto=False):
+        """Configure the atmosphere from a basis object (params.py:1529-1568)."""
+        if auto:
+            if self.atemperature_params is None:
+                self.atemperature_params = AtmosphericTemperatureParams(self.scale_params)
+            if self.atmospheric_params is None:
+                self.atmospheric_params = AtmosphericParams(self.scale_params)
+        self.atmospheric_basis = basis
+        n = self.nmod[0]
+        self._atmospheric_var_string = (['psi_a_%d' % (i + 1) for i in range(n)] + (['T_a_0'] if self.dynamic_T else [])
+                                        + ['theta_a_%d' % (i + 1) for i in range(n)])
+
+    def set_oceanic_modes(self, basis, auto=True):
+        """Configure the ocean from a basis object (params.py:1570-1627)."""
+        if self._atmospheric_basis is None:
+            print('Atmosphere modes not set up. Add an atmosphere before adding an ocean!')
+            print('Oceanic setup aborted.')
+            return
+        if auto:
+            if self.gotemperature_params is None or isinstance(self.gotemperature_params, GroundTemperatureParams):
+                self.gotemperature_params = OceanicTemperatureParams(self.scale_params)
+            if self.oceanic_params is None:
+                self.oceanic_params = OceanicParams(self.scale_params)
+            self.ground_params = None
+            self._ground_basis = None
+        self.oceanic_basis = basis
+        n = self.nmod[1]
+        self._oceanic_var_string = (['psi_o_%d' % (i + 1) for i in range(n)] + (['T_o_0'] if self.dynamic_T else [])
+                                    + ['delta_T_o_%d' % (i + 1) for i in range(n)])
+        self._ground_var_string = list()
+
+    def set_ground_modes(self, basis=None, auto=True):
+        """Configure the ground from a basis object, default: the atmospheric one (params.py:1629-1681)."""
+        if self._atmospheric_basis is None:
+            print('Atmosphere modes not set up. Add an atmosphere before adding the ground!')
+            print('Ground setup aborted.')
+            return
+        if auto:
+            if self.gotemperature_params is None or isinstance(self.gotemperature_params, OceanicTemperatureParams):
+                self.gotemperature_params = GroundTemperatureParams(self.scale_params)
+            if self.ground_params is None:
+                self.ground_params = GroundParams(self.scale_params)
+            self.oceanic_params = None
+            self._oceanic_basis = None
+        self.ground_basis = basis if basis is not None else self._atmospheric_basis
+        self._oceanic_var_string = ['T_g_0'] if self.dynamic_T else []       # sic: the reference files it with the oceanic names
+        self._ground_var_string = ['delta_T_g_%d' % (i + 1) for i in range(self.nmod[1])]
 
     def set_atmospheric_channel_fourier_modes(self, nxmax, nymax, auto=False, mode='analytic'):
         """Fourier modes of the channel atmosphere up to wavenumbers (nxmax, nymax) (params.py:1688-1725)."""
+        if mode == 'symbolic':
+            return self.set_atmospheric_modes(ChannelFourierBasis(_spectral_blocks(nxmax, nymax), self.scale_params.n), auto)
         self._require_analytic(mode)
         if auto:
             if self.atemperature_params is None:
@@ -504,6 +663,8 @@ class QgParams(Params):
     def set_oceanic_basin_fourier_modes(self, nxmax, nymax, auto=True, mode='analytic'):
         """Fourier modes of the closed-basin ocean (params.py:1727-1768); `auto` creates the ocean blocks and
         removes the ground block."""
+        if mode == 'symbolic':
+            return self.set_oceanic_modes(BasinFourierBasis(_spectral_blocks(nxmax, nymax), self.scale_params.n), auto)
         self._require_analytic(mode)
         if self._ams is None:
             print('Atmosphere modes not set up. Add an atmosphere before adding an ocean!')
@@ -522,6 +683,11 @@ class QgParams(Params):
 
     def set_ground_channel_fourier_modes(self, nxmax=None, nymax=None, auto=True, mode='analytic'):
         """Fourier modes of the ground temperature field (default: the atmospheric ones) (params.py:1770-1819)."""
+        if mode == 'symbolic':
+            basis = None
+            if nxmax is not None and nymax is not None:
+                basis = ChannelFourierBasis(_spectral_blocks(nxmax, nymax), self.scale_params.n)
+            return self.set_ground_modes(basis, auto)
         self._require_analytic(mode)
         if self._ams is None:
             print('Atmosphere modes not set up. Add an atmosphere before adding the ground!')
@@ -538,10 +704,12 @@ class QgParams(Params):
         self._oceanic_var_string = list()
         self._ground_var_string = ['delta_T_g_%d' % (i + 1) for i in range(self.nmod[1])]
 
-    @staticmethod
-    def _require_analytic(mode):
+    def _require_analytic(self, mode):
         if mode != 'analytic':
-            raise NotImplementedError("only mode='analytic' (closed-form inner products) is in scope")
+            raise ValueError("mode must be 'analytic' or 'symbolic'")
+        if self.dynamic_T:
+            raise ValueError("dynamic_T / T4 models need mode='symbolic': the constant temperature mode has no "
+                             "closed-form inner products (see notebooks/maooam_dynamic_temperature.ipynb)")
 
     @staticmethod
     def _count_channel_modes(blocks):
@@ -558,11 +726,16 @@ class QgParams(Params):
         atp.hd = None
         atp.gamma = Parameter(1.e7, units='[J][m^-2][K^-1]', scale_object=sp, return_dimensional=True,
                               description='specific heat capacity of the atmosphere')
-        atp.set_insolation(self.nmod[0] * [0.e0])
-        atp.set_insolation(100.0, 0)
+        if self.dynamic_T:
+            atp.set_insolation((self.nmod[0] + 1) * [0.e0], None, True)
+            atp.set_insolation(100.0, 0, True)
+            atp.set_insolation(100.0, 1, True)
+        else:
+            atp.set_insolation(self.nmod[0] * [0.e0])
+            atp.set_insolation(100.0, 0)
+            atp.T0 = Parameter(270.0, units='[K]', scale_object=sp, return_dimensional=True,
+                               description="stationary solution for the 0-th order atmospheric temperature")
         atp.eps = Parameter(0.76e0, input_dimensional=False, description="emissivity coefficient for the grey-body atmosphere")
-        atp.T0 = Parameter(270.0, units='[K]', scale_object=sp, return_dimensional=True,
-                           description="stationary solution for the 0-th order atmospheric temperature")
         atp.sc = Parameter(1., input_dimensional=False, description="ratio of surface to atmosphere temperature")
         atp.hlambda = Parameter(20.00, units='[W][m^-2][K^-1]', scale_object=sp, return_dimensional=True,
                                 description="sensible+turbulent heat exchange between ocean/ground and atmosphere")

@@ -32,6 +32,24 @@ class CooTensor(object):
     nnz = property(lambda self: int(self.data.shape[0]))
     ndim = property(lambda self: len(self.shape))
 
+    @classmethod
+    def from_coords(cls, coords, data, shape):
+        """From a (rank, n) coordinate list with duplicates: entries are summed, zeros dropped, order lexicographic
+        (what the pydata/sparse COO constructor does for the reference, qgtensor.py:693)."""
+        coords = np.asarray(coords, dtype=np.int64).reshape(len(shape), -1)
+        data = np.asarray(data, dtype=np.float64)
+        lin = np.ravel_multi_index(tuple(coords), shape)
+        order = np.argsort(lin, kind='stable')
+        lin, data = lin[order], data[order]
+        uniq, start = np.unique(lin, return_index=True)
+        summed = np.add.reduceat(data, start) if len(data) else data
+        keep = summed != 0.
+        out = cls.__new__(cls)
+        out.shape = tuple(shape)
+        out.coords = np.array(np.unravel_index(uniq[keep], shape))
+        out.data = summed[keep]
+        return out
+
     def todense(self):
         out = np.zeros(self.shape)
         out[tuple(self.coords)] = self.data
@@ -91,6 +109,9 @@ class QgsTensor(object):
         return out
 
     def _assemble_dense(self):
+        """Rank-3 part of the tensor, dense.  With dynamic reference temperatures (`offset` = 1) the temperature fields
+        carry a 0-th (constant) mode: their inner products arrays are one larger than the streamfunction ones, and the
+        streamfunction equations skip index 0 (qgtensor.py:175-178: `jo = j + offset`)."""
         par = self.params
         aips = self.atmospheric_inner_products
         ocean = self.oceanic_inner_products is not None
@@ -101,122 +122,130 @@ class QgsTensor(object):
         nvar = par.number_of_variables
         ndim = par.ndim
         natm = nvar[0]
+        o = 1 if par.dynamic_T else 0
         T = np.zeros((ndim + 1, ndim + 1, ndim + 1))
 
         psi = np.arange(natm) + 1                                   # tensor index of psi_a,j
-        theta = np.arange(natm) + par.variables_range[0] + 1        # theta_a,j
+        theta_all = np.arange(nvar[1]) + par.variables_range[0] + 1  # theta_a,j (j = 0: T_a,0 with dynamic_T)
+        theta = theta_all[o:]                                       # ... the ones paired with psi_a,j
         kd, kdp, sig0, beta = float(ap.kd), float(ap.kdp), float(ap.sig0), float(scp.beta)
 
-        a, u, c, b, g = aips._a, aips._u, aips._c, aips._b, aips._g
-        a_inv = np.linalg.inv(a)
+        a, u, c, b, g = (np.asarray(t) for t in (aips._a, aips._u, aips._c, aips._b, aips._g))
+        a_inv = np.linalg.inv(a[o:, o:])
         a_theta = np.linalg.inv(sig0 * a - u)
         eye = np.eye(natm, dtype=int)
         hk = None
+        g_oro = g
         if gp is not None and gp.hk is not None:
             if gp.orographic_basis != "atmospheric":
-                raise NotImplementedError('orography on a non-atmospheric basis needs symbolic inner products')
+                g_oro = getattr(aips, '_gh', None)
+                if g_oro is None:
+                    raise NotImplementedError('orography on a non-atmospheric basis needs the symbolic-mode inner products')
             hk = np.asarray(gp.hk, dtype=float)
 
         # ---- psi_a equations (qgtensor.py:231-265) -------------------------------------------------
         rows = psi
-        v = a_inv @ c                                               # [i, j]
+        v = a_inv @ c[o:, o:]                                       # [i, j]
         T[rows[:, None], psi[None, :], 0] -= v * beta
         T[rows[:, None], psi[None, :], 0] -= (kd * eye) / 2
         T[rows[:, None], theta[None, :], 0] = (kd * eye) / 2
         if hk is not None:
-            oro = np.einsum('il,ljk->ijk', a_inv, g) @ hk          # a_inv[i,:] @ g[:, j, :] @ hk
+            oro = np.einsum('il,ljk->ijk', a_inv, g_oro[o:, o:, o:]) @ hk      # a_inv[i,:] @ g[:, j, :] @ hk
             T[rows[:, None], psi[None, :], 0] -= oro / 2
             T[rows[:, None], theta[None, :], 0] += oro / 2
-        vb = np.einsum('il,ljk->ijk', a_inv, b)
+        vb = np.einsum('il,ljk->ijk', a_inv, b[o:, o:, o:])
         T[rows[:, None, None], psi[None, :, None], psi[None, None, :]] = - vb
         T[rows[:, None, None], theta[None, :, None], theta[None, None, :]] = - vb
         if ocean:
             noc = nvar[2]
             psio = np.arange(noc) + par.variables_range[1] + 1
-            v = a_inv @ aips._d
+            v = a_inv @ np.asarray(aips._d)[o:, o:]
             T[rows[:, None], psio[None, :], 0] += v * kd / 2
 
         # ---- theta_a equations (qgtensor.py:268-338) -------------------------------------------------
-        rows = theta
+        rows = theta_all
         if par.Cpa is not None:
             T[rows, 0, 0] -= a_theta @ u @ np.asarray(par.Cpa, dtype=float)
         if atp.hd is not None and atp.thetas is not None:
             val = - a_theta @ u @ np.asarray(atp.thetas, dtype=float)
             T[rows, 0, 0] += val * float(atp.hd)
-        v = a_theta @ a
+        v = a_theta @ a[:, o:]
         T[rows[:, None], psi[None, :], 0] += v * kd * sig0 / 2
         T[rows[:, None], theta[None, :], 0] -= v * (kd / 2 + 2 * kdp) * sig0
-        v = - a_theta @ c
+        v = - a_theta @ c[:, o:]
         T[rows[:, None], theta[None, :], 0] += v * beta * sig0
         if hk is not None:
-            oro = np.einsum('il,ljk->ijk', a_theta, g) @ hk
+            oro = np.einsum('il,ljk->ijk', a_theta, g_oro[:, o:, o:]) @ hk
             T[rows[:, None], theta[None, :], 0] -= sig0 * oro / 2
             T[rows[:, None], psi[None, :], 0] += sig0 * oro / 2
-        vb = np.einsum('il,ljk->ijk', a_theta, b)
-        vg = np.einsum('il,ljk->ijk', a_theta, g)
+        vb = np.einsum('il,ljk->ijk', a_theta, b[:, o:, o:])
+        vg = np.einsum('il,ljk->ijk', a_theta, g[:, o:, o:])
         T[rows[:, None, None], psi[None, :, None], theta[None, None, :]] = - vb * sig0
         T[rows[:, None, None], theta[None, :, None], psi[None, None, :]] = - vb * sig0
         T[rows[:, None, None], psi[None, :, None], theta[None, None, :]] += vg
         v = a_theta @ u
         if par.Lpa is not None:
-            T[rows[:, None], theta[None, :], 0] += v * float(atp.sc) * par.Lpa
+            T[rows[:, None], theta_all[None, :], 0] += v * float(atp.sc) * par.Lpa
         if par.LSBpa is not None:
-            T[rows[:, None], theta[None, :], 0] += v * par.LSBpa
+            T[rows[:, None], theta_all[None, :], 0] += v * par.LSBpa
         if atp.hd is not None:
-            T[rows[:, None], theta[None, :], 0] += v * float(atp.hd)
+            T[rows[:, None], theta_all[None, :], 0] += v * float(atp.hd)
         if ocean:
-            v = - a_theta @ aips._d
+            v = - a_theta @ np.asarray(aips._d)[:, o:]
             T[rows[:, None], psio[None, :], 0] += v * sig0 * kd / 2
         if ocean or ground_temp:
             nsurf = nvar[3] if ocean else nvar[2]
-            dT = np.arange(nsurf) + (par.variables_range[2] if ocean else par.variables_range[1]) + 1
+            dT_all = np.arange(nsurf) + (par.variables_range[2] if ocean else par.variables_range[1]) + 1
+            dT = dT_all[o:]
         if (ocean or ground_temp) and par.Lpa is not None:
-            v = - a_theta @ aips._s
-            T[rows[:, None], dT[None, :], 0] += v * par.Lpa / 2
+            v = - a_theta @ np.asarray(aips._s)
+            T[rows[:, None], dT_all[None, :], 0] += v * par.Lpa / 2
             if par.LSBpgo is not None:
-                T[rows[:, None], dT[None, :], 0] += v * par.LSBpgo
+                T[rows[:, None], dT_all[None, :], 0] += v * par.LSBpgo
 
         if ocean:
             # ---- psi_o equations (qgtensor.py:342-364) ---------------------------------------------------
-            U_inv = np.linalg.inv(bips._U)
-            M_psio = np.linalg.inv(bips._M + par.G * bips._U)
+            bU, bM, bN, bO, bC, bK, bW = (np.asarray(t) for t in (bips._U, bips._M, bips._N, bips._O, bips._C, bips._K, bips._W))
+            U_inv = np.linalg.inv(bU)
+            M_psio = np.linalg.inv(bM[o:, o:] + par.G * bU[o:, o:])
             rows = psio
-            v = M_psio @ bips._K * float(op.d)
+            v = M_psio @ bK[o:, o:] * float(op.d)
             T[rows[:, None], psi[None, :], 0] += v
             T[rows[:, None], theta[None, :], 0] -= v
-            v = - M_psio @ bips._N
+            v = - M_psio @ bN[o:, o:]
             T[rows[:, None], psio[None, :], 0] += v * beta
-            v = - M_psio @ bips._M
+            v = - M_psio @ bM[o:, o:]
             T[rows[:, None], psio[None, :], 0] += v * (float(op.r) + float(op.d))
-            T[rows[:, None, None], psio[None, :, None], psio[None, None, :]] -= np.einsum('il,ljk->ijk', M_psio, bips._C)
+            T[rows[:, None, None], psio[None, :, None], psio[None, None, :]] -= np.einsum('il,ljk->ijk', M_psio, bC[o:, o:, o:])
 
             # ---- delta T_o equations (qgtensor.py:367-389) -----------------------------------------------
-            rows = dT
-            T[rows, 0, 0] += U_inv @ bips._W @ np.asarray(par.Cpgo, dtype=float)
-            v = U_inv @ bips._W
-            T[rows[:, None], theta[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
+            rows = dT_all
+            T[rows, 0, 0] += U_inv @ bW @ np.asarray(par.Cpgo, dtype=float)
+            v = U_inv @ bW
+            T[rows[:, None], theta_all[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
             if par.sbpa is not None:
-                T[rows[:, None], theta[None, :], 0] += v * par.sbpa
-            eye_o = np.eye(noc, dtype=int)
-            T[rows[:, None], dT[None, :], 0] = - par.Lpgo * eye_o
+                T[rows[:, None], theta_all[None, :], 0] += v * par.sbpa
+            eye_o = np.eye(nvar[3], dtype=int)
+            T[rows[:, None], dT_all[None, :], 0] = - par.Lpgo * eye_o
             if par.sbpgo is not None:
-                T[rows[:, None], dT[None, :], 0] += - par.sbpgo * eye_o
-            T[rows[:, None, None], psio[None, :, None], dT[None, None, :]] -= np.einsum('il,ljk->ijk', U_inv, bips._O)
+                T[rows[:, None], dT_all[None, :], 0] += - par.sbpgo * eye_o
+            T[rows[:, None, None], psio[None, :, None], dT[None, None, :]] -= np.einsum('il,ljk->ijk', U_inv, bO[:, o:, o:])
 
         if ground_temp:
             # ---- delta T_g equations (qgtensor.py:392-409) -----------------------------------------------
             ngr = nvar[2]
-            U_inv = np.linalg.inv(bips._U)
-            rows = dT
-            T[rows, 0, 0] += U_inv @ bips._W @ np.asarray(par.Cpgo, dtype=float)
-            v = U_inv @ bips._W
-            T[rows[:, None], theta[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
+            bU, bW = np.asarray(bips._U), np.asarray(bips._W)
+            U_inv = np.linalg.inv(bU)
+            rows = dT_all
+            T[rows, 0, 0] += U_inv @ bW @ np.asarray(par.Cpgo, dtype=float)
+            v = U_inv @ bW
+            T[rows[:, None], theta_all[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
             if par.sbpa is not None:
-                T[rows[:, None], theta[None, :], 0] += v * par.sbpa
+                T[rows[:, None], theta_all[None, :], 0] += v * par.sbpa
             eye_g = np.eye(ngr, dtype=int)
-            T[rows[:, None], dT[None, :], 0] = - par.Lpgo * eye_g
+            T[rows[:, None], dT_all[None, :], 0] = - par.Lpgo * eye_g
             if par.sbpgo is not None:
-                T[rows[:, None], dT[None, :], 0] += - par.sbpgo * eye_g
+                T[rows[:, None], dT_all[None, :], 0] += - par.sbpgo * eye_g
         return T
 
     # ---- I/O ------------------------------------------------------------------------------------------
@@ -245,3 +274,73 @@ class QgsTensor(object):
         name = tensor_name or 'QgsTensorJacobian'
         for coo, val in zip(self.jacobian_tensor.coords.T, self.jacobian_tensor.data):
             self._string_format(print, name, coo, val)
+
+
+class QgsTensorDynamicT(QgsTensor):
+    """Tendencies tensor of the models with dynamic reference temperatures (reference: qgtensor.py:843-1170): rank 5,
+
+        d eta_i/dt = sum T_ijklm eta_j eta_k eta_l eta_m ,     eta_0 = 1,
+
+    the rank-3 tensor of `QgsTensor` (entries (i, j, k, 0, 0)) plus the quartic long-wave radiation terms
+    sigma_B T^4 of the temperature equations.  With `dynamic_T` only the 0-th mode is kept to fourth order,
+    T_0^4 + 4 T_0^3 dT_m (qgtensor.py:1009-1154); `QgsTensorT4` keeps every product.
+
+    `tensor` / `jacobian_tensor` are rank-5 `CooTensor`s with the reference's conventions: the Jacobian tensor is
+    T + T.swapaxes(1, 2) + T.swapaxes(1, 3) + T.swapaxes(1, 4) of the un-simplified tensor (qgtensor.py:700-722), the
+    tensor itself has its last four indices sorted and duplicates merged (qgtensor.py:724-746).
+    """
+
+    def _quartic_blocks(self):
+        """[(row indices, variable indices, block (n_rows, n, n, n, n))]: the T^4 terms of the temperature equations,
+        qgtensor.py:916-1007 (the same contraction serves dynamic T and T4: the inner products decide what is kept)."""
+        par = self.params
+        aips = self.atmospheric_inner_products
+        ocean = self.oceanic_inner_products is not None
+        bips = self.oceanic_inner_products if ocean else self.ground_inner_products
+        nvar = par.number_of_variables
+        sig0 = float(par.atmospheric_params.sig0)
+        theta = np.arange(nvar[1]) + par.variables_range[0] + 1
+        blocks = []
+        a_theta = np.linalg.inv(sig0 * np.asarray(aips._a) - np.asarray(aips._u))
+        if par.T4LSBpa is not None:
+            blocks.append((theta, theta, par.T4LSBpa * np.einsum('ij,jklmn->iklmn', a_theta, aips._z)))
+        if bips is not None:
+            nsurf = nvar[3] if ocean else nvar[2]
+            dT = np.arange(nsurf) + (par.variables_range[2] if ocean else par.variables_range[1]) + 1
+            if par.T4LSBpgo is not None:
+                blocks.append((theta, dT, - par.T4LSBpgo * np.einsum('ij,jklmn->iklmn', a_theta, aips._v)))
+            U_inv = np.linalg.inv(np.asarray(bips._U))
+            blocks.append((dT, theta, par.T4sbpa * np.einsum('ij,jklmn->iklmn', U_inv, bips._Z)))
+            blocks.append((dT, dT, - par.T4sbpgo * np.einsum('ij,jklmn->iklmn', U_inv, bips._V)))
+        return blocks
+
+    def compute_tensor(self):
+        par = self.params
+        if par is None or self.atmospheric_inner_products is None:
+            return
+        n1 = par.ndim + 1
+        shape = (n1,) * 5
+        full3 = self._assemble_dense()
+        nz = np.nonzero(full3)
+        coords = [np.vstack((np.array(nz), np.zeros((2, len(nz[0])), dtype=np.int64)))]    # (i, j, k, 0, 0)
+        data = [full3[nz]]
+        for rows, var, block in self._quartic_blocks():
+            bz = np.nonzero(block)
+            coords.append(np.vstack((rows[bz[0]], var[bz[1]], var[bz[2]], var[bz[3]], var[bz[4]])))
+            data.append(block[bz])
+        coords, data = np.hstack(coords), np.concatenate(data)
+        # Jacobian tensor: the un-simplified tensor plus its copies with axis 1 swapped with axes 2, 3, 4
+        jc = [coords]
+        for ax in (2, 3, 4):
+            sw = coords.copy()
+            sw[[1, ax]] = sw[[ax, 1]]
+            jc.append(sw)
+        self.jacobian_tensor = CooTensor.from_coords(np.hstack(jc), np.tile(data, 4), shape)
+        srt = coords.copy()
+        srt[1:] = np.sort(coords[1:], axis=0)
+        self.tensor = CooTensor.from_coords(srt, data, shape)
+
+
+class QgsTensorT4(QgsTensorDynamicT):
+    """Tendencies tensor of the models with the full T^4 long-wave radiation terms (reference: qgtensor.py:1173-1363).
+    Same assembly as `QgsTensorDynamicT`: the inner products z, v, Z, V then hold every index combination."""

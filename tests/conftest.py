@@ -10,7 +10,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
-CONFIGS = ('rp20', 'a36', 'm36', 't228', 'g30', 'd38')       # d38: rank-5 tensor (dynamic-T model)
+CONFIGS = ('rp20', 'a36', 'm36', 't228', 'g30', 'd38', 'q38')       # d38, q38: rank-5 tensors (dynamic-T, T4 models)
 
 
 def pytest_configure(config):

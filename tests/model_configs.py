@@ -54,6 +54,34 @@ def params_g30():
     return p
 
 
+def _params_notebook_T(**flags):
+    """notebooks/maooam_dynamic_temperature.ipynb / maooam_T4.ipynb: MAOOAM 2x2 / 2x4 with dynamic reference
+    temperatures (rank-5 tensor); the modes must be set in `symbolic` mode."""
+    p = QgParams({'n': 1.5}, **flags)
+    p.set_atmospheric_channel_fourier_modes(2, 2, mode="symbolic")
+    p.set_oceanic_basin_fourier_modes(2, 4, mode="symbolic")
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'hlambda': 15.06})
+    p.gotemperature_params.set_params({'gamma': 5.6e8})
+    p.atemperature_params.set_insolation(103., 0)
+    p.atemperature_params.set_insolation(103., 1)
+    p.gotemperature_params.set_insolation(310., 0)
+    p.gotemperature_params.set_insolation(310., 1)
+    return p
+
+
+def params_d38():
+    return _params_notebook_T(dynamic_T=True)
+
+
+def params_q38():
+    return _params_notebook_T(T4=True)
+
+
+# rank-5 configurations: the reference computes their inner products by numerical quadrature, so its tensors are
+# reproduced to its quadrature accuracy instead of bit for bit
+MAKERS_RANK5 = {'d38': params_d38, 'q38': params_q38}
+
 MAKERS = {'rp20': params_rp20, 'a36': params_a36, 'm36': params_m36, 't228': params_t228, 'g30': params_g30}
 
 

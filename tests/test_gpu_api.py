@@ -10,7 +10,7 @@ from conftest import load_golden, rel_err
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope='module', params=['rp20', 'a36', 'm36', 'g30'])
+@pytest.fixture(scope='module', params=['rp20', 'a36', 'm36', 'g30', 'd38'])       # d38: rank-5 tensor (dynamic T)
 def setup(request):
     from qgs_amd.functions.tendencies import tendencies_from_tensor
     g = load_golden(request.param)
@@ -29,7 +29,7 @@ def test_f_and_Df_callables(setup):
     x = g['fx_x'][3]
     assert f(0., x).shape == (g.ndim,) and rel_err(f(0., x), g['fx_f'][3]) < 1e-14
     assert Df(0., x).shape == (g.ndim, g.ndim) and rel_err(Df(0., x), g['fx_Df'][3]) < 1e-14
-    assert f.coo.shape[1] == 3 and len(f.val) == f.coo.shape[0] and f.ndim == g.ndim
+    assert f.coo.shape[1] == (5 if g.name == 'd38' else 3) and len(f.val) == f.coo.shape[0] and f.ndim == g.ndim
     f2 = pickle.loads(pickle.dumps(f))                       # picklable like the reference's f
     assert rel_err(f2(0., x), g['fx_f'][3]) < 1e-14
     f2.operands.release()
@@ -234,3 +234,35 @@ def test_sparse_mul_entry_points_match_oracle():
     assert np.abs(ref2[1:, 0]).max() > 0                      # column 0 (linear part) is exercised
     with pytest.raises(NotImplementedError):
         sparse_mul3(g['coo'], g['val'], xx, 2. * xx)
+
+
+def test_dynamic_T_model_end_to_end():
+    """QgParams(dynamic_T=True) -> quadrature inner products -> QgsTensorDynamicT -> rank-5 f / Df on the GPU ->
+    RungeKuttaIntegrator / RungeKuttaTglsIntegrator, against the reference's outputs for the same model
+    (notebooks/maooam_dynamic_temperature.ipynb parameters).  The reference's tensor carries its quadrature error
+    (2e-14 relative), hence 1e-10 instead of the 1e-12 of the models with closed-form inner products."""
+    from model_configs import params_d38
+    from qgs_amd.functions.tendencies import create_tendencies
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator, RungeKuttaTglsIntegrator
+    g = load_golden('d38')
+    p = params_d38()
+    f, Df = create_tendencies(p)
+    assert p.ndim == 38 and f.coo.shape[1] == 5
+    assert f.hip_model().specialised_available and f.hip_model().n_derived == (4, 22)
+    assert rel_err(f(0., g['fx_x']), g['fx_f']) < 1e-10
+    n = g['fx_Df'].shape[0]
+    assert rel_err(Df(0., g['fx_x'][:n]), g['fx_Df']) < 1e-10
+    ic = g['rk_ic']
+    integ = RungeKuttaIntegrator()
+    integ.set_func(f)
+    integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=5)
+    tt, tr = integ.get_trajectories()
+    assert np.array_equal(tt, g['cls_rk_w5_time']) and rel_err(tr, g['cls_rk_w5_traj']) < 1e-10
+    integ.terminate()
+    tinteg = RungeKuttaTglsIntegrator()
+    tinteg.set_func(f, Df)
+    tinteg.integrate(0., 0.3, 0.1, ic=ic[:2], write_steps=1)
+    tt, tr, fm = tinteg.get_trajectories()
+    assert rel_err(tr, g['cls_tgls_traj']) < 1e-10 and rel_err(fm, g['cls_tgls_fm']) < 1e-10
+    tinteg.terminate()
+    f.operands.release()

@@ -42,7 +42,7 @@ def test_backend_is_gfx950():
     assert n >= 1 and arch.startswith('gfx950'), arch
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38', 'q38'])
 def test_f_and_Df_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):
@@ -55,7 +55,7 @@ def test_f_and_Df_vs_golden(models, name):
         assert m.jacobian(g['fx_x'][0]).shape == (g.ndim, g.ndim)
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38', 'q38'])
 def test_rk_cases_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):
@@ -69,7 +69,7 @@ def test_rk_cases_vs_golden(models, name):
             assert rel_err(rec, g['rk_%s_traj' % t]) < tol, (kind, t)
 
 
-@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38'])
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38', 'q38'])
 def test_tgls_cases_vs_golden(models, name):
     g, m = load_golden(name), models(name)
     for kind in _kinds(m):
@@ -151,6 +151,46 @@ def test_lds_resident_tangent_ndim228_vs_oracle(models, n_traj, n_tg):
         tr, fm = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
         assert m.last_kernel_info()['name'] == ('qgs_spec_adjlds16' if adj else 'qgs_spec_tgllds16')
         assert fm.shape == rfm.shape and rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (d, ws, adj, inv)
+    m.set_kernel(0)
+
+
+@pytest.mark.parametrize('name,n_traj', [('d38', 1), ('d38', 130), ('q38', 70)])
+def test_rank5_models_vs_oracle(models, name, n_traj):
+    """Rank-5 tensors (sparse_mul5 / sparse_mul4 path): the derived-monomial specialised kernels (dynamic T: registers;
+    T4: the trajectory kernels only, its Jacobian code would need 516 derived monomials) and the 4-factor generic kernels
+    against the oracle on seeded ensembles around the wavefront boundary: f, Df, RK4 with records, backward Heun,
+    tangent and adjoint models."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden(name), models(name)
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    assert ora.rank == 5
+    rng = np.random.RandomState(n_traj)
+    ic = rng.rand(n_traj, g.ndim) * 0.01
+    ic[:, 10] += 1.5
+    ic[:, 29] += 3.
+    t = np.concatenate((np.arange(0., 1.0, 0.1), [1.0]))
+    b2, c2 = np.array([.5, .5]), np.array([0., 1.])
+    a2 = np.zeros((2, 2)); a2[1, 0] = 1.
+    ref4 = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
+    ref2 = ora.integrate_runge_kutta_jit(t, ic, -1, 0, b2, c2, a2, threads=4)
+    nt = min(n_traj, 4)
+    tg = rng.randn(nt, g.ndim, 3)
+    rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    atr, afm = ora.integrate_runge_kutta_tgls_jit(t[:5], ic[:nt], tg, -1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+    for kind in _kinds(m):
+        m.set_kernel(KINDS[kind])
+        assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14, kind
+        assert rel_err(m.jacobian(ic[:nt]), ora.Df(0., ic[:nt])) < 1e-14, kind
+        assert rel_err(m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a']), ref4) < 1e-12, kind
+        if kind == 'specialised':
+            assert m.last_kernel_info()['name'] == 'qgs_spec_rk_s4'
+        assert rel_err(m.rk_integrate(t, ic, -1, 0, b2, c2, a2), ref2) < 1e-12, kind
+        tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
+        if kind == 'specialised':
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'gen_tgl_kernel')
+        tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, -1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+        assert rel_err(tr, atr) < 1e-12 and rel_err(fm, afm) < 1e-11, kind
     m.set_kernel(0)
 
 

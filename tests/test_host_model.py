@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN_DIR, load_golden
-from model_configs import MAKERS
+from model_configs import MAKERS, MAKERS_RANK5
 
 REAL_EPS = np.finfo(np.float64).eps
 
@@ -181,3 +181,99 @@ def test_print_tensor(built, capsys):
     built['rp20'][4].print_tensor('T')
     out = capsys.readouterr().out.strip().split('\n')
     assert len(out) == 225 and out[0].startswith('T[1][0][')
+
+
+# ---- `symbolic`-mode models: quadrature inner products, rank-5 tensors ----------------------------------------------------
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'g30'])
+def test_quadrature_inner_products_equal_the_analytic_ones(built, name):
+    """The same basis through both routes: closed-form (analytic.py) and Gauss-Legendre quadrature (symbolic.py) -- the check
+    model_test/test_aotensor_sym.py makes on the reference's symbolic inner products."""
+    from qgs_amd.inner_products import symbolic as S
+    p = built[name][0]
+    aip, oip, gip = built[name][3]
+    sa = S.AtmosphericSymbolicInnerProducts(p)
+    pairs = [(getattr(aip, '_' + k), getattr(sa, '_' + k)) for k in 'aucbg']
+    if oip is not None:
+        so = S.OceanicSymbolicInnerProducts(p)
+        sa.connect_to_ocean(so)
+        pairs += [(getattr(oip, '_' + k), getattr(so, '_' + k)) for k in 'MUNOCKW'] + [(aip._s, sa._s), (aip._d, sa._d)]
+    if gip is not None:
+        sg = S.GroundSymbolicInnerProducts(p)
+        sa.connect_to_ground(sg)
+        pairs += [(gip._U, sg._U), (gip._W, sg._W), (aip._s, sa._s)]
+    for ref, val in pairs:
+        assert np.abs(np.asarray(ref) - np.asarray(val)).max() <= 1e-14 * max(1., np.abs(ref).max())
+
+
+@pytest.fixture(scope='module')
+def built_rank5():
+    from qgs_amd.functions.tendencies import create_tendencies
+    out = {}
+    for name, mk in MAKERS_RANK5.items():
+        p = mk()
+        f, Df, ips, T = create_tendencies(p, return_inner_products=True, return_qgtensor=True)
+        out[name] = (p, f, Df, ips, T)
+    return out
+
+
+def _as_dict(coo, val):
+    return {tuple(int(q) for q in c): float(v) for c, v in zip(coo, val)}
+
+
+@pytest.mark.parametrize('name', list(MAKERS_RANK5))
+def test_rank5_tensors_vs_golden(built_rank5, name):
+    """QgsTensorDynamicT / QgsTensorT4 against the reference's tensors.  The reference integrates these models' inner
+    products numerically (scipy dblquad), so its entries carry its quadrature error (measured: 2e-14 relative for the
+    dynamic-T model, 1e-11 for the quartic inner products of T4) and rounding residue (|v| < 1e-12) where an entry
+    vanishes identically; the structure (coordinates of every entry above that level) must be identical."""
+    g = load_golden(name)
+    p, f, Df, ips, T = built_rank5[name]
+    assert p.ndim == g.ndim == 38 and list(p.variables_range) == [int(v) for v in g['par_variables_range']]
+    assert p.var_string[10] == 'T_a_0' and p.var_string[29] == 'T_o_0' and len(p.var_string) == 38
+    assert T.tensor.coords.shape[0] == 5 and f.coo.shape[1] == 5 and Df.coo.shape[1] == 5
+    for mine, ref in ((_as_dict(T.tensor.coords.T, T.tensor.data), _as_dict(g['coo'], g['val'])),
+                      (_as_dict(T.jacobian_tensor.coords.T, T.jacobian_tensor.data), _as_dict(g['jcoo'], g['jval']))):
+        big_m = {k for k, v in mine.items() if abs(v) > 1e-12}
+        big_r = {k for k, v in ref.items() if abs(v) > 1e-12}
+        assert big_m == big_r
+        for k in big_r:
+            assert abs(mine[k] - ref[k]) <= 2e-11 * abs(ref[k]), (k, mine[k], ref[k])
+        for k in (set(mine) | set(ref)) - big_r:
+            assert abs(mine.get(k, 0.) - ref.get(k, 0.)) < 1e-12
+    c = T.tensor.coords
+    assert (np.diff(c[1:], axis=0) >= 0).all() and (c[0] >= 1).all()          # last four indices sorted, no row 0
+    for k in ('Cpa', 'Cpgo', 'Lpa', 'Lpgo', 'LR', 'G'):
+        assert np.array_equal(np.asarray(getattr(p, k), dtype=float), g['par_' + k]), k
+    assert p.LSBpa is None and p.sbpgo is None and p.T4LSBpa > 0 and p.T4sbpgo > 0
+
+
+@pytest.mark.parametrize('name', list(MAKERS_RANK5))
+def test_rank5_inner_products_vs_golden(built_rank5, name):
+    g = load_golden(name)
+    aip, oip, _ = built_rank5[name][3]
+    for obj, pre, syms in ((aip, 'aip_', 'aucbgsdzv'), (oip, 'oip_', 'MUNOCKWZV')):
+        for k in syms:
+            if pre + k in g:
+                ref = g[pre + k]
+                assert np.abs(np.asarray(getattr(obj, '_' + k)) - ref).max() <= 2e-11 * max(1., np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize('name', list(MAKERS_RANK5))
+def test_oracle_on_own_rank5_tensor_reproduces_golden_f(built_rank5, name):
+    """Own tensor + oracle (sparse_mul5 / sparse_mul4 restatement) against the reference's f and Df."""
+    from oracle.oracle import OracleModel
+    g = load_golden(name)
+    f, Df = built_rank5[name][1], built_rank5[name][2]
+    m = OracleModel(f.ndim, f.coo, f.val, Df.coo, Df.val)
+    n = g['fx_Df'].shape[0]
+    assert np.abs(m.f(0., g['fx_x']) - g['fx_f']).max() <= 1e-10 * np.abs(g['fx_f']).max()
+    assert np.abs(m.Df(0., g['fx_x'][:n]) - g['fx_Df']).max() <= 1e-10 * np.abs(g['fx_Df']).max()
+
+
+def test_dynamic_T_needs_symbolic_mode():
+    from qgs_amd.params.params import QgParams
+    p = QgParams(dynamic_T=True)
+    with pytest.raises(ValueError):
+        p.set_atmospheric_channel_fourier_modes(2, 2)
+    assert QgParams(T4=True).dynamic_T is True            # params.py:921-923
