@@ -1150,16 +1150,65 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
     if (hook_phase >= (int)phases.size()) hook(so);
 }
 
-void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+// Derived monomials (rank-5 tensors) in the LDS-resident kernels: every derived value is one more LDS node behind the
+// base ones.  The products are formed between two barriers right after a stage state has been published; a chain
+// (q = x*x, r = q*x) stays inside one wavefront, the chains are spread over the wavefronts.
+std::vector<std::vector<int>> lds_derived_shares(int nbase, const std::vector<std::pair<int, int>> &der, int W)
+{
+    const int nd = (int)der.size();
+    std::vector<int> comp(nd);
+    for (int n = 0; n < nd; ++n) comp[n] = n;
+    std::function<int(int)> find = [&](int a) { return comp[a] == a ? a : comp[a] = find(comp[a]); };
+    for (int n = 0; n < nd; ++n)
+        for (int f : {der[n].first, der[n].second})
+            if (f > nbase) comp[find(n)] = find(f - nbase - 1);
+    std::map<int, std::vector<int>> groups;
+    for (int n = 0; n < nd; ++n) groups[find(n)].push_back(n);
+    std::vector<std::vector<int>> share(W);
+    std::vector<std::pair<size_t, int>> order;
+    for (auto &kv : groups) order.push_back({kv.second.size(), kv.first});
+    std::sort(order.begin(), order.end(), [](const std::pair<size_t, int> &a, const std::pair<size_t, int> &b) {
+        return a.first != b.first ? a.first > b.first : a.second < b.second;
+    });
+    for (auto &og : order) {
+        int w = 0;
+        for (int v = 1; v < W; ++v) if (share[v].size() < share[w].size()) w = v;
+        for (int n : groups[og.second]) share[w].push_back(n);
+    }
+    for (auto &sv : share) std::sort(sv.begin(), sv.end());          // a derived value only refers to earlier ones
+    return share;
+}
+
+// `value(node)`: expression reading a base node from LDS
+void emit_lds_derived(std::ostringstream &o, const char *ind, int nbase, const std::vector<std::pair<int, int>> &der,
+                      const std::vector<int> &mine, const std::function<std::string(int)> &value,
+                      const std::function<std::string(int)> &slot)
+{
+    if (mine.empty()) return;
+    o << ind << "{\n";
+    auto operand = [&](int f) { return f > nbase ? "dq" + std::to_string(f) : value(f); };
+    for (int n : mine) {
+        const int id = nbase + 1 + n;
+        o << ind << "    const f64 dq" << id << " = " << operand(der[n].first) << " * " << operand(der[n].second) << ";\n";
+        o << ind << "    " << slot(id) << " = dq" << id << ";\n";
+    }
+    o << ind << "}\n";
+}
+
+void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
+                        const std::vector<std::pair<int, int>> &der)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
+    const int nnode = ndim + (int)der.size();
+    const std::vector<std::vector<int>> dshare = lds_derived_shares(ndim, der, W);
+    const std::function<std::string(int)> dval = [](int f) { return "xs[" + std::to_string(f - 1) + "][lane]"; };
     const std::string kname = "qgs_spec_rklds" + std::to_string(W);
     RowTerms rt(ndim + 1);
     for (int i = 1; i <= ndim; ++i) {
         for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
         for (const Bil &b : rows[i].bil) rt[i].push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
     }
-    const std::vector<std::vector<int>> owns = lds_partition(ndim, ndim, rt, W, cap, opt.lds_group);
+    const std::vector<std::vector<int>> owns = lds_partition(ndim, nnode, rt, W, cap, opt.lds_group);
     const NodeFn node = [](int m) { return LdsNode{(int64_t)(m - 1) * 512, 0}; };
     std::ostringstream o;
     std::vector<KTable> tables(W);
@@ -1174,7 +1223,9 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S,\n"
       << "    int tend_only)                   // 1: evaluate f(y_in) once into y_out and return (one step, one stage requested)\n{\n";
-    o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
+    o << "    __shared__ f64 xs[" << nnode << "][QGS_WAVE];";
+    if (!der.empty()) o << "   // " << ndim << " variables + " << der.size() << " derived monomials";
+    o << "\n";
     o << "    const int lane = threadIdx.x & 63;\n"
       << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
       << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
@@ -1193,6 +1244,10 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         for (int d : own) o << I2 << "f64 acc" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
         for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
         o << I2 << "__syncthreads();\n";
+        if (!der.empty()) {
+            emit_lds_derived(o, I2, ndim, der, dshare[w], dval, dval);
+            o << I2 << "__syncthreads();\n";
+        }
         o << I2 << "QGS_REC_INIT\n";
         o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
         o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
@@ -1231,7 +1286,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
             else so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        const std::vector<Phase> phases = build_phases(ndim, terms, cap);
+        const std::vector<Phase> phases = build_phases(nnode, terms, cap);
         // step-start state of the own rows, consumed at the end of the stage
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
@@ -1252,6 +1307,10 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
         for (int d : own) o << I4 << "xs[" << (d - 1) << "][lane] = k" << d << ";\n";
         o << I4 << "__syncthreads();\n";
+        if (!der.empty()) {                                  // derived monomials of the new stage state
+            emit_lds_derived(o, I4, ndim, der, dshare[w], dval, dval);
+            o << I4 << "__syncthreads();\n";
+        }
         o << I3 << "}\n";
         // the new state is the start of the next step (stored after the barriers: a barrier waits for outstanding stores)
         for (int d : own) o << I3 << "yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
@@ -1278,18 +1337,21 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
 // J^T w); its terms c * x_k * w_j are ordered into phases that cache <= cap LDS values in registers.
 //   tangent  (J w)_i   = sum_{j,k} Tj_ijk x_k w_j        adjoint  (J^T w)_j = sum_{i,k} Tj_ijk x_k w_i
 void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &wx, bool adjoint,
-                         const CodegenOptions &opt)
+                         const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
     const std::string kname = std::string(adjoint ? "qgs_spec_adjlds" : "qgs_spec_tgllds") + std::to_string(W);
-    const int64_t xs_bytes = (int64_t)ndim * 16 * 8;
+    const int nx = ndim + (int)der.size();                  // x nodes: the stage state and (rank 5) its derived monomials
+    const int64_t xs_bytes = (int64_t)nx * 16 * 8;
+    const std::vector<std::vector<int>> dshare = lds_derived_shares(ndim, der, W);
+    const std::function<std::string(int)> dval = [](int f) { return "xs[" + std::to_string(f - 1) + "][lane & 15]"; };
     RowTerms rt(ndim + 1);
     for (int i = 1; i <= ndim; ++i)
         for (const WX &t : wx[i]) {
             if (t.x == 0) rt[i].push_back({i, 0, t.w, t.c});                 // x_0 = 1: c * w_j
             else rt[i].push_back({i, t.w, ndim + t.x, t.c});                 // node w_j < node x_k
         }
-    const std::vector<std::vector<int>> owns = lds_partition(ndim, 2 * ndim, rt, W, cap, opt.lds_group);
+    const std::vector<std::vector<int>> owns = lds_partition(ndim, ndim + nx, rt, W, cap, opt.lds_group);
     const NodeFn node = [ndim, xs_bytes](int n) {
         return n <= ndim ? LdsNode{xs_bytes + (int64_t)(n - 1) * 512, 0} : LdsNode{(int64_t)(n - ndim - 1) * 128, 1};
     };
@@ -1306,9 +1368,10 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
       << "    int backward, int write_final, f64 inverse, int S)\n{\n";
-    o << "    __shared__ f64 lds_all[" << ndim * 16 + ndim * 64 << "];\n"
-      << "    f64 (*xs)[16] = (f64 (*)[16])lds_all;                       // stage state of the 16 members\n"
-      << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << ndim * 16 << ");   // tangent stage vector of the 64 pairs\n";
+    o << "    __shared__ f64 lds_all[" << nx * 16 + ndim * 64 << "];\n"
+      << "    f64 (*xs)[16] = (f64 (*)[16])lds_all;                       // stage state of the 16 members"
+      << (der.empty() ? "" : " + derived monomials") << "\n"
+      << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << nx * 16 << ");   // tangent stage vector of the 64 pairs\n";
     o << "    const int lane = threadIdx.x & 63;\n"
       << "    const unsigned lane8 = (unsigned)lane * 8u, xl8 = (unsigned)(lane & 15) * 8u;\n"
       << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
@@ -1333,6 +1396,10 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
         for (int d : own) o << I2 << "ws[" << (d - 1) << "][lane] = acc" << d << "; vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
         o << I2 << "if (step_begin < step_end) QGS_LOAD_XS(stages);\n";
         o << I2 << "__syncthreads();\n";
+        if (!der.empty()) {
+            emit_lds_derived(o, I2, ndim, der, dshare[w], dval, dval);
+            o << I2 << "__syncthreads();\n";
+        }
         o << I2 << "QGS_REC_INIT\n";
         o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
         o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
@@ -1361,7 +1428,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
             so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        const std::vector<Phase> phases = build_phases(2 * ndim, terms, cap);
+        const std::vector<Phase> phases = build_phases(ndim + nx, terms, cap);
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8", "xl8"}, "(const char*)lds_all", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
@@ -1382,6 +1449,10 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
           << I4 << "    if (nxt < (step_end - step_begin) * S) QGS_LOAD_XS(stages + nxt * " << ndim << " * ld);\n"
           << I4 << "}\n";
         o << I4 << "__syncthreads();\n";
+        if (!der.empty()) {                                  // derived monomials of the stage state just loaded
+            emit_lds_derived(o, I4, ndim, der, dshare[w], dval, dval);
+            o << I4 << "__syncthreads();\n";
+        }
         o << I3 << "}\n";
         for (int d : own) o << I3 << "vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
         o << I2 << "}\n";
@@ -1452,9 +1523,9 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
         emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
                               opt.tgl_split, opt);
         break;
-    case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt); break;
-    case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt); break;
-    case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt); break;
+    case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t); break;
+    case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt, der.j); break;
+    case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt, der.j); break;
     }
     return o.str();
 }

@@ -265,6 +265,7 @@ struct qgs_model {
     bool spec_possible = false;
     bool spec_jac_possible = false;   // ... and the Jacobian / tangent kernels too (rank 5: their derived monomials fit as well)
     bool lds_spec_possible = false;   // too large for the register file, stage state fits LDS: JIT LDS-resident stepper
+    bool prefer_lds = false;          // register-resident kernels exist but would spill (rank 5 with many derived monomials)
     mutable std::map<std::string, bool> lds_on_disk;   // kernel name -> code object found in the kernel cache (checked once)
     qgs::CodegenOptions cg;
     // compiled specialised kernels, one module per kernel (keyed by the kernel name)
@@ -280,6 +281,28 @@ struct qgs_model {
 };
 
 namespace {
+
+// Which specialised kernel families a model can have (shared by qgs_model_create_rank and qgs_prebuild_rank).
+//   register-resident: ndim <= 64 and (rank 5) at most QGS_SPEC_MAX_DERIVED derived monomials per evaluation
+//   LDS-resident: stage state + derived monomials fit one workgroup's LDS; used when the register kernels do not exist,
+//   or when they exist but must spill (more than QGS_PREFER_LDS_DERIVED derived monomials: the T4 model keeps 111 pair
+//   products alive next to its 38 variables; measured 205 ms vs the LDS kernel for 65 536 members x 100 steps)
+#ifndef QGS_PREFER_LDS_DERIVED
+#define QGS_PREFER_LDS_DERIVED 24
+#endif
+void classify_model(qgs_model *m)
+{
+    const size_t ndim = (size_t)m->ndim, nt = m->der.t.size(), nj = m->der.j.size();
+    m->spec_possible = (m->ndim <= QGS_SPEC_MAX_NDIM) && nt <= QGS_SPEC_MAX_DERIVED;
+    m->spec_jac_possible = m->spec_possible && nj <= QGS_SPEC_MAX_DERIVED;
+    m->prefer_lds = m->spec_possible && nt > QGS_PREFER_LDS_DERIVED;
+    if (const char *e = std::getenv("QGS_HIP_PREFER_LDS")) m->prefer_lds = m->spec_possible && (*e == '1');
+    const bool fits = (ndim + nt) * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
+    m->lds_spec_possible = fits && (!m->spec_possible || m->prefer_lds);
+}
+
+// bytes of LDS the LDS-resident tangent kernel needs: stage state (+ derived monomials) of 16 members, tangent vector of 64 pairs
+size_t lds_tgl_bytes(const qgs_model *m) { return ((size_t)m->ndim + m->der.j.size()) * 128 + (size_t)m->ndim * 512; }
 
 int upload_csr(const HostCsr &h, DevCsr &d)
 {
@@ -525,7 +548,7 @@ bool use_lds_spec(const qgs_model *m, int64_t n_traj, int64_t n_steps, int s, co
 bool use_lds_tgl(const qgs_model *m, int64_t pairs, int64_t n_steps, int s, const double *a, int adjoint)
 {
     if (m->kernel_kind == 1 || !m->lds_spec_possible || m->J.empty()) return false;
-    if ((size_t)m->ndim * 640 > (size_t)QGS_LDS_STATE_BYTES) return false;
+    if (lds_tgl_bytes(m) > (size_t)QGS_LDS_STATE_BYTES) return false;
     if (s < 1 || s > 64 || !qgs::tableau_is_subdiagonal(s, a)) return false;
     return lds_kernel_wanted(m, adjoint ? qgs::Kernel::AdjLds : qgs::Kernel::TglLds,
                              (double)pairs * (double)n_steps * (double)s * (double)m->J.size());
@@ -692,10 +715,7 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     HostCsr hJj = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.j; }, [&](const Entry &t) { return pack(t.i, t.k); });
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
     if (!r5 && upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
-    // register-resident specialised kernels: the state and (rank 5) the derived monomials of a stage must fit the file
-    m->spec_possible = (ndim <= QGS_SPEC_MAX_NDIM) && m->der.t.size() <= QGS_SPEC_MAX_DERIVED;
-    m->spec_jac_possible = m->spec_possible && m->der.j.size() <= QGS_SPEC_MAX_DERIVED;
-    m->lds_spec_possible = !r5 && !m->spec_possible && (size_t)ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
+    classify_model(m);
     apply_env_options(m->cg);
     if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
     *out = m;
@@ -809,7 +829,7 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
     if (check_common(m, n_traj, ld)) return -1;
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
-    if (use_spec(m, 1, nullptr)) {
+    if (use_spec(m, 1, nullptr) && !m->prefer_lds) {
         hipFunction_t f;
         if (get_function(m, qgs::Kernel::Tend, 0, &f)) return -1;
         long long nt = n_traj, l = ld;
@@ -827,6 +847,14 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
         }
         return launch_rk_lds(m, n_traj, ld, d_x, d_dx, nullptr, nullptr, m->b_unit.f64(), m->b_unit.f64() + 2, 0, 1, 0, 1, 0, 0, 1,
                              st, 1);
+    }
+    if (use_spec(m, 1, nullptr)) {                                    // prefer_lds, but the LDS kernel is not wanted / built
+        hipFunction_t f;
+        if (get_function(m, qgs::Kernel::Tend, 0, &f)) return -1;
+        long long nt = n_traj, l = ld;
+        void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
+        note_kernel(m, "qgs_spec_tend", f);
+        return launch(f, n_traj, st, args);
     }
     qgs::launch_gen_tend(m->dT.view(), m->ndim, n_traj, ld, d_x, d_dx, st);
     note_kernel(m, "gen_tend_kernel", nullptr);
@@ -874,6 +902,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         note_kernel(m, "gen_rk_wave_kernel", nullptr);
         return 0;
     }
+    if (m->prefer_lds && use_lds_spec(m, n_traj, n_time - 1, s, a))
+        return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
+                             n_records, backward, 1, s, st);
     if (use_spec(m, s, a)) {
         // Kernel choice by ensemble size (measured, tools/kbench.py / tools/latency_bench.py, MAOOAM-36, ms per 1000 steps):
         //   n <= 2048      wave-per-trajectory kernel (handled above)        0.8-1.5
@@ -971,6 +1002,9 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         double inv = inverse;
         if (use_wave(m, n_traj, s, a)) {                  // few members: latency-optimised, lane = tensor row
             HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+        } else if (m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a)) {
+            if (launch_rk_lds(m, n_traj, ld, y_src, y_state, d_rec, stages, d_time, d_tab_spec, begin, end, write_steps, n_records,
+                              backward, final_chunk, s, st)) return -1;
         } else if (spec) {
             hipFunction_t f1;
             if (get_function(m, qgs::Kernel::RkStages, s, &f1)) return -1;
@@ -986,7 +1020,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             qgs::launch_gen_rk(m->dT.view(), pa, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
         }
         // --- tangent / adjoint pass ---
-        const bool lds_tgl = !spec && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
+        const bool lds_tgl = (!spec || !m->spec_jac_possible) && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
         if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs())) {
             if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
                                n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
@@ -1181,18 +1215,17 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     apply_env_options(m.cg);
     if (rank == 5) m.cg.row_split = 1;
     std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
-    if (ndim > QGS_SPEC_MAX_NDIM) {
-        if (rank != 3 || (size_t)ndim * 512 > (size_t)QGS_LDS_STATE_BYTES || m.T.size() > 200000) return 0;
+    classify_model(&m);
+    if (m.lds_spec_possible) {
         std::vector<char> code;
         bool cached;
-        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg), m.arch, code, &cached)) return -1;
-        if (!m.J.empty() && (size_t)ndim * 640 <= (size_t)QGS_LDS_STATE_BYTES)
+        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        if (!m.J.empty() && !m.spec_jac_possible && lds_tgl_bytes(&m) <= (size_t)QGS_LDS_STATE_BYTES)
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
-                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg), m.arch, code, &cached)) return -1;
-        return 0;
+                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
-    if (m.der.t.size() > QGS_SPEC_MAX_DERIVED) return 0;
-    const bool jac_spec = !m.J.empty() && m.der.j.size() <= QGS_SPEC_MAX_DERIVED;
+    if (!m.spec_possible) return 0;
+    const bool jac_spec = !m.J.empty() && m.spec_jac_possible;
     auto list = qgs::kernel_list(m.ndim, jac_spec, stages, m.cg);
     if (!m.J.empty() && !jac_spec)                       // the trajectory pass of the tangent model is still specialised
         for (int S : stages) list.push_back({qgs::Kernel::RkStages, S});

@@ -156,8 +156,8 @@ def test_lds_resident_tangent_ndim228_vs_oracle(models, n_traj, n_tg):
 
 @pytest.mark.parametrize('name,n_traj', [('d38', 1), ('d38', 130), ('q38', 70)])
 def test_rank5_models_vs_oracle(models, name, n_traj):
-    """Rank-5 tensors (sparse_mul5 / sparse_mul4 path): the derived-monomial specialised kernels (dynamic T: registers;
-    T4: the trajectory kernels only, its Jacobian code would need 516 derived monomials) and the 4-factor generic kernels
+    """Rank-5 tensors (sparse_mul5 / sparse_mul4 path): the derived-monomial specialised kernels (dynamic T: 4 / 22 derived
+    monomials, register-resident; T4: 111 / 516, kept in LDS by the LDS-resident kernels) and the 4-factor generic kernels
     against the oracle on seeded ensembles around the wavefront boundary: f, Df, RK4 with records, backward Heun,
     tangent and adjoint models."""
     from oracle.oracle import OracleModel
@@ -183,14 +183,16 @@ def test_rank5_models_vs_oracle(models, name, n_traj):
         assert rel_err(m.jacobian(ic[:nt]), ora.Df(0., ic[:nt])) < 1e-14, kind
         assert rel_err(m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a']), ref4) < 1e-12, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == 'qgs_spec_rk_s4'
+            assert m.last_kernel_info()['name'] == ('qgs_spec_rk_s4' if name == 'd38' else 'qgs_spec_rklds16')
         assert rel_err(m.rk_integrate(t, ic, -1, 0, b2, c2, a2), ref2) < 1e-12, kind
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'gen_tgl_kernel')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'qgs_spec_tgllds16')
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, -1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.)
         assert rel_err(tr, atr) < 1e-12 and rel_err(fm, afm) < 1e-11, kind
+        if kind == 'specialised':
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'qgs_spec_adjlds16')
     m.set_kernel(0)
 
 
