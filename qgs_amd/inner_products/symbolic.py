@@ -106,22 +106,55 @@ def _jac_lap(A, B):
     return _jac(A, B) * B.lam[None, :, None]
 
 
+class DynTQuartic(object):
+    """Quartic inner products of the dynamic-T scheme: (L_i, R_0^3 R_m), stored for (i, 0, 0, 0, m) and every
+    permutation of the last four indices (symbolic.py:497-502) -- kept as the (i, m) matrix instead of an n^5 array
+    (37^5 doubles = 555 MB for a 4x4 / 4x4 model).  Indexable like the array it stands for; `todense()` / `np.asarray`
+    expand it."""
+
+    def __init__(self, val, n):
+        self.val = np.asarray(val, dtype=float)
+        self.shape = (self.val.shape[0], n, n, n, n)
+
+    @staticmethod
+    def _perms(m):
+        return sorted(set(itertools.permutations((0, 0, 0, m))))
+
+    def __getitem__(self, idx):
+        i, rest = idx[0], tuple(int(q) for q in idx[1:])
+        m = max(rest)
+        return self.val[i, m] if sorted(rest) == [0, 0, 0, m] else 0.
+
+    def entries(self):
+        """(coords (5, n), data) of the non-zero entries."""
+        coords, data = [], []
+        for i, m in zip(*np.nonzero(self.val)):
+            for perm in self._perms(int(m)):
+                coords.append((int(i),) + perm)
+                data.append(self.val[i, m])
+        return np.array(coords, dtype=np.int64).reshape(-1, 5).T, np.array(data)
+
+    def todense(self):
+        out = np.zeros(self.shape)
+        c, d = self.entries()
+        out[tuple(c)] = d
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        return self.todense()
+
+
 def _quartic(left, w, R, full):
-    """(L_i, R_j R_k R_l R_m).  full: every index (T4, symbolic.py:490-495); else only (i, 0, 0, 0, m) and its
-    permutations (dynamic T, symbolic.py:497-502)."""
+    """(L_i, R_j R_k R_l R_m).  full: every index, dense (T4, symbolic.py:490-495); else only (i, 0, 0, 0, m) and its
+    permutations (dynamic T, symbolic.py:497-502), as a `DynTQuartic`."""
     n = len(R)
-    out = np.zeros((len(left), n, n, n, n))
     Lw = left.F * w[None, :]
-    if full:
-        PP = (R.F[:, None, :] * R.F[None, :, :]).reshape(n * n, -1)              # (jk, g)
-        for i in range(len(left)):
-            out[i] = ((PP * Lw[i][None, :]) @ PP.T).reshape(n, n, n, n)
-    else:
-        r0 = R.F[0] ** 3
-        val = (Lw * r0[None, :]) @ R.F.T                                          # (i, m)
-        for m in range(n):
-            for perm in set(itertools.permutations((0, 0, 0, m))):
-                out[(slice(None),) + perm] = val[:, m]
+    if not full:
+        return DynTQuartic(_chop((Lw * (R.F[0] ** 3)[None, :]) @ R.F.T), n)
+    out = np.zeros((len(left), n, n, n, n))
+    PP = (R.F[:, None, :] * R.F[None, :, :]).reshape(n * n, -1)              # (jk, g)
+    for i in range(len(left)):
+        out[i] = ((PP * Lw[i][None, :]) @ PP.T).reshape(n, n, n, n)
     return _chop(out)
 
 

@@ -290,9 +290,10 @@ class QgsTensorDynamicT(QgsTensor):
     tensor itself has its last four indices sorted and duplicates merged (qgtensor.py:724-746).
     """
 
-    def _quartic_blocks(self):
-        """[(row indices, variable indices, block (n_rows, n, n, n, n))]: the T^4 terms of the temperature equations,
+    def _quartic_entries(self):
+        """[(coords (5, n), data)]: the T^4 terms of the temperature equations as un-simplified tensor entries,
         qgtensor.py:916-1007 (the same contraction serves dynamic T and T4: the inner products decide what is kept)."""
+        from qgs_amd.inner_products.symbolic import DynTQuartic
         par = self.params
         aips = self.atmospheric_inner_products
         ocean = self.oceanic_inner_products is not None
@@ -300,19 +301,30 @@ class QgsTensorDynamicT(QgsTensor):
         nvar = par.number_of_variables
         sig0 = float(par.atmospheric_params.sig0)
         theta = np.arange(nvar[1]) + par.variables_range[0] + 1
-        blocks = []
+
+        def contract(rows, var, mat, ip, factor):
+            """factor * sum_jj mat[i, jj] ip[jj, j, k, l, m] at (rows[i], var[j], var[k], var[l], var[m])"""
+            if isinstance(ip, DynTQuartic):
+                c, d = DynTQuartic(factor * (mat @ ip.val), ip.shape[1]).entries()
+            else:
+                block = factor * np.einsum('ij,jklmn->iklmn', mat, np.asarray(ip))
+                nz = np.nonzero(block)
+                c, d = np.array(nz), block[nz]
+            return np.vstack((rows[c[0]], var[c[1]], var[c[2]], var[c[3]], var[c[4]])), d
+
+        out = []
         a_theta = np.linalg.inv(sig0 * np.asarray(aips._a) - np.asarray(aips._u))
         if par.T4LSBpa is not None:
-            blocks.append((theta, theta, par.T4LSBpa * np.einsum('ij,jklmn->iklmn', a_theta, aips._z)))
+            out.append(contract(theta, theta, a_theta, aips._z, par.T4LSBpa))
         if bips is not None:
             nsurf = nvar[3] if ocean else nvar[2]
             dT = np.arange(nsurf) + (par.variables_range[2] if ocean else par.variables_range[1]) + 1
             if par.T4LSBpgo is not None:
-                blocks.append((theta, dT, - par.T4LSBpgo * np.einsum('ij,jklmn->iklmn', a_theta, aips._v)))
+                out.append(contract(theta, dT, a_theta, aips._v, - par.T4LSBpgo))
             U_inv = np.linalg.inv(np.asarray(bips._U))
-            blocks.append((dT, theta, par.T4sbpa * np.einsum('ij,jklmn->iklmn', U_inv, bips._Z)))
-            blocks.append((dT, dT, - par.T4sbpgo * np.einsum('ij,jklmn->iklmn', U_inv, bips._V)))
-        return blocks
+            out.append(contract(dT, theta, U_inv, bips._Z, par.T4sbpa))
+            out.append(contract(dT, dT, U_inv, bips._V, - par.T4sbpgo))
+        return out
 
     def compute_tensor(self):
         par = self.params
@@ -324,10 +336,9 @@ class QgsTensorDynamicT(QgsTensor):
         nz = np.nonzero(full3)
         coords = [np.vstack((np.array(nz), np.zeros((2, len(nz[0])), dtype=np.int64)))]    # (i, j, k, 0, 0)
         data = [full3[nz]]
-        for rows, var, block in self._quartic_blocks():
-            bz = np.nonzero(block)
-            coords.append(np.vstack((rows[bz[0]], var[bz[1]], var[bz[2]], var[bz[3]], var[bz[4]])))
-            data.append(block[bz])
+        for c, d in self._quartic_entries():
+            coords.append(c)
+            data.append(d)
         coords, data = np.hstack(coords), np.concatenate(data)
         # Jacobian tensor: the un-simplified tensor plus its copies with axis 1 swapped with axes 2, 3, 4
         jc = [coords]

@@ -93,3 +93,20 @@ def params_a72():
     p.ground_params.set_orography(0.2, 1)
     p.atemperature_params.set_thetas(0.2, 0)
     return p
+
+
+def params_d106():
+    """Dynamic-temperature MAOOAM at 4x4 / 4x4 resolution (ndim 106, rank-5 tensor): beyond the register-resident kernels,
+    served by the LDS-resident JIT kernels with the derived monomials as LDS nodes; checked against the oracle (the
+    reference needs ~10 min of quadratures for this model, qgs_amd 1.5 s)."""
+    p = QgParams({'n': 1.5}, dynamic_T=True)
+    p.set_atmospheric_channel_fourier_modes(4, 4, mode="symbolic")
+    p.set_oceanic_basin_fourier_modes(4, 4, mode="symbolic")
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'hlambda': 15.06})
+    p.gotemperature_params.set_params({'gamma': 5.6e8})
+    p.atemperature_params.set_insolation(103., 0)
+    p.atemperature_params.set_insolation(103., 1)
+    p.gotemperature_params.set_insolation(310., 0)
+    p.gotemperature_params.set_insolation(310., 1)
+    return p

@@ -332,3 +332,37 @@ def test_lds_resident_kernels_on_a_second_tensor_ndim72():
         if names[1]:
             assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16'
     f.operands.release()
+
+
+def test_lds_resident_kernels_rank5_ndim106():
+    """Dynamic-T MAOOAM 4x4 / 4x4 (ndim 106, rank-5 tensor, 4 / 56 derived monomials): the LDS-resident stepper, tangent and
+    adjoint kernels with the derived monomials as LDS nodes, and the 4-factor generic kernels, against the oracle."""
+    from model_configs import params_d106
+    from oracle.oracle import OracleModel
+    from qgs_amd.functions.tendencies import create_tendencies
+    p = params_d106()
+    f, Df = create_tendencies(p)
+    assert f.ndim == 106 and f.coo.shape[1] == 5
+    m = f.hip_model()
+    ora = OracleModel(f.ndim, f.coo, f.val, Df.coo, Df.val)
+    vr = p.variables_range
+    rng = np.random.RandomState(106)
+    ic = rng.rand(70, f.ndim) * 0.01
+    ic[:, vr[0]] += 1.5                                   # T_a,0
+    ic[:, vr[2]] += 3.                                    # T_o,0
+    t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
+    ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
+    tg = rng.randn(9, f.ndim, 6)
+    for kind, names in ((1, ('gen_rk_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16'))):
+        m.set_kernel(kind)
+        assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14, kind
+        out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
+        assert m.last_kernel_info()['name'] == names[0]
+        assert rel_err(out, ref) < 1e-12, kind
+        for adj in (False, True):
+            rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
+            tr, fm = m.rk_tgls_integrate(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
+            assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (kind, adj)
+        if names[1]:
+            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16'
+    f.operands.release()
