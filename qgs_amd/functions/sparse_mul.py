@@ -1,4 +1,5 @@
-"""`sparse_mul3` / `sparse_mul2` with the reference's call signatures, evaluated on the GPU.
+"""`sparse_mul3` / `sparse_mul2` (rank-3 tensors) and `sparse_mul5` / `sparse_mul4` (rank-5 tensors of the dynamic-T / T4
+models) with the reference's call signatures, evaluated on the GPU.
 
 The reference's users write their own tendencies by hand from ``aotensor.tensor.coords.T`` / ``aotensor.tensor.data``
 (documentation user_guide.rst:437-458) and call these two functions (qgs/functions/sparse_mul.py:13-81).  Here the
@@ -24,13 +25,13 @@ def _model(kind, ndim, coo, val):
     key = (kind, ndim, hashlib.blake2b(coo.tobytes() + val.tobytes(), digest_size=16).digest())
     m = _CACHE.get(key)
     if m is None:
-        if kind == 'mul3':
+        if kind in ('mul3', 'mul5'):
             m = (_lib.HipModel(ndim, coo, val, None, None), None)
         else:
             # column 0 of the result, sum_k T_i0k v_k, is a tendencies evaluation of the entries with j == 0
             sel = coo[:, 1] == 0
             col0 = _lib.HipModel(ndim, coo[sel], val[sel], None, None) if sel.any() else None
-            zero = np.zeros((0, 3), dtype=np.int32), np.zeros(0)
+            zero = np.zeros((0, coo.shape[1]), dtype=np.int32), np.zeros(0)
             m = (_lib.HipModel(ndim, zero[0], zero[1], coo, val), col0)
         _CACHE[key] = m
         while len(_CACHE) > _CACHE_MAX:
@@ -78,4 +79,39 @@ def sparse_mul2(coo, val, vec):
     res[1:, 1:] = model.jacobian(vec[1:])
     if col0 is not None:
         res[1:, 0] = col0.tendencies(vec[1:])
+    return res
+
+
+def _same(vectors, what):
+    first = vectors[0]
+    for v in vectors[1:]:
+        if v is not first and not np.array_equal(v, first):
+            raise NotImplementedError('%s with different vectors is not available on the device' % what)
+    return first
+
+
+def sparse_mul5(coo, val, a, b, c, d):
+    """``res[i] = sum_n val[n] * a[j_n] * b[k_n] * c[l_n] * d[m_n]``, ``res[0] = 1`` (sparse_mul.py:123-158).
+    `coo` is (nnz, 5); the four vectors must be the same one (tendencies.py:100-103)."""
+    x = _same([_check_vec(v, nm) for v, nm in ((a, 'a'), (b, 'b'), (c, 'c'), (d, 'd'))], 'sparse_mul5')
+    n = x.shape[0] - 1
+    res = np.empty(n + 1)
+    res[0] = 1.
+    res[1:] = _model('mul5', n, coo, val)[0].tendencies(x[1:])
+    return res
+
+
+def sparse_mul4(coo, val, a, b, c):
+    """``res[i, j] = sum_n val[n] * a[k_n] * b[l_n] * c[m_n]`` -> (ndim+1, ndim+1) (sparse_mul.py:84-120), the three
+    vectors being the same one (tendencies.py:105-109)."""
+    x = _same([_check_vec(v, nm) for v, nm in ((a, 'a'), (b, 'b'), (c, 'c'))], 'sparse_mul4')
+    n = x.shape[0] - 1
+    coo = np.asarray(coo)
+    if (coo[:, 0] == 0).any():
+        raise NotImplementedError('entries in row 0 are not supported')
+    model, col0 = _model('mul4', n, coo, val)
+    res = np.zeros((n + 1, n + 1))
+    res[1:, 1:] = model.jacobian(x[1:])
+    if col0 is not None:
+        res[1:, 0] = col0.tendencies(x[1:])
     return res

@@ -236,6 +236,23 @@ def test_sparse_mul_entry_points_match_oracle():
         sparse_mul3(g['coo'], g['val'], xx, 2. * xx)
 
 
+def test_sparse_mul_rank5_entry_points_match_oracle():
+    """sparse_mul5 / sparse_mul4 (sparse_mul.py:84-158) on the dynamic-T tensor, evaluated on the device."""
+    from qgs_amd.functions.sparse_mul import sparse_mul4, sparse_mul5
+    from oracle import oracle
+    g = load_golden('d38')
+    x = g['fx_x'][2]
+    xx = np.concatenate(([1.], x))
+    r5 = sparse_mul5(g['coo'], g['val'], xx, xx, xx, xx)
+    assert r5.shape == (g.ndim + 1,) and r5[0] == 1. and rel_err(r5[1:], g['fx_f'][2]) < 1e-14
+    r4 = sparse_mul4(g['jcoo'], g['jval'], xx, xx, xx)
+    ref4 = oracle.sparse_mul4(g['jcoo'], g['jval'], xx, xx, xx)
+    assert r4.shape == ref4.shape and np.abs(r4 - ref4).max() < 1e-14 * np.abs(ref4).max()
+    assert np.abs(ref4[1:, 0]).max() > 0                      # column 0 (the j == 0 entries) is exercised
+    with pytest.raises(NotImplementedError):
+        sparse_mul5(g['coo'], g['val'], xx, xx, xx, 2. * xx)
+
+
 def test_dynamic_T_model_end_to_end():
     """QgParams(dynamic_T=True) -> quadrature inner products -> QgsTensorDynamicT -> rank-5 f / Df on the GPU ->
     RungeKuttaIntegrator / RungeKuttaTglsIntegrator, against the reference's outputs for the same model
