@@ -124,6 +124,59 @@ def _ptr(a):
     return a.ctypes.data_as(_vp) if a is not None else None
 
 
+class _PooledBlock(object):
+    """Owner of one result block: the ndarray handed to the caller has this object as its base, so the block returns
+    to the pool when the caller's last reference (array or view) goes away."""
+
+    def __init__(self, pool, store, shape):
+        self._pool, self._store = pool, store
+        self.__array_interface__ = {'shape': tuple(int(q) for q in shape), 'typestr': '<f8', 'version': 3,
+                                    'data': (store.ctypes.data, False)}
+
+    def __del__(self):
+        try:
+            self._pool._give_back(self._store)
+        except Exception:
+            pass
+
+
+class _ResultPool(object):
+    """Host memory of large results (ensemble trajectories, propagators), recycled.
+
+    A fresh 1.9 GB NumPy array costs ~150 ms of first-touch page faults inside the device-to-host copy (measured: 196 ms
+    per call for the full record of 65 536 members x 100 steps, of which the copy itself is 38 ms at 52 GB/s).  Results
+    are still *fresh arrays owned by the caller* -- a block is only reused after every array and view on it has been
+    garbage collected.  QGS_HOST_POOL_BYTES caps what the pool keeps (default 4 GiB, 0 disables it)."""
+
+    MIN_BYTES = 8 << 20
+
+    def __init__(self):
+        self._free = {}
+        self._held = 0
+        self._cap = int(os.environ.get('QGS_HOST_POOL_BYTES', str(4 << 30)))
+
+    def empty(self, shape):
+        n = int(np.prod(shape))
+        if n * 8 < self.MIN_BYTES or self._cap <= 0:
+            return np.empty(shape)
+        size = -(-n * 8 // (2 << 20)) * (2 << 20) // 8          # whole 2 MiB blocks, in doubles
+        lst = self._free.get(size)
+        if lst:
+            store = lst.pop()
+            self._held -= store.nbytes
+        else:
+            store = np.empty(size)
+        return np.asarray(_PooledBlock(self, store, shape))
+
+    def _give_back(self, store):
+        if self._held + store.nbytes <= self._cap:
+            self._free.setdefault(store.shape[0], []).append(store)
+            self._held += store.nbytes
+
+
+_RESULTS = _ResultPool()
+
+
 def _tensor_rank(coo, jcoo=None):
     """3 for the (nnz, 3) coordinate lists of QgsTensor, 5 for the (nnz, 5) ones of QgsTensorDynamicT / QgsTensorT4."""
     rank = int(coo.shape[1]) if coo.ndim == 2 else 0
@@ -215,14 +268,14 @@ class HipModel(object):
     def jacobian(self, x):
         x = _c(x)
         xb = x.reshape(-1, self.ndim)
-        out = np.empty((xb.shape[0], self.ndim, self.ndim))
+        out = _RESULTS.empty((xb.shape[0], self.ndim, self.ndim))
         _check(lib().qgs_jacobian(self._h, xb.shape[0], xb, out))
         return out[0] if x.ndim == 1 else out
 
     def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a):
         time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
         nrec = n_records(time, write_steps)
-        traj = np.empty((ic.shape[0], self.ndim, nrec))
+        traj = _RESULTS.empty((ic.shape[0], self.ndim, nrec))
         _check(lib().qgs_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
                                       len(b), b, c, a, traj))
         return traj
@@ -247,8 +300,8 @@ class HipModel(object):
         time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)
         nrec = n_records(time, write_steps)
         n_traj, n_tg = ic.shape[0], tg_ic.shape[2]
-        traj = np.empty((n_traj, self.ndim, nrec))
-        fm = np.empty((n_traj, self.ndim, n_tg, nrec))
+        traj = _RESULTS.empty((n_traj, self.ndim, nrec))
+        fm = _RESULTS.empty((n_traj, self.ndim, n_tg, nrec))
         _check(lib().qgs_rk_tgls_integrate(self._h, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
                                            int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
                                            traj, fm))

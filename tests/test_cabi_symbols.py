@@ -80,3 +80,29 @@ def test_package_never_imports_the_oracle():
                 if re.search(r'(^|\W)(import\s+oracle|from\s+oracle|libqgs_oracle|oracle/)', txt):
                     bad.append(os.path.join(root, fn))
     assert not bad, bad
+
+
+def test_result_pool_hands_out_fresh_arrays_and_recycles_released_ones():
+    """Large results come from recycled host blocks (no first-touch page faults in the device-to-host copy), but a block
+    is reused only after the caller dropped every array and view on it: results stay caller-owned, fresh arrays."""
+    import gc
+    import numpy as np
+    from qgs_amd import _lib
+    pool = _lib._ResultPool()
+    small = pool.empty((4, 36, 3))
+    assert small.base is None                                   # below the threshold: a plain NumPy array
+    a = pool.empty((2048, 36, 101))
+    a[:] = 1.
+    assert isinstance(a, np.ndarray) and a.flags['C_CONTIGUOUS'] and a.flags['WRITEABLE'] and a.shape == (2048, 36, 101)
+    addr = a.ctypes.data
+    b = pool.empty((2048, 36, 101))
+    assert b.ctypes.data != addr                                # a is still held by the caller
+    view = np.squeeze(a[:1])
+    del a
+    gc.collect()
+    assert pool.empty((2048, 36, 101)).ctypes.data != addr      # a view keeps the block out of the pool
+    del view
+    gc.collect()
+    c = pool.empty((2048, 36, 101))
+    assert c.ctypes.data == addr                                # released: recycled
+    assert _lib._f64p.from_param(c) is not None                 # accepted by the ctypes signatures
