@@ -668,15 +668,25 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
 
 // Tangent-linear / adjoint propagation along stored stage states.  One lane per (member, column):
 // lane l = col*ld + member; tangent arrays are F[mode][col][member] = element d*(n_tg*ld) + l.
+// share_x = C > 1: a workgroup of C wavefronts handles C columns of the same 64 members.  The stage states they all need
+// (ndim values per member and stage, read from the record the trajectory pass wrote) go through LDS: every wavefront
+// fetches 1/C of the NEXT stage's state at the start of a stage (the loads fly during the ~800 FMAs of the stage) and
+// parks it in the other half of a double buffer at the end; one barrier per stage.  The plain kernel issues its ndim
+// loads at the top of every stage and waits for them with nothing else to do (lone wavefront per SIMD: PMC, 19 % of
+// the cycles in s_waitcnt), and reads every stage state once per column.
 void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
                      const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt,
-                     const std::vector<std::pair<int, int>> &der)
+                     const std::vector<std::pair<int, int>> &der, int share_x = 1)
 {
     std::ostringstream o;
     KTable tables[2];
-    const std::string kname = "qgs_spec_tgl_s" + std::to_string(S);
-    o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") qgs_spec_tgl_s" << S << "(\n"
+    const int C = std::max(1, share_x);
+    const bool shx = C > 1;
+    const std::string kname = shx ? "qgs_spec_tglx" + std::to_string(C) + "_s" + std::to_string(S) : "qgs_spec_tgl_s" + std::to_string(S);
+    o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)";
+    if (shx) o << ", " << C << " columns per workgroup sharing the stage states through LDS";
+    o << "\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * C << ", " << opt.min_waves_per_simd << ") " << kname << "(\n"
       << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
       << "    f64* __restrict__ w_out_p,       // after step `step_end-1` (may be null)\n"
       << "    f64* __restrict__ rec,           // F[record][mode][col][member]\n"
@@ -688,19 +698,42 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     // stage) live in LDS, [row][lane], so that x, w_in and w_out (216 VGPRs) fit the 256 architectural registers
     // without accumulation-register moves or scratch.  36.9 KB per wavefront-workgroup: 4 per CU = one per SIMD,
     // which is what the 400+-register variant gets as well.
-    const bool park = opt.tgl_park_lds && S > 1;
+    const bool park = opt.tgl_park_lds && S > 1 && !shx;
     if (park) o << "    __shared__ f64 vsh[" << ndim << "][QGS_WAVE];\n    __shared__ f64 accsh[" << ndim << "][QGS_WAVE];\n";
-    o << "    const int lane = threadIdx.x;\n";
-    o << "    const i64 L = n_tg * ld;\n"
-      << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
-      << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
-      << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
-      << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
+    if (shx) {
+        o << "    __shared__ f64 xsh[2][" << ndim << "][QGS_WAVE];     // stage states of the 64 members, double-buffered\n";
+        o << "    const int lane = threadIdx.x & 63;\n"
+          << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+          << "    const i64 L = n_tg * ld;\n"
+          << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;          // grid.x = ld / 64: m0 < ld\n"
+          << "    const i64 c0 = (i64)blockIdx.y * " << C << " + wave;\n"
+          << "    const bool live = (c0 < n_tg) && (m0 < n_traj);\n"
+          << "    const i64 l = (c0 < n_tg ? c0 : n_tg - 1) * ld + m0;       // wavefronts past the last column shadow it (never store)\n"
+          << "    const i64 m = m0 < n_traj ? m0 : n_traj - 1;\n"
+          << "    const i64 g_total = (step_end - step_begin) * " << S << ";\n";
+    } else {
+        o << "    const int lane = threadIdx.x;\n";
+        o << "    const i64 L = n_tg * ld;\n"
+          << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+          << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
+          << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
+          << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
+    }
     o << "    " << decl_list("v", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
     if (park) for (int d = 1; d <= ndim; ++d) o << "    vsh[" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    if (shx) {
+        // first stage state: wavefront w brings the modes w, w + C, w + 2C, ... (slot q holds mode w + q*C)
+        o << "    if (g_total > 0) {\n        const f64* sp0 = stages + m;\n";
+        for (int q = 0; q * C < ndim; ++q) {
+            const bool guard = (q + 1) * C > ndim;
+            o << "        " << (guard ? "if (wave + " + std::to_string(q * C) + " < " + std::to_string(ndim) + ") " : "")
+              << "xsh[0][wave + " << q * C << "][lane] = sp0[(i64)(wave + " << q * C << ") * ld];\n";
+        }
+        o << "    }\n    __syncthreads();\n";
+    }
     o << "    QGS_REC_INIT\n";
     o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
     o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
@@ -720,8 +753,21 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         o << "        {   // stage " << st << "\n";
         o << "            const f64 hb = dt * tb" << st << " * inverse;\n";      // inverse = +-1: exact
         if (!last) o << "            const f64 ha = dt * ta" << st << " * inverse;\n";
-        o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-        for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+        if (shx) {
+            o << "            const i64 g = (ti - step_begin) * " << S << " + " << st << ";\n"
+              << "            const int pb = (int)(g & 1);\n"
+              << "            const f64* spn = stages + (g + 1 < g_total ? g + 1 : g) * " << ndim << " * ld + m;   // next stage state\n";
+            for (int q = 0; q * C < ndim; ++q) {
+                const bool guard = (q + 1) * C > ndim;
+                o << "            f64 xn" << q << " = 0.0;\n";
+                o << "            " << (guard ? "if (wave + " + std::to_string(q * C) + " < " + std::to_string(ndim) + ") " : "")
+                  << "xn" << q << " = spn[(i64)(wave + " << q * C << ") * ld];\n";
+            }
+            for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = xsh[pb][" << (d - 1) << "][lane];\n";
+        } else {
+            o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+            for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+        }
         emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
             o << "            if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
@@ -754,6 +800,14 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
             o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group) : so.str());
             g_ktab = nullptr;
             o << "            }\n";
+        }
+        if (shx) {
+            for (int q = 0; q * C < ndim; ++q) {
+                const bool guard = (q + 1) * C > ndim;
+                o << "            " << (guard ? "if (wave + " + std::to_string(q * C) + " < " + std::to_string(ndim) + ") " : "")
+                  << "xsh[pb ^ 1][wave + " << q * C << "][lane] = xn" << q << ";\n";
+            }
+            o << "            __syncthreads();\n";
         }
         o << "        }\n";
     }
@@ -1494,6 +1548,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
     case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves);
     case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves);
+    case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
     }
     return "";
 }
@@ -1519,6 +1574,10 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::Tgl:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;
+    case Kernel::TglX:
+        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j,
+                        opt.tgl_share_x);
+        break;
     case Kernel::TglSplit:
         emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
                               opt.tgl_split, opt);
@@ -1543,6 +1602,7 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
         if (have_jac) {
             l.push_back({Kernel::RkStages, S});
             l.push_back({Kernel::Tgl, S});
+            if (opt.tgl_share_x > 1) l.push_back({Kernel::TglX, S});
             if (opt.tgl_split > 1) l.push_back({Kernel::TglSplit, S});
         }
     }

@@ -29,6 +29,8 @@ struct CodegenOptions {
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
+    int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
+                               // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
     bool nt_record = false;    // plain stepper: non-temporal stores for the records
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
@@ -68,10 +70,12 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //                            workgroup, stage state and tangent vector in LDS
 //   qgs_spec_tgl_s<S>        tangent / adjoint propagation, one lane per (member, column)
 //                                                                       (integrate.py:226-231, 555-614)
+//   qgs_spec_tglx<C>_s<S>    same, C columns of 64 members per workgroup sharing the (double-buffered, prefetched) stage
+//                            states through LDS
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

@@ -474,6 +474,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) cg.ktab_group = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK")) cg.tgl_park_lds = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_X")) cg.tgl_share_x = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
@@ -1031,15 +1032,31 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         } else if (spec && m->spec_jac_possible) {
             // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
             bool tgl_split = m->cg.tgl_split > 1 && m->ndim >= 2 * m->cg.tgl_split;
-            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
+            // shared-stage-state kernel: C columns of the same 64 members per workgroup, stage states prefetched through LDS
+            const int C = m->cg.tgl_share_x;
+            // Measured (tools/tgls_scale.py, MAOOAM-36, 36 columns, 10 steps): while the stage record of a chunk stays in the
+            // 256 MB Infinity Cache every column can afford to read it (one-wavefront kernel 3-8 % ahead: 1.11 vs 1.21 ms at
+            // 16 384 members, 189 MB); beyond that the re-reads go to HBM and sharing wins 1.5x (65 536 members, 755 MB:
+            // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
+            size_t share_min = (size_t)256 << 20;
+            if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) share_min = (size_t)std::atoll(e) << 20;
+            bool share_x = !tgl_split && C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
+                           (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
+                           stage_bytes_per_step * (size_t)(end - begin) >= share_min;
+            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) {
+                tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
+                share_x = share_x && std::strcmp(e, "plain") != 0;
+            }
             hipFunction_t f2;
             std::string n2;
-            if (get_function(m, tgl_split ? qgs::Kernel::TglSplit : qgs::Kernel::Tgl, s, &f2, &n2)) return -1;
+            if (get_function(m, tgl_split ? qgs::Kernel::TglSplit : (share_x ? qgs::Kernel::TglX : qgs::Kernel::Tgl), s, &f2, &n2)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
             if (tgl_split) {
                 HIPCHK(hipModuleLaunchKernel(f2, (unsigned)((L + 63) / 64), 1, 1, 64 * m->cg.tgl_split, 1, 1, 0, st, a2, nullptr));
+            } else if (share_x) {
+                HIPCHK(hipModuleLaunchKernel(f2, (unsigned)(ld / 64), (unsigned)((n_tg + C - 1) / C), 1, 64 * C, 1, 1, 0, st, a2, nullptr));
             } else if (launch(f2, L, st, a2)) return -1;
         } else {
             qgs::launch_gen_tgl(Jrow, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);

@@ -281,7 +281,9 @@ def test_linearity_of_tangent_model(models):
 
 @pytest.mark.parametrize('env', [{'QGS_HIP_RK_VARIANT': 'plain'}, {'QGS_HIP_RK_VARIANT': 'split'},
                                  {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '2'}, {'QGS_HIP_KTAB_GROUP': '0'},
-                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
+                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'},
+                                 {'QGS_HIP_TGL_VARIANT': 'plain', 'QGS_HIP_WAVE_MAX_TRAJ': '0'},
+                                 {'QGS_HIP_TGL_SHARE_X': '5', 'QGS_HIP_TGL_SHARE_MIN_MB': '0', 'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
 def test_kernel_variants_agree_with_oracle(monkeypatch, env):
     """Every code-generation / kernel-selection variant (plain one-wave stepper, row split 2 and 3, literal
     coefficients, ungrouped terms, simple generic kernel) against the oracle on the same inputs."""
@@ -303,6 +305,40 @@ def test_kernel_variants_agree_with_oracle(monkeypatch, env):
         tr, fm = m.rk_tgls_integrate(t[:8], ic[:3], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], True, -1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (env, kind)
     m.close()
+
+
+@pytest.mark.parametrize('n_traj,n_tg', [(70, 5), (64, 36), (1, 2)])
+def test_shared_stage_state_tangent_kernel(models, n_traj, n_tg):
+    """`qgs_spec_tglx4_s<S>`: four columns of the same 64 members per workgroup, stage states prefetched through LDS.
+    Ragged member blocks and column groups (wavefronts past the last column shadow it), records, backward adjoint with
+    `inverse`, a 2-stage tableau; against the oracle and bitwise against the one-wavefront kernel it replaces."""
+    from oracle.oracle import OracleModel
+    import os
+    os.environ['QGS_HIP_TGL_SHARE_MIN_MB'] = '0'          # in production only stage records beyond the Infinity Cache take it
+    g, m = load_golden('m36'), models('m36')
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    rng = np.random.RandomState(1000 * n_traj + n_tg)
+    ic = rng.rand(n_traj, g.ndim) * 0.01
+    tg = rng.randn(n_traj, g.ndim, n_tg)
+    t = np.concatenate((np.arange(0., 0.7, 0.1), [0.7]))
+    b2, c2 = np.array([0., 1.]), np.array([0., .5])
+    a2 = np.zeros((2, 2)); a2[1, 0] = .5
+    cases = [(1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.), (-1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.), (1, 0, b2, c2, a2, False, 1.)]
+    m.set_kernel(2)
+    for d, ws, b, c, a, adj, inv in cases:
+        rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t, ic, tg, d, ws, b, c, a, adj, inv)
+        tr, fm = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
+        assert m.last_kernel_info()['name'] == 'qgs_spec_tglx4_s%d' % len(b)
+        assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (d, ws, adj)
+        os.environ['QGS_HIP_TGL_VARIANT'] = 'plain'
+        try:
+            _, fm1 = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
+            assert m.last_kernel_info()['name'] == 'qgs_spec_tgl_s%d' % len(b)
+        finally:
+            del os.environ['QGS_HIP_TGL_VARIANT']
+        assert np.array_equal(fm, fm1)                       # same arithmetic, only the way the stage states arrive differs
+    del os.environ['QGS_HIP_TGL_SHARE_MIN_MB']
+    m.set_kernel(0)
 
 
 def test_lds_resident_kernels_on_a_second_tensor_ndim72():
