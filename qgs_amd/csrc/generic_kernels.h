@@ -26,6 +26,18 @@ struct DevTensor {
     const uint32_t *idx2;    // nnz or null
 };
 
+// Derived monomials of a rank-5 model for the kernels that keep the stage state in LDS slots (wavefront-per-trajectory
+// kernels): slot `slot[e]` = slot `a[e]` * slot `b[e]`, evaluated after every stage-state update.  The products are
+// sorted into levels (level 1 uses variables only, level 2 may use level 1, ...): within a level every thread forms at
+// most WAVE_DER_PER products, which it keeps (a, b, slot) in registers for the whole run; a barrier separates the levels.
+// n_levels == 0: rank 3.
+constexpr int WAVE_DER_LEVELS = 3, WAVE_DER_PER = 2;
+struct DerivedChains {
+    int n_levels;
+    int level_ptr[WAVE_DER_LEVELS + 1];     // products of level l are [level_ptr[l], level_ptr[l + 1])
+    const int32_t *a, *b, *slot;
+};
+
 struct RkArgs {
     int ndim, s;
     int64_t n_traj, ld;
@@ -81,16 +93,20 @@ hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const doub
 // ndim 36).  Here a trajectory owns a whole workgroup: lane = tensor row, the stage state lives in LDS, each lane
 // keeps its row's terms in registers (rows of at most 16 terms) or streams them from memory.
 // Tensor = the CSR `DevTensor` (idx = j<<16 | k).  Sub-diagonal tableaus; tab_spec = b[s], a[1][0], a[2][1], ...
-bool wave_supported(int ndim);
+// n_slots = ndim + number of derived monomials.  For rank-5 models T is the REDUCED tensor (codegen.h reduce_polynomial:
+// two factors per term over the extended index space) and D lists the derived monomials.
+bool wave_supported(int n_slots);
 hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArgs &p, const double *y_in, double *y_out,
-                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st);
+                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st,
+                              const DerivedChains &D = DerivedChains{0, {0, 0, 0, 0}, nullptr, nullptr, nullptr});
 
 // Same idea for the tangent / adjoint model: one workgroup per (member, tangent column), lane = row of J (or J^T),
 // the row's entries (w index, x index, value) in registers when there are at most 32, x and w staged in LDS.
 // Jrow as for launch_gen_tgl; stages as written by the trajectory pass.
 hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const RkArgs &p, int64_t n_tg, double inverse,
                                const double *w_in, double *w_out, double *rec, const double *stages, const double *dtime,
-                               const double *tab_spec, hipStream_t st);
+                               const double *tab_spec, hipStream_t st,
+                               const DerivedChains &D = DerivedChains{0, {0, 0, 0, 0}, nullptr, nullptr, nullptr});
 
 // Batched Householder QR (LAPACK dgeqr2 + dorg2r conventions: R_jj = -sign(a_jj)*||.||) of one
 // (n_rows x n_cols) matrix per member in the device layout A[row][col][member]; A is overwritten by Q,

@@ -366,12 +366,46 @@ __device__ __forceinline__ double wave_row_eval(const char *xb, const uint32_t *
     return k0 + k1;
 }
 
+// Derived monomials of the stage state (rank-5 models), see generic_kernels.h DerivedChains.  The (a, b, slot) triples of
+// this thread are loaded once; unused entries multiply slot 0 by itself into a scratch slot.
+constexpr int WAVE_DER_SCRATCH = WAVE_XS_STRIDE - 1;
+struct WaveDerived {
+    int a[WAVE_DER_LEVELS][WAVE_DER_PER], b[WAVE_DER_LEVELS][WAVE_DER_PER], s[WAVE_DER_LEVELS][WAVE_DER_PER];
+    int n_levels;
+    __device__ __forceinline__ void load(const DerivedChains &D)
+    {
+        n_levels = D.n_levels;
+#pragma unroll
+        for (int l = 0; l < WAVE_DER_LEVELS; ++l)
+#pragma unroll
+            for (int q = 0; q < WAVE_DER_PER; ++q) {
+                const int e = D.level_ptr[l] + (int)threadIdx.x + q * (int)blockDim.x;
+                const bool ok = l < D.n_levels && e < D.level_ptr[l + 1];
+                a[l][q] = ok ? D.a[e] : 0;
+                b[l][q] = ok ? D.b[e] : 0;
+                s[l][q] = ok ? D.slot[e] : WAVE_DER_SCRATCH;
+            }
+    }
+    // call with the stage state complete in xbuf (after a barrier); ends with a barrier
+    __device__ __forceinline__ void eval(double *xbuf) const
+    {
+#pragma unroll
+        for (int l = 0; l < WAVE_DER_LEVELS; ++l) {
+            if (l < n_levels) {
+#pragma unroll
+                for (int q = 0; q < WAVE_DER_PER; ++q) xbuf[s[l][q]] = xbuf[a[l][q]] * xbuf[b[l][q]];
+                __syncthreads();
+            }
+        }
+    }
+};
+
 template <int NWV, int REG_TERMS, int S>
 __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkArgs p, const double *__restrict__ y_in,
                                                                double *__restrict__ y_out, double *__restrict__ rec,
                                                                double *__restrict__ stages,
                                                                const double *__restrict__ dtime,
-                                                               const double *__restrict__ tab)
+                                                               const double *__restrict__ tab, DerivedChains D)
 {
     __shared__ double xs[2 * WAVE_XS_STRIDE];              // two stage buffers, slot 0 of each = eta_0 = 1
     const int ndim = p.ndim, s = (S > 0) ? S : p.s;
@@ -401,7 +435,10 @@ __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkAr
     double y = active ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
     if (threadIdx.x == 0) { xs[0] = 1.0; xs[WAVE_XS_STRIDE] = 1.0; }
     if (active) xs[row] = y;
+    WaveDerived wd;
+    wd.load(D);
     __syncthreads();
+    wd.eval(xs);
 
     int64_t iw = 0, next_rec = -1;
     if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
@@ -430,6 +467,7 @@ __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkAr
                 if (active) xo[row] = xn;
                 if (last) y = acc;
                 __syncthreads();
+                wd.eval(xo);
             }
             if (S % 2) cur ^= 1;
         } else {
@@ -445,6 +483,7 @@ __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkAr
                 if (last) y = acc;
                 cur ^= 1;
                 __syncthreads();
+                wd.eval(xo);
             }
         }
     }
@@ -456,13 +495,13 @@ __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkAr
 
 template <int NWV, int REG_TERMS>
 hipError_t launch_wave(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
-                       const double *dtime, const double *tab, hipStream_t st)
+                       const double *dtime, const double *tab, hipStream_t st, const DerivedChains &D)
 {
     const dim3 grid((unsigned)p.n_traj), block(64 * NWV);
     switch (p.s) {
-    case 2: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 2>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
-    case 4: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 4>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
-    default: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 0>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab); break;
+    case 2: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 2>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab, D); break;
+    case 4: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 4>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab, D); break;
+    default: hipLaunchKernelGGL((gen_rk_wave_kernel<NWV, REG_TERMS, 0>), grid, block, 0, st, T, p, y_in, y_out, rec, stages, dtime, tab, D); break;
     }
     return hipGetLastError();
 }
@@ -495,9 +534,10 @@ template <int NWV, int REG_TERMS>
 __global__ void __launch_bounds__(64 * NWV) gen_tgl_wave_kernel(DevTensor J, RkArgs p, int64_t n_tg, double inverse,
                                                                 const double *__restrict__ w_in, double *__restrict__ w_out,
                                                                 double *__restrict__ rec, const double *__restrict__ stages,
-                                                                const double *__restrict__ dtime, const double *__restrict__ tab)
+                                                                const double *__restrict__ dtime, const double *__restrict__ tab,
+                                                                DerivedChains D)
 {
-    __shared__ double xsh[WAVE_XS_STRIDE];                 // stage state of the member, slot 0 = 1
+    __shared__ double xsh[WAVE_XS_STRIDE];                 // stage state of the member (+ derived monomials), slot 0 = 1
     __shared__ double wsh[2 * WAVE_XS_STRIDE];             // tangent stage vector, double buffered (slot 0 unused = 0)
     const int ndim = p.ndim, s = p.s;
     const int row = (int)threadIdx.x + 1;
@@ -521,6 +561,8 @@ __global__ void __launch_bounds__(64 * NWV) gen_tgl_wave_kernel(DevTensor J, RkA
     double v = active ? w_in[(int64_t)(row - 1) * L + l] : 0.0;
     if (threadIdx.x == 0) { xsh[0] = 1.0; wsh[0] = 0.0; wsh[WAVE_XS_STRIDE] = 0.0; }
     if (active) wsh[row] = v;
+    WaveDerived wd;
+    wd.load(D);
     int64_t iw = 0, next_rec = -1;
     if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
     int cur = 0;
@@ -534,6 +576,7 @@ __global__ void __launch_bounds__(64 * NWV) gen_tgl_wave_kernel(DevTensor J, RkA
         for (int st = 0; st < s; ++st) {
             if (active) xsh[row] = stages[((ti - p.step_begin) * s + st) * AS + (int64_t)(row - 1) * ld + m];
             __syncthreads();                               // x of this stage and w written by the previous stage visible
+            wd.eval(xsh);
             const char *wb = (const char *)(wsh + cur * WAVE_XS_STRIDE);
             const double k = inverse * wave_wx_eval<REG_TERMS>((const char *)xsh, wb, wo, xo, cf, J, e0, e1);
             acc = __builtin_fma(dt * tab[st], k, acc);
@@ -716,16 +759,18 @@ void launch_gen_tgl(const DevTensor &Jrow, const RkArgs &p, int64_t n_tg, double
                        w_out, rec, stages, work, dtime, tab_full);
 }
 
-bool wave_supported(int ndim) { return ndim <= 256; }
+bool wave_supported(int n_slots) { return n_slots <= 256; }
 
 hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArgs &p, const double *y_in, double *y_out,
-                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st)
+                              double *rec, double *stages, const double *dtime, const double *tab_spec, hipStream_t st,
+                              const DerivedChains &D)
 {
     const int nwv = (p.ndim + 63) / 64;
 #define QGS_WAVE_CASE(N)                                                                                          \
     if (nwv == N) {                                                                                               \
-        if (max_row_terms <= 16) return launch_wave<N, 16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);   \
-        return launch_wave<N, 0>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st);                             \
+        if (max_row_terms <= 16) return launch_wave<N, 16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st, D); \
+        if (max_row_terms <= 32) return launch_wave<N, 32>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st, D); \
+        return launch_wave<N, 0>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st, D);                           \
     }
     QGS_WAVE_CASE(1)
     QGS_WAVE_CASE(2)
@@ -737,7 +782,7 @@ hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArg
 
 hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const RkArgs &p, int64_t n_tg, double inverse,
                                const double *w_in, double *w_out, double *rec, const double *stages, const double *dtime,
-                               const double *tab_spec, hipStream_t st)
+                               const double *tab_spec, hipStream_t st, const DerivedChains &D)
 {
     const int nwv = (p.ndim + 63) / 64;
     const dim3 grid((unsigned)(p.n_traj * n_tg));
@@ -745,10 +790,10 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
     if (nwv == N) {                                                                                                      \
         if (max_row_terms <= 32)                                                                                         \
             hipLaunchKernelGGL((gen_tgl_wave_kernel<N, 32>), grid, dim3(64 * N), 0, st, Jrow, p, n_tg, inverse, w_in, w_out, rec, \
-                               stages, dtime, tab_spec);                                                                 \
+                               stages, dtime, tab_spec, D);                                                              \
         else                                                                                                             \
             hipLaunchKernelGGL((gen_tgl_wave_kernel<N, 0>), grid, dim3(64 * N), 0, st, Jrow, p, n_tg, inverse, w_in, w_out, rec, \
-                               stages, dtime, tab_spec);                                                                 \
+                               stages, dtime, tab_spec, D);                                                              \
         return hipGetLastError();                                                                                        \
     }
     QGS_TGLW_CASE(1)

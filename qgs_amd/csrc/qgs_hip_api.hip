@@ -248,6 +248,30 @@ struct qgs_model {
     qgs::Derived der;
     int64_t nnz_in = 0, jnnz_in = 0;
     DevCsr dT, dJ_by_i, dJ_by_j;
+    // rank 5: the reduced tensors (two factors per term over variables + derived monomials) and the derived chains, for
+    // the wavefront-per-trajectory kernels (generic_kernels.h DerivedChains); rank 3: unused, the kernels take dT / dJ_*
+    DevCsr dT_red, dJ_red_by_i, dJ_red_by_j;
+    int32_t *d_chain_t = nullptr, *d_chain_j = nullptr;     // [a | b | slot] packed, products sorted by level
+    int n_der_t = 0, n_der_j = 0, n_lev_t = 0, n_lev_j = 0;
+    int lev_ptr_t[qgs::WAVE_DER_LEVELS + 1] = {0, 0, 0, 0}, lev_ptr_j[qgs::WAVE_DER_LEVELS + 1] = {0, 0, 0, 0};
+    bool wave_der_ok_t = true, wave_der_ok_j = true;        // the derived monomials fit the wave kernels' level scheme
+    qgs::DerivedChains chains(bool jac) const
+    {
+        qgs::DerivedChains D{0, {0, 0, 0, 0}, nullptr, nullptr, nullptr};
+        const int32_t *b = jac ? d_chain_j : d_chain_t;
+        const int n = jac ? n_der_j : n_der_t;
+        if (n == 0) return D;
+        D.n_levels = jac ? n_lev_j : n_lev_t;
+        for (int l = 0; l <= qgs::WAVE_DER_LEVELS; ++l) D.level_ptr[l] = jac ? lev_ptr_j[l] : lev_ptr_t[l];
+        D.a = b; D.b = b + n; D.slot = b + 2 * n;
+        return D;
+    }
+    qgs::DevTensor wave_T() const { return rank == 3 ? dT.view() : dT_red.view(); }
+    qgs::DevTensor wave_J(bool adjoint) const
+    {
+        if (rank == 3) return adjoint ? dJ_by_j.view() : dJ_by_i.view();
+        return adjoint ? dJ_red_by_j.view() : dJ_red_by_i.view();
+    }
     // regrouped tendencies tensor for the tiled generic stepper (generic_kernels.h TiledTensor)
     int32_t *t_row_term = nullptr;
     uint32_t *t_term_joff = nullptr, *t_term_koff = nullptr;
@@ -381,6 +405,64 @@ int upload_tiled(qgs_model *m, const std::vector<Entry> &Tr)
     return 0;
 }
 
+// Derived monomials sorted into levels for the wave kernels (generic_kernels.h DerivedChains).  *ok = false when the
+// scheme does not fit (more than WAVE_DER_LEVELS levels or more products in a level than the workgroup can hold).
+int upload_levels(int ndim, const std::vector<std::pair<int, int>> &der, int32_t **d_out, int *n_levels, int *level_ptr, bool *ok)
+{
+    const int nd = (int)der.size();
+    std::vector<int> level(nd, 1);
+    int nl = nd ? 1 : 0;
+    for (int n = 0; n < nd; ++n) {                           // a derived value only refers to earlier ones
+        for (int f : {der[n].first, der[n].second}) if (f > ndim) level[n] = std::max(level[n], level[f - ndim - 1] + 1);
+        nl = std::max(nl, level[n]);
+    }
+    const int threads = 64 * ((ndim + 63) / 64);
+    *ok = nl <= qgs::WAVE_DER_LEVELS;
+    std::vector<int32_t> a, b, slot;
+    for (int l = 0; l <= qgs::WAVE_DER_LEVELS; ++l) level_ptr[l] = 0;
+    for (int l = 1; l <= std::min(nl, (int)qgs::WAVE_DER_LEVELS); ++l) {
+        for (int n = 0; n < nd; ++n)
+            if (level[n] == l) { a.push_back(der[n].first); b.push_back(der[n].second); slot.push_back(ndim + 1 + n); }
+        level_ptr[l] = (int)a.size();
+        if (level_ptr[l] - level_ptr[l - 1] > threads * qgs::WAVE_DER_PER) *ok = false;
+    }
+    for (int l = nl + 1; l <= qgs::WAVE_DER_LEVELS; ++l) level_ptr[l] = level_ptr[std::max(nl, 0)];
+    *n_levels = std::min(nl, (int)qgs::WAVE_DER_LEVELS);
+    if (!*ok) { a.clear(); b.clear(); slot.clear(); }
+    std::vector<int32_t> packed(a);
+    packed.resize(3 * (size_t)nd, 0);
+    if (*ok) {
+        std::copy(b.begin(), b.end(), packed.begin() + nd);
+        std::copy(slot.begin(), slot.end(), packed.begin() + 2 * (size_t)nd);
+    }
+    return upload_vec(packed, d_out);
+}
+
+// rank 5: reduced tensors for the wavefront-per-trajectory kernels
+int upload_reduced(qgs_model *m)
+{
+    const int ndim = m->ndim;
+    auto pack = [](int a, int b) { return ((uint32_t)a << 16) | (uint32_t)b; };
+    std::vector<Entry> Tr, Jr;
+    for (const auto &t : m->T) if (t.i >= 1) Tr.push_back(Entry{t.i, t.j, t.k, 0, 0, t.v});
+    for (const auto &t : m->J) if (t.i >= 1 && t.j >= 1) Jr.push_back(Entry{t.i, t.j, t.k, 0, 0, t.v});
+    m->max_row_terms = m->max_jrow_terms = 0;
+    {
+        std::vector<int> cnt(ndim + 2, 0), ci(ndim + 2, 0), cj(ndim + 2, 0);
+        for (const auto &t : Tr) m->max_row_terms = std::max(m->max_row_terms, ++cnt[t.i]);
+        for (const auto &t : Jr) m->max_jrow_terms = std::max(m->max_jrow_terms, std::max(++ci[t.i], ++cj[t.j]));
+    }
+    HostCsr hT = build_csr(ndim, Tr, false, [](const Entry &t) { return t.i; }, [&](const Entry &t) { return pack(t.j, t.k); });
+    HostCsr hJi = build_csr(ndim, Jr, false, [](const Entry &t) { return t.i; }, [&](const Entry &t) { return pack(t.j, t.k); });
+    HostCsr hJj = build_csr(ndim, Jr, false, [](const Entry &t) { return t.j; }, [&](const Entry &t) { return pack(t.i, t.k); });
+    if (upload_csr(hT, m->dT_red) || upload_csr(hJi, m->dJ_red_by_i) || upload_csr(hJj, m->dJ_red_by_j)) return -1;
+    m->n_der_t = (int)m->der.t.size();
+    m->n_der_j = (int)m->der.j.size();
+    if (upload_levels(ndim, m->der.t, &m->d_chain_t, &m->n_lev_t, m->lev_ptr_t, &m->wave_der_ok_t)) return -1;
+    if (upload_levels(ndim, m->der.j, &m->d_chain_j, &m->n_lev_j, m->lev_ptr_j, &m->wave_der_ok_j)) return -1;
+    return 0;
+}
+
 void free_csr(DevCsr &d)
 {
     if (d.rowptr) (void)hipFree(d.rowptr);
@@ -497,10 +579,11 @@ bool use_spec(const qgs_model *m, int s, const double *a)
 // DESIGN.md 3.5) it beats one-member-per-lane because the lanes of the few wavefronts would do all rows serially
 bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
 {
-    if (m->kernel_kind != 0 || m->rank != 3) return false;  // explicit generic / specialised request; rank-3 tensors only
-    int64_t limit = (m->max_row_terms <= 16) ? 2048 : 256;   // measured crossovers (tools/latency_bench.py)
+    if (m->kernel_kind != 0) return false;                 // explicit generic / specialised request
+    int64_t limit = (m->max_row_terms <= 16) ? 2048 : (m->max_row_terms <= 32 ? 1024 : 256);   // measured crossovers (tools/latency_bench.py)
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
-    return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+    return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.t.size()) && m->wave_der_ok_t &&
+           qgs::tableau_is_subdiagonal(s, a);
 }
 
 // below this many (member, column) pairs the wavefront-per-pair kernel would be preferred to the LDS-resident tangent
@@ -515,10 +598,11 @@ int64_t lds_tgl_min_pairs()
 // against the simple generic kernel (large ndim, latency-bound at ~350 ms per 10 steps) up to ~16k pairs
 bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
 {
-    if (m->kernel_kind != 0 || m->rank != 3) return false;
+    if (m->kernel_kind != 0) return false;
     int64_t limit = m->spec_possible ? 4096 : 16384;
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
-    return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
+    return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.j.size()) && m->wave_der_ok_j &&
+           qgs::tableau_is_subdiagonal(s, a);
 }
 
 // JIT LDS-resident stepper for systems beyond the register file (codegen.cpp emit_rk_lds_kernel).  Compiling it takes
@@ -716,6 +800,7 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     HostCsr hJj = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.j; }, [&](const Entry &t) { return pack(t.i, t.k); });
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
     if (!r5 && upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
+    if (r5 && upload_reduced(m)) { qgs_model_destroy(m); return -1; }
     classify_model(m);
     apply_env_options(m->cg);
     if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
@@ -735,6 +820,9 @@ int qgs_model_destroy(qgs_model *m)
     (void)hipSetDevice(m->device);
     for (auto &kv : m->modules) (void)hipModuleUnload(kv.second);
     free_csr(m->dT); free_csr(m->dJ_by_i); free_csr(m->dJ_by_j);
+    free_csr(m->dT_red); free_csr(m->dJ_red_by_i); free_csr(m->dJ_red_by_j);
+    if (m->d_chain_t) (void)hipFree(m->d_chain_t);
+    if (m->d_chain_j) (void)hipFree(m->d_chain_j);
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
@@ -899,7 +987,7 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
     if (use_wave(m, n_traj, s, a)) {
         // small ensemble: one workgroup per trajectory, lane = tensor row (latency-optimised)
         qgs::RkArgs pw{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
-        HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pw, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
+        HIPCHK(qgs::launch_gen_rk_wave(m->wave_T(), m->max_row_terms, pw, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st, m->chains(false)));
         note_kernel(m, "gen_rk_wave_kernel", nullptr);
         return 0;
     }
@@ -1002,7 +1090,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
         double inv = inverse;
         if (use_wave(m, n_traj, s, a)) {                  // few members: latency-optimised, lane = tensor row
-            HIPCHK(qgs::launch_gen_rk_wave(m->dT.view(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st));
+            HIPCHK(qgs::launch_gen_rk_wave(m->wave_T(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st, m->chains(false)));
         } else if (m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a)) {
             if (launch_rk_lds(m, n_traj, ld, y_src, y_state, d_rec, stages, d_time, d_tab_spec, begin, end, write_steps, n_records,
                               backward, final_chunk, s, st)) return -1;
@@ -1026,8 +1114,8 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
                                n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
         } else if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
-            HIPCHK(qgs::launch_gen_tgl_wave(Jrow, m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, d_time,
-                                            d_tab_spec, st));
+            HIPCHK(qgs::launch_gen_tgl_wave(m->wave_J(adjoint != 0), m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm,
+                                            stages, d_time, d_tab_spec, st, m->chains(true)));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
         } else if (spec && m->spec_jac_possible) {
             // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
