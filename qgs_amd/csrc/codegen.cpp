@@ -452,14 +452,20 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // Fused S-stage explicit RK stepper for sub-diagonal tableaus, one member per lane, all state in
 // registers for the whole run.  Storage: y (step start), acc (running y + dt*sum b_i k_i),
 // xa/xb (ping-pong stage inputs).  k_i is consumed row by row as it is produced.
+// park_y: the step-start state y is only the *input* of stage 0; in the later stages it is read once per row (x_next_i =
+// y_i + dt a k_i).  Parked in LDS (ysh[mode][lane], 288 B per lane) after stage 0 it leaves three state arrays in
+// registers instead of four, which brings the kernel under 256 VGPRs = two wavefronts per SIMD (the LDS of a CU holds the
+// 8 x 18 KB).  Pays off when the ensemble offers more than one wavefront per SIMD (>= 131 072 members on an MI355X).
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
-                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der)
+                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool park_y = false)
 {
     std::ostringstream o;
     KTable table;
-    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : "qgs_spec_rk_s") + std::to_string(S);
-    o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only") << "\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
+    park_y = park_y && S > 1 && !store_stages;
+    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (park_y ? "qgs_spec_rkp_s" : "qgs_spec_rk_s")) + std::to_string(S);
+    o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only")
+      << (park_y ? ", step-start state parked in LDS (two wavefronts per SIMD)" : "") << "\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << (park_y ? 2 : opt.min_waves_per_simd) << ") " << kname << "(\n"
       << "    const f64* __restrict__ y_in,   // X[mode][member] state at step `step_begin`\n"
       << "    f64* __restrict__ y_out,        // state after step `step_end-1` (may be null)\n"
       << "    f64* __restrict__ rec,          // R[record][mode][member] (may be null when no record is due)\n"
@@ -467,6 +473,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const f64* __restrict__ dtime,  // directed time grid\n"
       << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
+    if (park_y) o << "    __shared__ f64 ysh[" << ndim << "][QGS_WAVE];\n    const int lane = threadIdx.x;\n";
     o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);   // tail lanes shadow the last member and never store\n";
@@ -489,6 +496,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
     o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
+    if (park_y) for (int d = 1; d <= ndim; ++d) o << "        ysh[" << (d - 1) << "][lane] = y" << d << ";\n";
     for (int st = 0; st < S; ++st) {
         const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
         const std::string outn = (st % 2 == 0) ? "xa" : "xb";
@@ -515,7 +523,10 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
                 std::ostringstream ro;
                 emit_tend_row(ro, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
                 ro << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
-                if (!last) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
+                if (!last) {
+                    if (park_y && st > 0) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", ysh[" << (i - 1) << "][lane]);\n";
+                    else ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
+                }
                 lists.push_back(split_lines(ro.str()));
             }
             so << interleave(lists);
@@ -1549,6 +1560,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves);
     case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves);
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
+    case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
     }
     return "";
 }
@@ -1571,6 +1583,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t); break;
     case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt, der.t); break;
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
+    case Kernel::RkPark: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
     case Kernel::Tgl:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;
@@ -1598,6 +1611,7 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
     if (have_jac) l.push_back({Kernel::Jac, 0});
     for (int S : stages) {
         l.push_back({Kernel::Rk, S});
+        if (opt.rk_park_y && S > 1) l.push_back({Kernel::RkPark, S});
         if (opt.row_split > 1) l.push_back({Kernel::RkSplit, S});
         if (have_jac) {
             l.push_back({Kernel::RkStages, S});

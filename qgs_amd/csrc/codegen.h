@@ -32,6 +32,9 @@ struct CodegenOptions {
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
     bool nt_record = false;    // plain stepper: non-temporal stores for the records
+    bool rk_park_y = false;    // also emit qgs_spec_rkp_s<S>: step-start state parked in LDS, 216 VGPRs, 2 wavefronts per SIMD
+                               // (measured: no gain -- 9.8 vs 9.0 ms at 131 072 members, equal at 1 048 576: the lone wavefront
+                               // already keeps the fp64 pipe 91 % busy)
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
     int lds_cap = 20;          // ... and modes cached in registers per phase (24 spills at 128 VGPRs: 63.6 ms vs 55.6 ms)
@@ -63,6 +66,8 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_tend            f(x) for an ensemble                       (tendencies.py:111-115)
 //   qgs_spec_jac             Df(x) for an ensemble                      (tendencies.py:117-121)
 //   qgs_spec_rk_s<S>         fused S-stage RK trajectory stepper        (integrate.py:182-223)
+//   qgs_spec_rkp_s<S>        same as qgs_spec_rk_s<S> with the step-start state parked in LDS after stage 0: two wavefronts per
+//                            SIMD, for ensembles that offer them
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
 //   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
 //                            registers phase by phase; run-time stage count, optional stage store
@@ -75,7 +80,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

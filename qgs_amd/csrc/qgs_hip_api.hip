@@ -562,6 +562,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) cg.lds_cap = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_NT_RECORD")) cg.nt_record = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_RK_PARK")) cg.rk_park_y = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
@@ -1004,13 +1005,16 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         const int R = m->cg.row_split;
         const int64_t waves = (n_traj + 63) / 64;
         bool split = R > 1 && m->ndim >= 2 * R && waves * R <= (int64_t)m->n_simd * 5 / 2;
+        // more wavefronts than SIMDs: the variant with the step-start state parked in LDS fits two wavefronts per SIMD
+        bool park = !split && m->cg.rk_park_y && s > 1 && waves > (int64_t)m->n_simd && m->der.t.empty();
         if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
-            if (!std::strcmp(e, "plain")) split = false;
-            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) split = true;
+            if (!std::strcmp(e, "plain")) split = park = false;
+            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) { split = true; park = false; }
+            if (!std::strcmp(e, "park") && s > 1 && m->der.t.empty()) { park = true; split = false; }
         }
         hipFunction_t f;
         std::string name;
-        if (get_function(m, split ? qgs::Kernel::RkSplit : qgs::Kernel::Rk, s, &f, &name)) return -1;
+        if (get_function(m, split ? qgs::Kernel::RkSplit : (park ? qgs::Kernel::RkPark : qgs::Kernel::Rk), s, &f, &name)) return -1;
         double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
         int bw = backward, wf = 1;
