@@ -1,7 +1,7 @@
-// codegen.cpp -- see codegen.h.  Emits HIP C++ source; everything is straight-line fp64 code
-// with the tensor coefficients as hex-float literals, so the compiled kernels contain no
-// tensor loads at all: coefficients arrive through the scalar unit (s_mov literals) and every
-// VALU slot is a v_mul_f64 / v_fma_f64.
+// codegen.cpp -- see codegen.h.  Emits HIP C++ source; everything is straight-line fp64 code built from the
+// tensor, so the compiled kernels contain no tensor index loads at all: the coefficients arrive through the
+// scalar unit (per-kernel __constant__ tables walked with s_load_dwordx16, or s_mov literals on request) and
+// every VALU slot is a v_mul_f64 / v_fma_f64.
 #include "codegen.h"
 
 #include <algorithm>
@@ -371,6 +371,26 @@ std::string decl_list(const std::string &prefix, int ndim)
     return o.str();
 }
 
+// "Use" the freshly loaded values before the step loop.  Without it the compiler waits for the initial loads where they
+// are first needed -- inside the loop -- and, vmcnt being one in-order counter, that wait (vmcnt(0) at the loop head)
+// also drains the RECORD STORES of the previous step on every iteration: a full store round trip per step
+// (65 536 members x 100 steps with write_steps = 1: 0.69 ms, of which 0.23 ms were this stall).
+void emit_settle_loads(std::ostringstream &o, const char *indent, const std::string &prefix, const std::vector<int> &idx)
+{
+    for (size_t a = 0; a < idx.size(); a += 12) {
+        o << indent << "asm volatile(\"\" ::";
+        for (size_t q = a; q < std::min(idx.size(), a + 12); ++q) o << (q > a ? ", " : " ") << "\"v\"(" << prefix << idx[q] << ")";
+        o << ");\n";
+    }
+}
+
+std::vector<int> all_rows(int ndim)
+{
+    std::vector<int> v;
+    for (int d = 1; d <= ndim; ++d) v.push_back(d);
+    return v;
+}
+
 const char *PRELUDE = R"(// ---- generated by qgs_amd/csrc/codegen.cpp: tensor-specialised gfx950 kernels -------------
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>   // offline hipcc build; hiprtc predefines the HIP builtins
@@ -456,13 +476,18 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // y_i + dt a k_i).  Parked in LDS (ysh[mode][lane], 288 B per lane) after stage 0 it leaves three state arrays in
 // registers instead of four, which brings the kernel under 256 VGPRs = two wavefronts per SIMD (the LDS of a CU holds the
 // 8 x 18 KB).  Pays off when the ensemble offers more than one wavefront per SIMD (>= 131 072 members on an MI355X).
+// spread_rec: a record is not stored in one burst at the top of the step (36 x 512 B per wavefront, 18.9 MB for the
+// whole chip at 65 536 members, which the memory system needs 2.9 us to absorb while the step itself takes 4.6 us) but
+// row by row during stage 0: y_i goes out right after row i has been evaluated.
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
-                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool park_y = false)
+                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool park_y = false,
+                    bool spread_rec = false)
 {
     std::ostringstream o;
     KTable table;
     park_y = park_y && S > 1 && !store_stages;
-    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (park_y ? "qgs_spec_rkp_s" : "qgs_spec_rk_s")) + std::to_string(S);
+    spread_rec = spread_rec && !store_stages && !park_y;
+    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (park_y ? "qgs_spec_rkp_s" : (spread_rec ? "qgs_spec_rkr_s" : "qgs_spec_rk_s"))) + std::to_string(S);
     o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only")
       << (park_y ? ", step-start state parked in LDS (two wavefronts per SIMD)" : "") << "\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << (park_y ? 2 : opt.min_waves_per_simd) << ") " << kname << "(\n"
@@ -481,18 +506,26 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
     for (int d = 1; d <= ndim; ++d) o << "    y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    emit_settle_loads(o, "    ", "y", all_rows(ndim));
     o << "    QGS_REC_INIT\n";
     o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
     o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
-    o << "        if (ti == next_rec) {\n"
-      << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
-      << "            ++iw; next_rec += write_steps;\n"
-      << "            if (live) {\n";
-    for (int d = 1; d <= ndim; ++d) {
-        if (opt.nt_record) o << "                __builtin_nontemporal_store(y" << d << ", p + " << (d - 1) << " * ld);\n";
-        else o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    if (spread_rec) {
+        o << "        const bool rec_now = (ti == next_rec);\n"
+          << "        f64* p = rec + m;\n"
+          << "        if (rec_now) { p += qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld; ++iw; next_rec += write_steps; }\n"
+          << "        const bool rec_lane = rec_now && live;\n";
+    } else {
+        o << "        if (ti == next_rec) {\n"
+          << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
+          << "            ++iw; next_rec += write_steps;\n"
+          << "            if (live) {\n";
+        for (int d = 1; d <= ndim; ++d) {
+            if (opt.nt_record) o << "                __builtin_nontemporal_store(y" << d << ", p + " << (d - 1) << " * ld);\n";
+            else o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+        }
+        o << "            }\n        }\n";
     }
-    o << "            }\n        }\n";
     o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
@@ -527,6 +560,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
                     if (park_y && st > 0) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", ysh[" << (i - 1) << "][lane]);\n";
                     else ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
                 }
+                if (spread_rec && st == 0) ro << "            if (rec_lane) p[" << (i - 1) << " * ld] = y" << i << ";\n";
                 lists.push_back(split_lines(ro.str()));
             }
             so << interleave(lists);
@@ -604,6 +638,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
         if (opt.const_table) g_ktab = &tables[w];
         o << "        " << decl_list("y", ndim) << "\n";
         for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+        emit_settle_loads(o, "        ", "y", all_rows(ndim));
         o << "        QGS_REC_INIT\n";
         o << "        for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
         o << "            const f64 dt = dtime[ti + 1] - dtime[ti];\n";
@@ -735,6 +770,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     if (park) for (int d = 1; d <= ndim; ++d) o << "    vsh[" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    emit_settle_loads(o, "    ", "v", all_rows(ndim));
     if (shx) {
         // first stage state: wavefront w brings the modes w, w + C, w + 2C, ... (slot q holds mode w + q*C)
         o << "    if (g_total > 0) {\n        const f64* sp0 = stages + m;\n";
@@ -880,6 +916,7 @@ void emit_tgl_split_kernel(std::ostringstream &out, int ndim, const std::vector<
         o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {\n";
         o << "        " << decl_list("v", ndim) << "\n";
         for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
+        emit_settle_loads(o, "        ", "v", all_rows(ndim));
         o << "        QGS_REC_INIT\n";
         o << "        for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
         o << "            const f64 dt = dtime[ti + 1] - dtime[ti];\n";
@@ -1561,6 +1598,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves);
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
     case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
+    case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
     }
     return "";
 }
@@ -1584,6 +1622,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt, der.t); break;
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
     case Kernel::RkPark: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
+    case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, false, true); break;
     case Kernel::Tgl:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;
@@ -1612,6 +1651,7 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
     for (int S : stages) {
         l.push_back({Kernel::Rk, S});
         if (opt.rk_park_y && S > 1) l.push_back({Kernel::RkPark, S});
+        if (opt.rk_spread_rec) l.push_back({Kernel::RkRec, S});
         if (opt.row_split > 1) l.push_back({Kernel::RkSplit, S});
         if (have_jac) {
             l.push_back({Kernel::RkStages, S});

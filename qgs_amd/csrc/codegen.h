@@ -32,6 +32,8 @@ struct CodegenOptions {
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
     bool nt_record = false;    // plain stepper: non-temporal stores for the records
+    bool rk_spread_rec = false; // also emit qgs_spec_rkr_s<S>: records stored row by row during stage 0 instead of in one burst
+                               // (measured: 1.04 ms instead of 0.66-0.76 ms for 65 536 members x 100 records -- slower, off)
     bool rk_park_y = false;    // also emit qgs_spec_rkp_s<S>: step-start state parked in LDS, 216 VGPRs, 2 wavefronts per SIMD
                                // (measured: no gain -- 9.8 vs 9.0 ms at 131 072 members, equal at 1 048 576: the lone wavefront
                                // already keeps the fp64 pipe 91 % busy)
@@ -80,7 +82,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

@@ -1012,9 +1012,13 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
             if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) { split = true; park = false; }
             if (!std::strcmp(e, "park") && s > 1 && m->der.t.empty()) { park = true; split = false; }
         }
+        // dense records (a record at least every 8th step): the variant that spreads the record stores over stage 0
+        bool spread = !split && !park && m->cg.rk_spread_rec && write_steps > 0 && write_steps <= 8;
+        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) spread = (*e == '1') && !split && !park && write_steps > 0;
         hipFunction_t f;
         std::string name;
-        if (get_function(m, split ? qgs::Kernel::RkSplit : (park ? qgs::Kernel::RkPark : qgs::Kernel::Rk), s, &f, &name)) return -1;
+        if (get_function(m, split ? qgs::Kernel::RkSplit : (park ? qgs::Kernel::RkPark : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk)), s,
+                         &f, &name)) return -1;
         double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
         int bw = backward, wf = 1;
@@ -1333,7 +1337,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
                 if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
-    if (!m.spec_possible) return 0;
+    if (!m.spec_possible || m.prefer_lds) return 0;       // prefer_lds: the register-resident kernels would only spill (and take minutes to compile)
     const bool jac_spec = !m.J.empty() && m.spec_jac_possible;
     auto list = qgs::kernel_list(m.ndim, jac_spec, stages, m.cg);
     if (!m.J.empty() && !jac_spec)                       // the trajectory pass of the tangent model is still specialised
