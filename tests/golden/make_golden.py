@@ -385,6 +385,8 @@ def gen_lyapunov(name):
     ndim = p.ndim
     out = {'ndim': np.int64(ndim)}
     ic = np.random.RandomState(4242).rand(2, ndim) * cfg['ic_scale']
+    for k, v in cfg.get('ic_fix', {}).items():
+        ic[:, k] += v
     out['ic'] = ic
     t0, tw, t, dt, mdt = 0., 0.5, 1.0, 0.1, 0.02
     pretime = np.concatenate((np.arange(t0, tw, dt), np.full((1,), tw)))
@@ -428,5 +430,7 @@ if __name__ == '__main__':
         if nm == 'lyap':
             gen_lyapunov('rp20')
             gen_lyapunov('m36')
+        elif nm.startswith('lyap_'):
+            gen_lyapunov(nm[5:])
         else:
             gen(nm)
