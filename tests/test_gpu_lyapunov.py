@@ -33,14 +33,16 @@ def test_batched_qr_matches_lapack():
     f.operands.release()
 
 
-@pytest.mark.parametrize('name', ['rp20', 'm36'])
+@pytest.mark.parametrize('name', ['rp20', 'm36', 'd38'])
 def test_lyapunov_estimator_vs_reference(name):
-    from model_configs import MAKERS
+    """d38: the dynamic-T model (rank-5 tensor); its goldens come from the reference's loops on the reference's own tensor,
+    which differs from ours by its quadrature error (2e-14), well inside the tolerances below."""
+    from model_configs import MAKERS, MAKERS_RANK5
     from qgs_amd.functions.tendencies import create_tendencies
     from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
     g = np.load(os.path.join(GOLDEN_DIR, 'lyap_%s.npz' % name))
     meta = json.loads(bytes(g['meta_json']).decode())
-    f, Df = create_tendencies(MAKERS[name]())
+    f, Df = create_tendencies(dict(MAKERS, **MAKERS_RANK5)[name]())
     est = LyapunovsEstimator(num_threads=1)
     est.set_func(f, Df)
     for cs in meta['cases']:
