@@ -120,7 +120,8 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group)
             const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
             bool ok;
             const size_t n = next_ref(v, &ok);
-            out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
+            if (group < 0) out += "kt[0]";                       // timing experiment: no coefficient stream
+            else out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
             pos = b + 1;
         }
         return out;
@@ -1297,14 +1298,20 @@ void emit_lds_derived(std::ostringstream &o, const char *ind, int nbase, const s
     o << ind << "}\n";
 }
 
+// tend_kernel: the same kernel text, named qgs_spec_tendlds<W>, that leaves after the first tendency evaluation with
+// f(y_in) in y_out (launched with a one-step grid and S = 1).  It is a kernel of its own because as a run-time mode of
+// the stepper the extra exit path made the register allocator spill in the stepper (700 instead of 396 B of scratch,
+// 60.9 instead of 55.1 ms for 65 536 members x 100 steps at ndim 228); a loop-free kernel built from the same phases
+// spills far worse (the scheduler hoists the LDS reads of all phases: 14.6 KB of scratch, 30x slower) -- which is also why
+// the exit is guarded by a run-time argument and not by something the compiler can prove.
 void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
-                        const std::vector<std::pair<int, int>> &der)
+                        const std::vector<std::pair<int, int>> &der, bool tend_kernel = false)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
     const int nnode = ndim + (int)der.size();
     const std::vector<std::vector<int>> dshare = lds_derived_shares(ndim, der, W);
     const std::function<std::string(int)> dval = [](int f) { return "xs[" + std::to_string(f - 1) + "][lane]"; };
-    const std::string kname = "qgs_spec_rklds" + std::to_string(W);
+    const std::string kname = std::string(tend_kernel ? "qgs_spec_tendlds" : "qgs_spec_rklds") + std::to_string(W);
     RowTerms rt(ndim + 1);
     for (int i = 1; i <= ndim; ++i) {
         for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
@@ -1323,8 +1330,8 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "                                    // the end of every stage instead of being held in registers\n"
       << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
-      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S,\n"
-      << "    int tend_only)                   // 1: evaluate f(y_in) once into y_out and return (one step, one stage requested)\n{\n";
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S"
+      << (tend_kernel ? ",\n    int tend_only)                   // always 1; a run-time value so that the stage loop stays a loop\n{\n" : ")\n{\n");
     o << "    __shared__ f64 xs[" << nnode << "][QGS_WAVE];";
     if (!der.empty()) o << "   // " << ndim << " variables + " << der.size() << " derived monomials";
     o << "\n";
@@ -1395,20 +1402,22 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
-        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
+        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : opt.ktab_group) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;
-        o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"
-          << I4 << "    if (live) {\n";
-        for (int d : own) o << I4 << "        y_out[" << (d - 1) << " * ld + m] = k" << d << ";\n";
-        o << I4 << "    }\n" << I4 << "    return;\n" << I4 << "}\n";
+        if (tend_kernel) {
+            o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"
+              << I4 << "    if (live) {\n";
+            for (int d : own) o << I4 << "        y_out[" << (d - 1) << " * ld + m] = k" << d << ";\n";
+            o << I4 << "    }\n" << I4 << "    return;\n" << I4 << "}\n";
+        }
         for (int d : own) {
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
             o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";
         }
-        o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
+        if (!(opt.lds_debug & 1)) o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
         for (int d : own) o << I4 << "xs[" << (d - 1) << "][lane] = k" << d << ";\n";
-        o << I4 << "__syncthreads();\n";
+        if (!(opt.lds_debug & 1)) o << I4 << "__syncthreads();\n";
         if (!der.empty()) {                                  // derived monomials of the new stage state
             emit_lds_derived(o, I4, ndim, der, dshare[w], dval, dval);
             o << I4 << "__syncthreads();\n";
@@ -1599,6 +1608,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
     case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
+    case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
     }
     return "";
 }
@@ -1635,6 +1645,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
                               opt.tgl_split, opt);
         break;
     case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t); break;
+    case Kernel::TendLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, true); break;
     case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt, der.j); break;
     case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt, der.j); break;
     }

@@ -43,6 +43,8 @@ struct CodegenOptions {
     bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
+    int lds_debug = 0;         // timing experiments only (WRONG results): 1 = no barriers in the stage loop, 2 = every coefficient
+                               // is table entry 0 (no coefficient stream)
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
 };
 
@@ -73,6 +75,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
 //   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
 //                            registers phase by phase; run-time stage count, optional stage store
+//   qgs_spec_tendlds<W>      f(x) with the same machinery (one evaluation)
 //   qgs_spec_tgllds<W> / qgs_spec_adjlds<W>   tangent / adjoint model of large systems, 16 members x 4 columns per
 //                            workgroup, stage state and tangent vector in LDS
 //   qgs_spec_tgl_s<S>        tangent / adjoint propagation, one lane per (member, column)
@@ -82,7 +85,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

@@ -566,6 +566,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) cg.lds_debug = std::atoi(e);
 }
 
 bool use_spec(const qgs_model *m, int s, const double *a)
@@ -651,18 +652,18 @@ bool use_tiled(const qgs_model *m, int s, const double *a)
 // LDS-resident JIT stepper launch (codegen.cpp emit_rk_lds_kernel): W wavefronts per 64 members
 int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, double *y_out, double *d_rec, double *stages,
                   const double *d_time, const double *d_tab, int64_t step_begin, int64_t step_end, int64_t write_steps,
-                  int64_t n_records, int backward, int write_final, int s, hipStream_t st, int tend_only = 0)
+                  int64_t n_records, int backward, int write_final, int s, hipStream_t st, qgs::Kernel which = qgs::Kernel::RkLds)
 {
     hipFunction_t f;
     std::string name;
-    if (get_function(m, qgs::Kernel::RkLds, 0, &f, &name)) return -1;
+    if (get_function(m, which, 0, &f, &name)) return -1;
     const int64_t blocks = (n_traj + 63) / 64;
     if (m->b_ywork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)blocks)) return -1;
     double *yw = m->b_ywork.f64();
     long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
-    int bw = backward, wf = write_final, S = s, to = tend_only;
+    int bw = backward, wf = write_final, S = s, one = 1;
     void *args[] = {(void *)&y_in, &y_out, &yw, &d_rec, &stages, (void *)&d_time, (void *)&d_tab,
-                    &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S, &to};
+                    &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S, &one};      // `one`: the extra argument of the tendencies-only flavour
     note_kernel(m, name, f);
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
     return 0;
@@ -928,15 +929,15 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
         return launch(f, n_traj, st, args);
     }
     if (m->kernel_kind != 1 && m->lds_spec_possible &&
-        lds_kernel_wanted(m, qgs::Kernel::RkLds, (double)n_traj * (double)m->T.size())) {
-        // one stage of the LDS-resident stepper with `tend_only`: the tendencies land in d_dx
+        lds_kernel_wanted(m, qgs::Kernel::TendLds, (double)n_traj * (double)m->T.size())) {
+        // the tendencies-only flavour of the LDS-resident stepper: one step, one stage, leaves after the first evaluation
         if (!m->b_unit.p) {
             const double unit[4] = {0.0, 1.0, 1.0, 0.0};                      // time grid {0, 1}; tableau b = {1}
             if (m->b_unit.ensure(sizeof unit)) return -1;
             HIPCHK(hipMemcpy(m->b_unit.p, unit, sizeof unit, hipMemcpyHostToDevice));
         }
         return launch_rk_lds(m, n_traj, ld, d_x, d_dx, nullptr, nullptr, m->b_unit.f64(), m->b_unit.f64() + 2, 0, 1, 0, 1, 0, 0, 1,
-                             st, 1);
+                             st, qgs::Kernel::TendLds);
     }
     if (use_spec(m, 1, nullptr)) {                                    // prefer_lds, but the LDS kernel is not wanted / built
         hipFunction_t f;
@@ -1333,6 +1334,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
         std::vector<char> code;
         bool cached;
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::TendLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
         if (!m.J.empty() && !m.spec_jac_possible && lds_tgl_bytes(&m) <= (size_t)QGS_LDS_STATE_BYTES)
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
                 if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;

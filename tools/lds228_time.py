@@ -1,0 +1,20 @@
+"""Time only: qgs_spec_rklds16 on the MAOOAM 6x6 tensor, 65 536 members x 100 steps (QGS_HIP_LDS_DEBUG experiments give wrong
+results on purpose)."""
+import json, os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from qgs_amd import _lib
+c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 't228.npz')); ndim = int(g['ndim'])
+m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval']); m.set_kernel(2)
+steps = 100; t = np.concatenate((np.arange(0., steps * 0.1, 0.1), [steps * 0.1]))[:steps + 1]
+st = torch.cuda.current_stream().cuda_stream
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+ic = torch.from_numpy(np.random.RandomState(3).rand(ndim, n) * 0.01).cuda(); rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')
+ts = []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st)
+    torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+print('QGS_HIP_LDS_DEBUG=%s: %.2f ms %s' % (os.environ.get('QGS_HIP_LDS_DEBUG', '0'), min(ts[1:]) * 1e3, m.last_kernel_info()), flush=True)
