@@ -56,7 +56,11 @@ std::string lit(double v)
 //   21 % of the stepper's cycles).  Here the coefficients are consumed in groups of 16 held in two 8-double vectors
 //   `kq<2g>`, `kq<2g+1>`; the loads of group g+1 are issued right AFTER the first statement that uses group g
 //   (which carries the wait) and pinned there with sched_barriers, so they fly during the 16 FMAs of group g.
-std::string resolve_ktab(const std::string &text, KTable &t, int group)
+// dedupe (LDS-resident kernels): a coefficient whose magnitude already sits in the group of 16 that is being consumed is
+// not fetched again, the statement refers to that entry (negated if the sign differs).  MAOOAM 6x6: cos / sin partner
+// modes and the psi / theta copies of the advection terms repeat their coefficients in neighbouring statements, 21 657
+// fetches per workgroup-stage become ~15 000 -- and the coefficient stream is what bounds that kernel.
+std::string resolve_ktab(const std::string &text, KTable &t, int group, bool dedupe = false)
 {
     std::string out;
     t.cursor = 0;
@@ -153,8 +157,20 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group)
             res.append(line, lp, a - lp);
             const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
             bool ok;
-            const size_t n = next_ref(v, &ok);
-            res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
+            size_t n = 0;
+            bool reused = false;
+            if (dedupe && t.cursor > 0) {
+                const size_t g0 = (t.cursor - 1) / 16 * 16;                       // first entry of the group being consumed
+                for (size_t q = t.cursor; q-- > g0;)
+                    if (std::fabs(t.vals[q]) == std::fabs(v) && v != 0.0) { n = q; reused = true; break; }
+            }
+            if (reused) {
+                const std::string ref = "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]";
+                res += (std::signbit(t.vals[n]) == std::signbit(v)) ? ref : "(-" + ref + ")";
+            } else {
+                n = next_ref(v, &ok);
+                res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
+            }
             if (first_group < 0) first_group = (long)(n / 16);
             lp = b + 1;
         }
@@ -1402,7 +1418,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
-        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : opt.ktab_group) : so.str());
+        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;
         if (tend_kernel) {
@@ -1545,7 +1561,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = vw[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
-        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
+        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;
         for (int d : own) {

@@ -43,6 +43,7 @@ struct CodegenOptions {
     bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
+    bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
     int lds_debug = 0;         // timing experiments only (WRONG results): 1 = no barriers in the stage loop, 2 = every coefficient
                                // is table entry 0 (no coefficient stream)
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
