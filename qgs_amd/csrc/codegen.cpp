@@ -861,7 +861,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                     }
                 }
             }
-            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group) : so.str());
+            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group, opt.tgl_coeff_dedupe) : so.str());
             g_ktab = nullptr;
             o << "            }\n";
         }
