@@ -582,7 +582,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             }
             so << interleave(lists);
         }
-        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
+        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group, opt.rk_coeff_dedupe) : so.str());
         g_ktab = nullptr;
         o << "        }\n";
     }
