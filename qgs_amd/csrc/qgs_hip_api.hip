@@ -617,6 +617,7 @@ bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work)
 {
     if (const char *e = std::getenv("QGS_HIP_LDS")) return *e == '1';
     if (m->kernel_kind == 2) return true;
+    if (m->prefer_lds) return true;         // the alternative is a register-resident kernel that spills and takes minutes to compile
     const std::string name = qgs::kernel_name(k, 0, m->cg);
     if (m->functions.count(name)) return true;                                              // already loaded
     auto it = m->lds_on_disk.find(name);
