@@ -763,6 +763,11 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     // which is what the 400+-register variant gets as well.
     const bool park = opt.tgl_park_lds && S > 1 && !shx;
     if (park) o << "    __shared__ f64 vsh[" << ndim << "][QGS_WAVE];\n    __shared__ f64 accsh[" << ndim << "][QGS_WAVE];\n";
+    // park_v: the step-start vector v is the input of stage 0 and afterwards only the base of w_next_i = v_i + dt a k_i, read
+    // once per row and stage.  Parked in LDS after stage 0 the kernel holds four vectors in registers instead of five and
+    // the accumulation-register traffic (v_accvgpr moves are VALU slots) shrinks.
+    const bool park_v = opt.tgl_park_v && S > 2 && !park;
+    if (park_v) o << "    __shared__ f64 vpk[" << C << "][" << ndim << "][QGS_WAVE];\n";
     if (shx) {
         o << "    __shared__ f64 xsh[2][" << ndim << "][QGS_WAVE];     // stage states of the 64 members, double-buffered\n";
         o << "    const int lane = threadIdx.x & 63;\n"
@@ -810,6 +815,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     if (!park) o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("wa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("wb", ndim) << "\n";
+    if (park_v) for (int d = 1; d <= ndim; ++d) o << "        vpk[" << (shx ? "wave" : "0") << "][" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) {
         const std::string in = (st == 0) ? "v" : ((st % 2 == 1) ? "wa" : "wb");
         const std::string outn = (st % 2 == 0) ? "wa" : "wb";
@@ -839,14 +845,20 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 g_ktab = &tables[pass];
                 o << "                kf64* kt = (kf64*)" << kname << "_kt" << pass << "; asm volatile(\"\" : \"+s\"(kt));\n";
             }
-            std::ostringstream so;
+            std::ostringstream so_all;
+            std::vector<std::vector<std::string>> row_lines;
             for (int i = 1; i <= ndim; ++i) {                 // brace-less rows: the coefficient group vectors stay in scope
+                std::ostringstream so;
                 const std::string rn = "r" + std::to_string(i);
                 emit_wx_row(so, "                ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
                             pass * 100000 + st * 1000 + i);
                 if (!park) {
                     so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
-                    if (!last) so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
+                    if (!last) {
+                        if (park_v && st > 0)
+                            so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", vpk[" << (shx ? "wave" : "0") << "][" << (i - 1) << "][lane]);\n";
+                        else so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
+                    }
                 } else {
                     const std::string acc_l = "accsh[" + std::to_string(i - 1) + "][lane]";
                     const std::string v_l = "vsh[" + std::to_string(i - 1) + "][lane]";
@@ -860,7 +872,16 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                         so << "                " << v_l << " = v" << i << ";\n";
                     }
                 }
+                row_lines.push_back(split_lines(so.str()));
             }
+            {
+                const int IW = std::max(1, opt.tgl_interleave);   // statements of IW consecutive rows round-robin (independent chains)
+                for (size_t c0 = 0; c0 < row_lines.size(); c0 += IW) {
+                    std::vector<std::vector<std::string>> grp(row_lines.begin() + c0, row_lines.begin() + std::min(row_lines.size(), c0 + IW));
+                    so_all << interleave(grp);
+                }
+            }
+            const std::ostringstream &so = so_all;
             o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group, opt.tgl_coeff_dedupe) : so.str());
             g_ktab = nullptr;
             o << "            }\n";

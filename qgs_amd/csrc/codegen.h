@@ -30,6 +30,8 @@ struct CodegenOptions {
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
     bool rk_coeff_dedupe = false;  // register-resident stepper: ditto (measured neutral with the system hiprtc build: 4.78 vs 4.78 ms; off)
+    int tgl_interleave = 1;    // tangent kernel: rows whose statements are emitted round-robin
+    bool tgl_park_v = false;   // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
     bool tgl_coeff_dedupe = true;  // tangent kernel: same de-duplication of coefficient fetches as lds_coeff_dedupe (config 4: 1.24 -> 1.20 ms)
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
