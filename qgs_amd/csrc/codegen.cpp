@@ -599,6 +599,92 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
     out << o.str();
 }
 
+// General explicit tableau (dense lower-triangular `a`, e.g. Kutta's third-order scheme or the 3/8 rule; reference
+// integrate.py:214-219 takes any b, c, a).  The input of stage q is P_q = y + dt * sum_{j<q} a_qj k_j.  k_j is still consumed
+// row by row as it is produced: the next stage's input P_{j+1} is completed in registers (as in the sub-diagonal kernel)
+// and the partial sums of the stages after that are read-modify-written in LDS, psum[q - 2][mode][lane] -- (S - 2) * ndim
+// doubles per lane, 36.9 KB per wavefront for a 4-stage scheme at ndim 36, so four wavefronts still fit a CU.  A first
+// version kept the k_j in a global scratch array: 170 MB of traffic per step at 65 536 members, 56 ms per 1000 steps;
+// this one needs 216 LDS operations per member-step next to 2 076 FMAs.  tab = b[S], a[S*S] (row-major), run-time values.
+void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, const CodegenOptions &opt,
+                          const std::vector<std::pair<int, int>> &der)
+{
+    std::ostringstream o;
+    KTable table;
+    const std::string kname = "qgs_spec_rkd_s" + std::to_string(S);
+    o << "\n// " << S << "-stage RK with a general lower-triangular tableau, partial stage sums in LDS\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
+      << "    const f64* __restrict__ y_in, f64* __restrict__ y_out, f64* __restrict__ rec,\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
+    if (S > 2) o << "    __shared__ f64 psum[" << (S - 2) << "][" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x;\n"
+      << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+      << "    const bool live = m0 < n_traj;\n"
+      << "    const i64 m = live ? m0 : (n_traj - 1);\n";
+    o << "    " << decl_list("y", ndim) << "\n";
+    for (int d = 1; d <= ndim; ++d) o << "    y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
+    for (int i = 1; i < S; ++i)
+        for (int j = 0; j < i; ++j) o << "    const f64 ta" << i << "_" << j << " = tab[" << (S + i * S + j) << "];\n";
+    emit_settle_loads(o, "    ", "y", all_rows(ndim));
+    o << "    QGS_REC_INIT\n";
+    o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+    o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    o << "        if (ti == next_rec) {\n"
+      << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
+      << "            ++iw; next_rec += write_steps;\n"
+      << "            if (live) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    o << "            }\n        }\n";
+    o << "        " << decl_list("acc", ndim) << "\n";
+    if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
+    if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
+    for (int st = 0; st < S; ++st) {
+        const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
+        const std::string outn = (st % 2 == 0) ? "xa" : "xb";
+        const bool last = (st == S - 1);
+        o << "        {   // stage " << st << "\n";
+        o << "            const f64 hb = dt * tb" << st << ";\n";
+        for (int q = st + 1; q < S; ++q) o << "            const f64 h" << q << " = dt * ta" << q << "_" << st << ";\n";
+        emit_derived(o, "            ", ndim, der, names(in));
+        if (opt.const_table) {
+            g_ktab = &table;
+            o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
+        }
+        std::ostringstream so;
+        for (int i = 1; i <= ndim; ++i) {
+            const std::string rn = "r" + std::to_string(i);
+            emit_tend_row(so, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
+            so << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
+            if (!last) {
+                // input of the next stage, completed in registers
+                const std::string base = (st == 0) ? "y" + std::to_string(i)
+                                                   : "psum[" + std::to_string(st + 1 - 2) + "][" + std::to_string(i - 1) + "][lane]";
+                so << "            " << outn << i << " = __builtin_fma(h" << (st + 1) << ", " << rn << ", " << base << ");\n";
+                // partial sums of the stages after the next one
+                for (int q = st + 2; q < S; ++q) {
+                    const std::string slot = "psum[" + std::to_string(q - 2) + "][" + std::to_string(i - 1) + "][lane]";
+                    so << "            " << slot << " = __builtin_fma(h" << q << ", " << rn << ", " << (st == 0 ? "y" + std::to_string(i) : slot) << ");\n";
+                }
+            }
+        }
+        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
+        g_ktab = nullptr;
+        o << "        }\n";
+    }
+    for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = acc" << d << ";\n";
+    o << "    }\n";
+    o << "    if (live) {\n        if (y_out) {\n";
+    for (int d = 1; d <= ndim; ++d) o << "            y_out[" << (d - 1) << " * ld + m] = y" << d << ";\n";
+    o << "        }\n        if (write_final) {\n"
+      << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
+    for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
+    o << "        }\n    }\n}\n";
+    if (opt.const_table) emit_ktable(out, kname + "_kt", table);
+    out << o.str();
+}
+
 // Row-split variant of the fused stepper: a workgroup of R wavefronts shares 64 members; wave w evaluates
 // only the rows of its partition and the R partitions exchange the new stage state through LDS once per
 // stage.  With n_traj/64 wavefronts of work a 1024-SIMD MI355X gets only ONE wave per SIMD from a
@@ -1646,6 +1732,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
     case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
+    case Kernel::RkDense: return "qgs_spec_rkd_s" + std::to_string(S);
     }
     return "";
 }
@@ -1670,6 +1757,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
     case Kernel::RkPark: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
     case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, false, true); break;
+    case Kernel::RkDense: emit_rk_dense_kernel(o, ndim, rows, S, opt, der.t); break;
     case Kernel::Tgl:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;

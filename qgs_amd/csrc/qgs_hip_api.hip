@@ -574,6 +574,15 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_RK_DEDUPE")) cg.rk_coeff_dedupe = (*e == '1');
 }
 
+// explicit scheme: a[i][j] == 0 for j >= i
+bool tableau_is_lower_triangular(int s, const double *a)
+{
+    for (int i = 0; i < s; ++i)
+        for (int j = i; j < s; ++j)
+            if (a[i * s + j] != 0.0) return false;
+    return true;
+}
+
 bool use_spec(const qgs_model *m, int s, const double *a)
 {
     if (m->kernel_kind == 1) return false;
@@ -1039,6 +1048,19 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
     if (use_lds_spec(m, n_traj, n_time - 1, s, a))
         return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
                              n_records, backward, 1, s, st);
+    if (m->kernel_kind != 1 && m->spec_possible && !m->prefer_lds && s >= 2 && s <= 8 && tableau_is_lower_triangular(s, a) &&
+        (size_t)(s - 2) * m->ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES) {
+        // general explicit tableau: register-resident tendencies, partial stage sums in LDS (codegen emit_rk_dense_kernel)
+        hipFunction_t f;
+        std::string name;
+        if (get_function(m, qgs::Kernel::RkDense, s, &f, &name)) return -1;
+        double *y_out = nullptr;
+        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
+        int bw = backward, wf = 1;
+        void *args[] = {(void *)&d_ic, &y_out, &d_rec, (void *)&d_time, (void *)&d_tab_full, &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+        note_kernel(m, name, f);
+        return launch(f, n_traj, st, args);
+    }
     qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
     if (use_tiled(m, s, a)) {
         HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
@@ -1350,6 +1372,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     auto list = qgs::kernel_list(m.ndim, jac_spec, stages, m.cg);
     if (!m.J.empty() && !jac_spec)                       // the trajectory pass of the tangent model is still specialised
         for (int S : stages) list.push_back({qgs::Kernel::RkStages, S});
+    for (int S : stages) if (S >= 3) list.push_back({qgs::Kernel::RkDense, S});   // general lower-triangular tableaus
     for (auto &ks : list) {
         std::vector<char> code;
         bool cached;

@@ -196,6 +196,38 @@ def test_rank5_models_vs_oracle(models, name, n_traj):
     m.set_kernel(0)
 
 
+@pytest.mark.parametrize('name', ['m36', 'rp20', 'd38'])
+def test_general_tableaus_on_the_specialised_stepper(models, name):
+    """Explicit schemes whose `a` is not sub-diagonal (the reference takes any b, c, a: integrate.py:214-219): Kutta's
+    third-order scheme, the 3/8 rule, and a 4-stage tableau with a zero column (its stage tendencies are never stored).
+    `qgs_spec_rkd_s<S>` keeps the tendencies in registers and the stage tendencies in a scratch array; against the oracle
+    and the generic kernel, forward with records and backward."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden(name), models(name)
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    kutta3 = (np.array([1. / 6, 2. / 3, 1. / 6]), np.array([0., .5, 1.]), np.array([[0., 0, 0], [.5, 0, 0], [-1., 2., 0]]))
+    rule38 = (np.array([1., 3., 3., 1.]) / 8., np.array([0., 1. / 3, 2. / 3, 1.]),
+              np.array([[0., 0, 0, 0], [1. / 3, 0, 0, 0], [-1. / 3, 1., 0, 0], [1., -1., 1., 0]]))
+    sparse4 = (np.array([.25, 0., .5, .25]), np.array([0., .5, .5, 1.]),
+               np.array([[0., 0, 0, 0], [.5, 0, 0, 0], [.5, 0, 0, 0], [.25, 0., .75, 0]]))     # k_2 never reused
+    rng = np.random.RandomState(38)
+    ic = rng.rand(70, g.ndim) * 0.01
+    if name == 'd38':
+        ic[:, 10] += 1.5
+        ic[:, 29] += 3.
+    t = np.concatenate((np.arange(0., 1.5, 0.1), [1.5]))
+    for b, c, a in (kutta3, rule38, sparse4):
+        for d, ws in ((1, 4), (-1, 0)):
+            ref = ora.integrate_runge_kutta_jit(t, ic, d, ws, b, c, a, threads=4)
+            m.set_kernel(2)
+            out = m.rk_integrate(t, ic, d, ws, b, c, a)
+            assert m.last_kernel_info()['name'] == 'qgs_spec_rkd_s%d' % len(b)
+            assert rel_err(out, ref) < 1e-12, (len(b), d, ws)
+            m.set_kernel(1)
+            assert rel_err(m.rk_integrate(t, ic, d, ws, b, c, a), ref) < 1e-12
+    m.set_kernel(0)
+
+
 def test_zero_steps_and_single_step(models):
     """n_time == 1 (no step): the only record is the initial condition (integrate.py:221)."""
     g, m = load_golden('a36'), models('a36')
