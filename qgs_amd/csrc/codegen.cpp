@@ -615,6 +615,7 @@ void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<R
     o << "\n// " << S << "-stage RK with a general lower-triangular tableau, partial stage sums in LDS\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
       << "    const f64* __restrict__ y_in, f64* __restrict__ y_out, f64* __restrict__ rec,\n"
+      << "    f64* __restrict__ stages,       // S[(step-step_begin)*" << S << "+stage][mode][member] for the tangent model, or null\n"
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
     if (S > 2) o << "    __shared__ f64 psum[" << (S - 2) << "][" << ndim << "][QGS_WAVE];\n";
@@ -647,6 +648,9 @@ void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<R
         o << "        {   // stage " << st << "\n";
         o << "            const f64 hb = dt * tb" << st << ";\n";
         for (int q = st + 1; q < S; ++q) o << "            const f64 h" << q << " = dt * ta" << q << "_" << st << ";\n";
+        o << "            if (stages && live) {\n                f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+        for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
+        o << "            }\n";
         emit_derived(o, "            ", ndim, der, names(in));
         if (opt.const_table) {
             g_ktab = &table;
@@ -825,16 +829,20 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
 // the cycles in s_waitcnt), and reads every stage state once per column.
 void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
                      const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt,
-                     const std::vector<std::pair<int, int>> &der, int share_x = 1)
+                     const std::vector<std::pair<int, int>> &der, int share_x = 1, bool dense = false)
 {
+    // dense: general lower-triangular tableau (tab = b[S], a[S*S]); the partial sums of the later stages' inputs are kept in
+    // LDS exactly as in emit_rk_dense_kernel
     std::ostringstream o;
     KTable tables[2];
-    const int C = std::max(1, share_x);
+    const int C = dense ? 1 : std::max(1, share_x);
     const bool shx = C > 1;
-    const std::string kname = shx ? "qgs_spec_tglx" + std::to_string(C) + "_s" + std::to_string(S) : "qgs_spec_tgl_s" + std::to_string(S);
+    const std::string kname = dense ? "qgs_spec_tgld_s" + std::to_string(S)
+                                    : (shx ? "qgs_spec_tglx" + std::to_string(C) + "_s" + std::to_string(S) : "qgs_spec_tgl_s" + std::to_string(S));
     o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)";
     if (shx) o << ", " << C << " columns per workgroup sharing the stage states through LDS";
     o << "\n";
+    if (dense) o << "// general lower-triangular tableau: partial sums of the later stages' tangent inputs in LDS\n";
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * C << ", " << opt.min_waves_per_simd << ") " << kname << "(\n"
       << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
       << "    f64* __restrict__ w_out_p,       // after step `step_end-1` (may be null)\n"
@@ -847,12 +855,13 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     // stage) live in LDS, [row][lane], so that x, w_in and w_out (216 VGPRs) fit the 256 architectural registers
     // without accumulation-register moves or scratch.  36.9 KB per wavefront-workgroup: 4 per CU = one per SIMD,
     // which is what the 400+-register variant gets as well.
-    const bool park = opt.tgl_park_lds && S > 1 && !shx;
+    const bool park = opt.tgl_park_lds && S > 1 && !shx && !dense;
+    if (dense && S > 2) o << "    __shared__ f64 psw[" << (S - 2) << "][" << ndim << "][QGS_WAVE];\n";
     if (park) o << "    __shared__ f64 vsh[" << ndim << "][QGS_WAVE];\n    __shared__ f64 accsh[" << ndim << "][QGS_WAVE];\n";
     // park_v: the step-start vector v is the input of stage 0 and afterwards only the base of w_next_i = v_i + dt a k_i, read
     // once per row and stage.  Parked in LDS after stage 0 the kernel holds four vectors in registers instead of five and
     // the accumulation-register traffic (v_accvgpr moves are VALU slots) shrinks.
-    const bool park_v = opt.tgl_park_v && S > 2 && !park;
+    const bool park_v = opt.tgl_park_v && S > 2 && !park && !dense;
     if (park_v) o << "    __shared__ f64 vpk[" << C << "][" << ndim << "][QGS_WAVE];\n";
     if (shx) {
         o << "    __shared__ f64 xsh[2][" << ndim << "][QGS_WAVE];     // stage states of the 64 members, double-buffered\n";
@@ -877,7 +886,12 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
     if (park) for (int d = 1; d <= ndim; ++d) o << "    vsh[" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
-    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    if (dense) {
+        for (int i = 1; i < S; ++i)
+            for (int j = 0; j < i; ++j) o << "    const f64 ta" << i << "_" << j << " = tab[" << (S + i * S + j) << "];\n";
+    } else {
+        for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    }
     emit_settle_loads(o, "    ", "v", all_rows(ndim));
     if (shx) {
         // first stage state: wavefront w brings the modes w, w + C, w + 2C, ... (slot q holds mode w + q*C)
@@ -908,7 +922,9 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         const bool last = (st == S - 1);
         o << "        {   // stage " << st << "\n";
         o << "            const f64 hb = dt * tb" << st << " * inverse;\n";      // inverse = +-1: exact
-        if (!last) o << "            const f64 ha = dt * ta" << st << " * inverse;\n";
+        if (dense) {
+            for (int q = st + 1; q < S; ++q) o << "            const f64 h" << q << " = dt * ta" << q << "_" << st << " * inverse;\n";
+        } else if (!last) o << "            const f64 ha = dt * ta" << st << " * inverse;\n";
         if (shx) {
             o << "            const i64 g = (ti - step_begin) * " << S << " + " << st << ";\n"
               << "            const int pb = (int)(g & 1);\n"
@@ -938,7 +954,19 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 const std::string rn = "r" + std::to_string(i);
                 emit_wx_row(so, "                ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
                             pass * 100000 + st * 1000 + i);
-                if (!park) {
+                if (dense) {
+                    so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
+                    if (!last) {
+                        const std::string base = (st == 0) ? "v" + std::to_string(i)
+                                                           : "psw[" + std::to_string(st + 1 - 2) + "][" + std::to_string(i - 1) + "][lane]";
+                        so << "                " << outn << i << " = __builtin_fma(h" << (st + 1) << ", " << rn << ", " << base << ");\n";
+                        for (int q = st + 2; q < S; ++q) {
+                            const std::string slot = "psw[" + std::to_string(q - 2) + "][" + std::to_string(i - 1) + "][lane]";
+                            so << "                " << slot << " = __builtin_fma(h" << q << ", " << rn << ", "
+                               << (st == 0 ? "v" + std::to_string(i) : slot) << ");\n";
+                        }
+                    }
+                } else if (!park) {
                     so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
                     if (!last) {
                         if (park_v && st > 0)
@@ -1733,6 +1761,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
     case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
     case Kernel::RkDense: return "qgs_spec_rkd_s" + std::to_string(S);
+    case Kernel::TglDense: return "qgs_spec_tgld_s" + std::to_string(S);
     }
     return "";
 }
@@ -1758,6 +1787,9 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::RkPark: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
     case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, false, true); break;
     case Kernel::RkDense: emit_rk_dense_kernel(o, ndim, rows, S, opt, der.t); break;
+    case Kernel::TglDense:
+        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j, 1, true);
+        break;
     case Kernel::Tgl:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j);
         break;

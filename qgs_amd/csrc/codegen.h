@@ -77,7 +77,8 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_rk_s<S>         fused S-stage RK trajectory stepper        (integrate.py:182-223)
 //   qgs_spec_rkp_s<S>        same as qgs_spec_rk_s<S> with the step-start state parked in LDS after stage 0: two wavefronts per
 //                            SIMD, for ensembles that offer them
-//   qgs_spec_rkd_s<S>        S-stage RK with a general lower-triangular tableau (stage tendencies in a scratch array)
+//   qgs_spec_rkd_s<S>        S-stage RK with a general lower-triangular tableau (partial stage sums in LDS; optional stage store)
+//   qgs_spec_tgld_s<S>       tangent / adjoint propagation for such a tableau
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
 //   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
 //                            registers phase by phase; run-time stage count, optional stage store
@@ -91,7 +92,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds, RkDense };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds, RkDense, TglDense };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

@@ -1054,10 +1054,10 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         hipFunction_t f;
         std::string name;
         if (get_function(m, qgs::Kernel::RkDense, s, &f, &name)) return -1;
-        double *y_out = nullptr;
+        double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
         int bw = backward, wf = 1;
-        void *args[] = {(void *)&d_ic, &y_out, &d_rec, (void *)&d_time, (void *)&d_tab_full, &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+        void *args[] = {(void *)&d_ic, &y_out, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_full, &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
         note_kernel(m, name, f);
         return launch(f, n_traj, st, args);
     }
@@ -1095,6 +1095,10 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
     const int64_t n_steps = n_time - 1;
     const int64_t A = (int64_t)m->ndim * ld, L = n_tg * ld;
     const bool spec = use_spec(m, s, a);
+    // general lower-triangular tableau on the register-resident kernels (partial stage sums in LDS)
+    const bool dense = !spec && m->kernel_kind != 1 && m->spec_possible && !m->prefer_lds && s >= 2 && s <= 8 &&
+                       !qgs::tableau_is_subdiagonal(s, a) && tableau_is_lower_triangular(s, a) &&
+                       (size_t)(s - 2) * m->ndim * 512 <= (size_t)64 * 1024;
 
     // The reference pre-writes record 0 with the initial conditions (integrate.py:581-582); with at least
     // one step that record is rewritten by the loop, with zero steps the final record covers it.
@@ -1131,6 +1135,12 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         } else if (m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a)) {
             if (launch_rk_lds(m, n_traj, ld, y_src, y_state, d_rec, stages, d_time, d_tab_spec, begin, end, write_steps, n_records,
                               backward, final_chunk, s, st)) return -1;
+        } else if (dense) {
+            hipFunction_t f1;
+            if (get_function(m, qgs::Kernel::RkDense, s, &f1)) return -1;
+            void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_full,
+                          &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
+            if (launch(f1, n_traj, st, a1)) return -1;
         } else if (spec) {
             hipFunction_t f1;
             if (get_function(m, qgs::Kernel::RkStages, s, &f1)) return -1;
@@ -1150,6 +1160,14 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs())) {
             if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
                                n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
+        } else if (dense && m->spec_jac_possible) {
+            hipFunction_t f2;
+            std::string n2;
+            if (get_function(m, qgs::Kernel::TglDense, s, &f2, &n2)) return -1;
+            void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_full,
+                          &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
+            note_kernel(m, n2, f2);
+            if (launch(f2, L, st, a2)) return -1;
         } else if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
             HIPCHK(qgs::launch_gen_tgl_wave(m->wave_J(adjoint != 0), m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm,
                                             stages, d_time, d_tab_spec, st, m->chains(true)));
@@ -1372,7 +1390,11 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     auto list = qgs::kernel_list(m.ndim, jac_spec, stages, m.cg);
     if (!m.J.empty() && !jac_spec)                       // the trajectory pass of the tangent model is still specialised
         for (int S : stages) list.push_back({qgs::Kernel::RkStages, S});
-    for (int S : stages) if (S >= 3) list.push_back({qgs::Kernel::RkDense, S});   // general lower-triangular tableaus
+    for (int S : stages)
+        if (S >= 3) {                                                            // general lower-triangular tableaus
+            list.push_back({qgs::Kernel::RkDense, S});
+            if (jac_spec) list.push_back({qgs::Kernel::TglDense, S});
+        }
     for (auto &ks : list) {
         std::vector<char> code;
         bool cached;

@@ -225,6 +225,15 @@ def test_general_tableaus_on_the_specialised_stepper(models, name):
             assert rel_err(out, ref) < 1e-12, (len(b), d, ws)
             m.set_kernel(1)
             assert rel_err(m.rk_integrate(t, ic, d, ws, b, c, a), ref) < 1e-12
+    # the tangent / adjoint model with such tableaus: stage-storing flavour of the same stepper + `qgs_spec_tgld_s<S>`
+    tg = rng.randn(5, g.ndim, 6)
+    for b, c, a in (kutta3, rule38):
+        for d, ws, adj, inv in ((1, 2, False, 1.), (-1, 1, True, -1.)):
+            rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:7], ic[:5], tg, d, ws, b, c, a, adj, inv)
+            m.set_kernel(2)
+            tr, fm = m.rk_tgls_integrate(t[:7], ic[:5], tg, d, ws, b, c, a, adj, inv)
+            assert m.last_kernel_info()['name'] == 'qgs_spec_tgld_s%d' % len(b)
+            assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (len(b), d, adj)
     m.set_kernel(0)
 
 
