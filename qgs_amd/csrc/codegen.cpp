@@ -1602,11 +1602,15 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
                          const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
-    const std::string kname = std::string(adjoint ? "qgs_spec_adjlds" : "qgs_spec_tgllds") + std::to_string(W);
+    // tile: MT members x (64 / MT) columns per workgroup.  16 x 4 by default; 8 x 8 halves the stage-state tile when the
+    // derived monomials of a rank-5 model would not fit otherwise (dynamic-T MAOOAM 6x6: 230 variables + 118 monomials)
+    const int MT = (opt.lds_tgl_members == 8) ? 8 : 16, MSH = (MT == 8) ? 3 : 4, NC = 64 / MT;
+    const std::string sMT = std::to_string(MT), sMSK = std::to_string(MT - 1), sMSH = std::to_string(MSH), sNC = std::to_string(NC);
+    const std::string kname = std::string(adjoint ? "qgs_spec_adjlds" : "qgs_spec_tgllds") + std::to_string(W) + (MT == 8 ? "m8" : "");
     const int nx = ndim + (int)der.size();                  // x nodes: the stage state and (rank 5) its derived monomials
-    const int64_t xs_bytes = (int64_t)nx * 16 * 8;
+    const int64_t xs_bytes = (int64_t)nx * MT * 8;
     const std::vector<std::vector<int>> dshare = lds_derived_shares(ndim, der, W);
-    const std::function<std::string(int)> dval = [](int f) { return "xs[" + std::to_string(f - 1) + "][lane & 15]"; };
+    const std::function<std::string(int)> dval = [sMSK](int f) { return "xs[" + std::to_string(f - 1) + "][lane & " + sMSK + "]"; };
     RowTerms rt(ndim + 1);
     for (int i = 1; i <= ndim; ++i)
         for (const WX &t : wx[i]) {
@@ -1614,12 +1618,12 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
             else rt[i].push_back({i, t.w, ndim + t.x, t.c});                 // node w_j < node x_k
         }
     const std::vector<std::vector<int>> owns = lds_partition(ndim, ndim + nx, rt, W, cap, opt.lds_group);
-    const NodeFn node = [ndim, xs_bytes](int n) {
-        return n <= ndim ? LdsNode{xs_bytes + (int64_t)(n - 1) * 512, 0} : LdsNode{(int64_t)(n - ndim - 1) * 128, 1};
+    const NodeFn node = [ndim, xs_bytes, MT](int n) {
+        return n <= ndim ? LdsNode{xs_bytes + (int64_t)(n - 1) * 512, 0} : LdsNode{(int64_t)(n - ndim - 1) * (MT * 8), 1};
     };
     std::ostringstream o;
     std::vector<KTable> tables(W);
-    o << "\n// " << (adjoint ? "adjoint" : "tangent") << " model, run-time stage count, 16 members x 4 columns per workgroup of " << W
+    o << "\n// " << (adjoint ? "adjoint" : "tangent") << " model, run-time stage count, " << MT << " members x " << NC << " columns per workgroup of " << W
       << " wavefronts,\n// stage state and tangent stage vector in LDS, factors cached in registers per phase (cap " << cap << ")\n";
     o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
       << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
@@ -1630,23 +1634,23 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
       << "    int backward, int write_final, f64 inverse, int S)\n{\n";
-    o << "    __shared__ f64 lds_all[" << nx * 16 + ndim * 64 << "];\n"
-      << "    f64 (*xs)[16] = (f64 (*)[16])lds_all;                       // stage state of the 16 members"
+    o << "    __shared__ f64 lds_all[" << nx * MT + ndim * 64 << "];\n"
+      << "    f64 (*xs)[" << MT << "] = (f64 (*)[" << MT << "])lds_all;                       // stage state of the " << MT << " members"
       << (der.empty() ? "" : " + derived monomials") << "\n"
-      << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << nx * 16 << ");   // tangent stage vector of the 64 pairs\n";
+      << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << nx * MT << ");   // tangent stage vector of the 64 pairs\n";
     o << "    const int lane = threadIdx.x & 63;\n"
-      << "    const unsigned lane8 = (unsigned)lane * 8u, xl8 = (unsigned)(lane & 15) * 8u;\n"
+      << "    const unsigned lane8 = (unsigned)lane * 8u, xl8 = (unsigned)(lane & " << sMSK << ") * 8u;\n"
       << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
       << "    const i64 L = n_tg * ld;\n"
-      << "    const i64 mt = (i64)blockIdx.x * 16, m0 = mt + (lane & 15), c0 = (i64)blockIdx.y * 4 + (lane >> 4);\n"
+      << "    const i64 mt = (i64)blockIdx.x * " << MT << ", m0 = mt + (lane & " << sMSK << "), c0 = (i64)blockIdx.y * " << NC << " + (lane >> " << sMSH << ");\n"
       << "    const bool live = (m0 < n_traj) && (c0 < n_tg);\n"
       << "    const i64 m = m0 < n_traj ? m0 : (n_traj - 1), col = c0 < n_tg ? c0 : (n_tg - 1);\n"
       << "    const i64 l = col * ld + m;                                  // this pair's lane of F[mode][col][member]\n"
       << "    f64* const vw = vwork + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * " << ndim * 64 << " + lane;\n"
-      << "    // stage-state tile of the 16 members, loaded by the whole workgroup: element e -> (mode e / 16, member e % 16)\n"
-      << "    i64 xm = mt + (threadIdx.x & 15); if (xm >= n_traj) xm = n_traj - 1;\n"
+      << "    // stage-state tile of the " << MT << " members, loaded by the whole workgroup: element e -> (mode e / " << MT << ", member e % " << MT << ")\n"
+      << "    i64 xm = mt + (threadIdx.x & " << sMSK << "); if (xm >= n_traj) xm = n_traj - 1;\n"
       << "#define QGS_LOAD_XS(sp) do { const f64* sp_ = (sp); \\\n"
-      << "        for (int e = threadIdx.x; e < " << ndim * 16 << "; e += " << 64 * W << ") xs[e >> 4][e & 15] = sp_[(i64)(e >> 4) * ld + xm]; } while (0)\n";
+      << "        for (int e = threadIdx.x; e < " << ndim * MT << "; e += " << 64 * W << ") xs[e >> " << sMSH << "][e & " << sMSK << "] = sp_[(i64)(e >> " << sMSH << ") * ld + xm]; } while (0)\n";
     LdsStats stats;
     for (int w = 0; w < W; ++w) {
         const std::vector<int> &own = owns[w];
@@ -1754,8 +1758,8 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::TglSplit: return "qgs_spec_tglsplit" + std::to_string(opt.tgl_split) + "_s" + std::to_string(S);
     case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
-    case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves);
-    case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves);
+    case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
+    case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
     case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);

@@ -43,6 +43,7 @@ struct CodegenOptions {
                                // already keeps the fp64 pipe 91 % busy)
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
+    int lds_tgl_members = 16;  // LDS-resident tangent kernels: members per workgroup tile (16 x 4 columns, or 8 x 8 columns)
     int lds_cap = 20;          // ... and modes cached in registers per phase (24 spills at 128 VGPRs: 63.6 ms vs 55.6 ms)
     bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)

@@ -306,6 +306,14 @@ struct qgs_model {
 
 namespace {
 
+// bytes of LDS the LDS-resident tangent kernel needs: stage state (+ derived monomials) of the tile's members (16, or 8 when
+// 16 do not fit), tangent vector of 64 pairs
+size_t lds_tgl_bytes(const qgs_model *m, int members = 0)
+{
+    if (members == 0) members = m->cg.lds_tgl_members;
+    return ((size_t)m->ndim + m->der.j.size()) * 8 * (size_t)members + (size_t)m->ndim * 512;
+}
+
 // Which specialised kernel families a model can have (shared by qgs_model_create_rank and qgs_prebuild_rank).
 //   register-resident: ndim <= 64 and (rank 5) at most QGS_SPEC_MAX_DERIVED derived monomials per evaluation
 //   LDS-resident: stage state + derived monomials fit one workgroup's LDS; used when the register kernels do not exist,
@@ -323,10 +331,10 @@ void classify_model(qgs_model *m)
     if (const char *e = std::getenv("QGS_HIP_PREFER_LDS")) m->prefer_lds = m->spec_possible && (*e == '1');
     const bool fits = (ndim + nt) * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
     m->lds_spec_possible = fits && (!m->spec_possible || m->prefer_lds);
+    if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MEMBERS")) m->cg.lds_tgl_members = (std::atoi(e) == 8) ? 8 : 16;
+    else m->cg.lds_tgl_members = (lds_tgl_bytes(m, 16) > (size_t)QGS_LDS_STATE_BYTES) ? 8 : 16;
 }
 
-// bytes of LDS the LDS-resident tangent kernel needs: stage state (+ derived monomials) of 16 members, tangent vector of 64 pairs
-size_t lds_tgl_bytes(const qgs_model *m) { return ((size_t)m->ndim + m->der.j.size()) * 128 + (size_t)m->ndim * 512; }
 
 int upload_csr(const HostCsr &h, DevCsr &d)
 {
@@ -693,7 +701,8 @@ int launch_tgl_lds(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const
     hipFunction_t f;
     std::string name;
     if (get_function(m, adjoint ? qgs::Kernel::AdjLds : qgs::Kernel::TglLds, 0, &f, &name)) return -1;
-    const int64_t bx = (n_traj + 15) / 16, by = (n_tg + 3) / 4;
+    const int MT = m->cg.lds_tgl_members, NC = 64 / MT;
+    const int64_t bx = (n_traj + MT - 1) / MT, by = (n_tg + NC - 1) / NC;
     if (by > 65535) return fail("too many tangent columns for the LDS-resident tangent kernel");
     if (m->b_vwork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)(bx * by))) return -1;
     double *vw = m->b_vwork.f64();

@@ -411,10 +411,15 @@ def test_lds_resident_kernels_on_a_second_tensor_ndim72():
     f.operands.release()
 
 
-def test_lds_resident_kernels_rank5_ndim106():
+@pytest.mark.parametrize('tile_members', [16, 8])
+def test_lds_resident_kernels_rank5_ndim106(monkeypatch, tile_members):
     """Dynamic-T MAOOAM 4x4 / 4x4 (ndim 106, rank-5 tensor, 4 / 56 derived monomials): the LDS-resident stepper, tangent and
-    adjoint kernels with the derived monomials as LDS nodes, and the 4-factor generic kernels, against the oracle."""
+    adjoint kernels with the derived monomials as LDS nodes, and the 4-factor generic kernels, against the oracle.  The
+    tangent kernels in both tile shapes: 16 members x 4 columns and 8 x 8 (chosen automatically when the stage state and
+    its derived monomials of 16 members do not fit the LDS, e.g. dynamic-T MAOOAM 6x6)."""
     from model_configs import params_d106
+    if tile_members == 8:
+        monkeypatch.setenv('QGS_HIP_LDS_TGL_MEMBERS', '8')
     from oracle.oracle import OracleModel
     from qgs_amd.functions.tendencies import create_tendencies
     p = params_d106()
@@ -430,7 +435,8 @@ def test_lds_resident_kernels_rank5_ndim106():
     t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
     ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = rng.randn(9, f.ndim, 6)
-    for kind, names in ((1, ('gen_rk_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16'))):
+    sfx = 'm8' if tile_members == 8 else ''
+    for kind, names in ((1, ('gen_rk_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16' + sfx))):
         m.set_kernel(kind)
         assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14, kind
         out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
@@ -441,5 +447,5 @@ def test_lds_resident_kernels_rank5_ndim106():
             tr, fm = m.rk_tgls_integrate(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
             assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (kind, adj)
         if names[1]:
-            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16'
+            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16' + sfx
     f.operands.release()
