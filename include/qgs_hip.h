@@ -152,6 +152,7 @@ int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_
 /* Batched QR of one (n_rows x n_cols) matrix per member, device layout A[row][col][member]: A is replaced by Q
  * (LAPACK Householder sign convention), d_rdiag[col][member] receives diag(R).  Replaces the per-trajectory
  * `np.linalg.qr` of the Benettin loops, qgs/toolbox/lyapunov.py:540-547, 599-628. */
+/* (n_rows <= 64: a kernel generated and compiled for the shape, columns in registers; larger: one matrix per wavefront in LDS.) */
 int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_cols,
                           double *d_a, double *d_rdiag, void *stream);
 
@@ -170,6 +171,9 @@ int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val,
 int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val,
                       int64_t jnnz, const int32_t *jcoo, const double *jval,
                       int n_stage_counts, const int *stage_counts, const char *arch);
+
+/* Same for the shape-specialised batched QR kernel of qgs_batched_qr_device (n_cols <= n_rows <= 64). */
+int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch);
 
 /* Generated HIP source of the specialised kernels of this model (debugging / inspection).
  * Returns the length; copies at most buflen-1 bytes. */

@@ -49,6 +49,7 @@ SIGNATURES = {
                                     ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
     'qgs_prebuild_rank': (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
+    'qgs_prebuild_qr': (_int, [_int, _int, ctypes.c_char_p]),
     'qgs_model_kernel_source': (_i64, [_vp, ctypes.c_char_p, _i64]),
 }
 
@@ -194,6 +195,11 @@ def prebuild(ndim, coo, val, jcoo, jval, stage_counts=(4,), arch=None):
     _check(lib().qgs_prebuild_rank(int(ndim), _tensor_rank(coo, jcoo), len(val), _ptr(coo), _ptr(val),
                                    0 if jval is None else len(jval), _ptr(jcoo), _ptr(jval), len(stage_counts), sc,
                                    arch.encode() if arch else None))
+
+
+def prebuild_qr(n_rows, n_cols, arch=None):
+    """Compile + cache the batched-QR kernel of one matrix shape without a GPU (see qgs_prebuild_qr)."""
+    _check(lib().qgs_prebuild_qr(int(n_rows), int(n_cols), arch.encode() if arch else None))
 
 
 class HipModel(object):

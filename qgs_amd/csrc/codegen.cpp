@@ -1739,6 +1739,70 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 
 }  // namespace
 
+// Batched Householder QR, one (n_rows x n_cols) matrix per wavefront, fully unrolled for the given shape: lane c keeps
+// column c in registers, the pivot column of step j is broadcast from lane j with v_readlane (j is a compile-time
+// constant, so is every row index: no selects, no LDS, no barriers), after which every lane has the reflector and forms
+// norm / beta / tau itself.  Same conventions as the LDS kernel of generic_kernels.hip (LAPACK dgeqr2 + dorg2r).
+std::string generate_qr_kernel(int n_rows, int n_cols)
+{
+    const int R = n_rows, C = n_cols, K = std::min(R, C);
+    std::ostringstream o;
+    o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
+    o << "__device__ __forceinline__ f64 qgs_bcast(f64 x, int lane)\n{\n"
+      << "    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);\n"
+      << "    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);\n"
+      << "    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);\n"
+      << "    return __builtin_bit_cast(f64, ((unsigned long long)hi << 32) | lo);\n}\n";
+    o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << " per wavefront, lane = column\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_qr_" << R << "x" << C
+      << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld)\n{\n";
+    o << "    const i64 m = blockIdx.x;\n    const int c = threadIdx.x;\n    const bool col = c < " << C << ";\n";
+    o << "    f64* const ap = a + (col ? c : 0) * ld + m;\n";
+    for (int i = 0; i < R; ++i) o << "    f64 q" << i << " = col ? ap[(i64)" << i * C << " * ld] : 0.0;\n";
+    o << "    f64 tau = 0.0;                       // lane j keeps tau_j\n";
+    for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
+        o << "    {   // column " << j << "\n";
+        for (int i = j; i < R; ++i) o << "        const f64 v" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
+        o << "        f64 xn2 = 0.0;\n";
+        for (int i = j + 1; i < R; ++i) o << "        xn2 = __builtin_fma(v" << i << ", v" << i << ", xn2);\n";
+        o << "        const f64 alpha = v" << j << ";\n"
+          << "        f64 t = 0.0, beta = alpha, scale = 0.0;\n"
+          << "        if (xn2 != 0.0) {\n"
+          << "            beta = -__builtin_copysign(__builtin_sqrt(__builtin_fma(alpha, alpha, xn2)), alpha);\n"
+          << "            t = (beta - alpha) / beta;\n"
+          << "            scale = 1.0 / (alpha - beta);\n"
+          << "        }\n";
+        for (int i = j + 1; i < R; ++i) o << "        const f64 u" << i << " = v" << i << " * scale;\n";
+        o << "        if (c > " << j << ") {\n            f64 w = q" << j << ";\n";
+        for (int i = j + 1; i < R; ++i) o << "            w = __builtin_fma(u" << i << ", q" << i << ", w);\n";
+        o << "            w *= t;\n            q" << j << " -= w;\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
+        o << "        }\n";
+        o << "        if (c == " << j << ") {\n            tau = t;\n            rdiag[(i64)" << j << " * ld + m] = beta;\n            q" << j << " = beta;\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = u" << i << ";\n";
+        o << "        }\n    }\n";
+    }
+    for (int j = K - 1; j >= 0; --j) {              // ---- dorg2r
+        o << "    {   // Q: reflector " << j << "\n";
+        o << "        const f64 t = qgs_bcast(tau, " << j << ");\n";
+        for (int i = j + 1; i < R; ++i) o << "        const f64 u" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
+        o << "        if (c > " << j << ") {\n            f64 w = q" << j << ";\n";
+        for (int i = j + 1; i < R; ++i) o << "            w = __builtin_fma(u" << i << ", q" << i << ", w);\n";
+        o << "            w *= t;\n            q" << j << " -= w;\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
+        o << "        }\n";
+        o << "        if (c == " << j << ") {\n";
+        for (int i = 0; i < j; ++i) o << "            q" << i << " = 0.0;\n";
+        o << "            q" << j << " = 1.0 - t;\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = -t * u" << i << ";\n";
+        o << "        }\n    }\n";
+    }
+    o << "    if (col) {\n";
+    for (int i = 0; i < R; ++i) o << "        ap[(i64)" << i * C << " * ld] = q" << i << ";\n";
+    o << "    }\n}\n";
+    return o.str();
+}
+
 bool tableau_is_subdiagonal(int s, const double *a)
 {
     for (int i = 0; i < s; ++i)

@@ -101,6 +101,11 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der = Derived());
 
+// Batched Householder QR fully unrolled for one matrix shape (n_rows, n_cols <= 64): kernel `qgs_spec_qr_<rows>x<cols>`
+// (a, rdiag, n_traj, ld), one wavefront per matrix, columns in registers.  Replaces np.linalg.qr in the Benettin loops
+// (qgs/toolbox/lyapunov.py:540-547, 599-628).
+std::string generate_qr_kernel(int n_rows, int n_cols);
+
 // Rough count of fp64 VALU instructions of one tendency evaluation in the generated code
 // (used for the roofline note in the bench output and DESIGN.md).
 int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, const CodegenOptions &opt);

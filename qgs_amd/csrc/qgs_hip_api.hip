@@ -1228,6 +1228,30 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows) return fail("batched QR needs 1 <= n_cols <= n_rows");
     if (n_cols > 64 || n_rows > 300) return fail("batched QR supports n_cols <= 64 (one column per lane) and n_rows <= 300 (LDS)");
     HIPCHK(hipSetDevice(m->device));
+    static const bool lds_only = [] { const char *e = std::getenv("QGS_HIP_QR"); return e && !std::strcmp(e, "lds"); }();
+    if (!lds_only && m->kernel_kind != 1 && n_rows <= 64) {
+        // shape-specialised kernel, columns in registers (codegen generate_qr_kernel), compiled once per shape
+        const std::string fname = "qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols);
+        hipFunction_t f = nullptr;
+        auto it = m->functions.find(fname);
+        if (it != m->functions.end()) f = it->second;
+        else {
+            std::vector<char> code;
+            bool cached = false;
+            if (compile_source(qgs::generate_qr_kernel(n_rows, n_cols), m->arch, code, &cached)) return -1;
+            hipModule_t mod;
+            HIPCHK(hipModuleLoadData(&mod, code.data()));
+            m->modules[fname] = mod;
+            hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
+            if (e != hipSuccess) return fail("kernel " + fname + " not found in its module: " + hipGetErrorString(e));
+            m->functions[fname] = f;
+        }
+        long long nt = n_traj, l = ld;
+        void *args[] = {(void *)&d_a, (void *)&d_rdiag, &nt, &l};
+        note_kernel(m, fname, f);
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)n_traj, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+        return 0;
+    }
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
@@ -1410,6 +1434,14 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
     return 0;
+}
+
+int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
+{
+    if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 64");
+    std::vector<char> code;
+    bool cached;
+    return compile_source(qgs::generate_qr_kernel(n_rows, n_cols), (arch && *arch) ? arch : target_arch(-1), code, &cached);
 }
 
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
