@@ -449,3 +449,52 @@ def test_lds_resident_kernels_rank5_ndim106(monkeypatch, tile_members):
         if names[1]:
             assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16' + sfx
     f.operands.release()
+
+
+def test_kernel_selection_at_the_baseline_configurations(models):
+    """Which kernel the library picks at the sizes of BASELINE.json (a guard against silently falling onto a slower path):
+    config 2 (65 536 members, MAOOAM-36) -> the plain register-resident stepper; smaller ensembles -> 4-way row split /
+    wavefront-per-trajectory; config 3 (ndim 228) -> the LDS-resident stepper; config 4 (16 384 members x 36 columns) -> the
+    one-wavefront tangent kernel, 65 536 members -> the shared-stage-state one; rank-5 models -> register-resident
+    (dynamic T) / LDS-resident (T4) kernels; a non-sub-diagonal tableau -> the general-tableau stepper."""
+    import torch
+    from qgs_amd import _lib  # noqa: F401
+    st = torch.cuda.current_stream().cuda_stream
+    t2 = np.array([0., 0.1, 0.2])
+
+    def stepper_name(m, ndim, n, b=RK4['b'], c=RK4['c'], a=RK4['a']):
+        ic = torch.full((ndim, n), 0.01, dtype=torch.float64, device='cuda')
+        rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')
+        m.rk_integrate_device(n, n, ic.data_ptr(), t2, 1, 0, b, c, a, rec.data_ptr(), st)
+        torch.cuda.synchronize()
+        return m.last_kernel_info()['name']
+
+    def tangent_name(m, ndim, n, n_tg):
+        ic = torch.full((ndim, n), 0.01, dtype=torch.float64, device='cuda')
+        tg = torch.zeros((ndim, n_tg, n), dtype=torch.float64, device='cuda')
+        rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')
+        recm = torch.empty((1, ndim, n_tg, n), dtype=torch.float64, device='cuda')
+        tt = np.concatenate((np.arange(0., 0.1 - 1e-12, 0.01), [0.1]))
+        m.rk_tgls_integrate_device(n, n, n_tg, ic.data_ptr(), tg.data_ptr(), tt, 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.,
+                                   rec.data_ptr(), recm.data_ptr(), st)
+        torch.cuda.synchronize()
+        return m.last_kernel_info()['name']
+
+    m36 = models('m36')
+    m36.set_kernel(0)
+    assert stepper_name(m36, 36, 65536) == 'qgs_spec_rk_s4'
+    assert stepper_name(m36, 36, 16384) == 'qgs_spec_rksplit4_s4'
+    assert stepper_name(m36, 36, 64) == 'gen_rk_wave_kernel'
+    assert tangent_name(m36, 36, 16384, 36) == 'qgs_spec_tgl_s4'
+    assert tangent_name(m36, 36, 65536, 36) == 'qgs_spec_tglx4_s4'
+    r38 = (np.array([1., 3., 3., 1.]) / 8., np.array([0., 1. / 3, 2. / 3, 1.]),
+           np.array([[0., 0, 0, 0], [1. / 3, 0, 0, 0], [-1. / 3, 1., 0, 0], [1., -1., 1., 0]]))
+    assert stepper_name(m36, 36, 65536, *r38) == 'qgs_spec_rkd_s4'
+    t228 = models('t228')
+    t228.set_kernel(0)
+    assert stepper_name(t228, 228, 4096) == 'qgs_spec_rklds16'
+    d38, q38 = models('d38'), models('q38')
+    d38.set_kernel(0)
+    q38.set_kernel(0)
+    assert stepper_name(d38, 38, 65536) == 'qgs_spec_rk_s4'
+    assert stepper_name(q38, 38, 4096) == 'qgs_spec_rklds16'
