@@ -113,6 +113,9 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
 // rdiag[col][member] receives diag(R).  Used by the Benettin Lyapunov
 // estimator (reference: np.linalg.qr in qgs/toolbox/lyapunov.py:540-547, 599-628).
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st);
+// any shape (n_cols > 64 or matrices beyond the LDS): matrix in a global scratch copy, scratch = n_traj * (n_rows + 1) * n_cols doubles
+void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
+                              hipStream_t st);
 // mean / variance over the members of every row of X[row][member]; `part` holds 2 * n_rows * moments_splits() doubles
 int moments_splits(int64_t n_rows, int64_t n_traj);
 void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x, double *part, double *mean, double *var,

@@ -877,6 +877,98 @@ void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x,
                        part, mean, var);
 }
 
+// Matrices that fit neither the register file nor the LDS (full Lyapunov spectrum of MAOOAM 6x6: 228 x 228 = 416 KB):
+// one workgroup of 256 threads per matrix, the matrix in a contiguous scratch copy B[row][col] in global memory (column
+// index fastest, so the threads of the column loops read consecutive doubles), the pivot column staged in LDS.  Same
+// Householder conventions as above.  Functional rather than fast: these are few-member workloads.
+constexpr int QRG_THREADS = 256;
+
+__device__ __forceinline__ double block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int q = 0; q < QRG_THREADS / WAVE; ++q) t += red[q];
+    return t;
+}
+
+__global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
+                                                                        double *__restrict__ a, double *__restrict__ rdiag,
+                                                                        double *__restrict__ scratch, double *__restrict__ taus)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *v = (double *)smem;                            // pivot column (n_rows)
+    __shared__ double red[QRG_THREADS / WAVE];
+    __shared__ double s_t, s_beta;
+    const int64_t m = blockIdx.x;
+    const int tid = threadIdx.x;
+    double *B = scratch + (int64_t)m * n_rows * n_cols;
+    double *tau = taus + (int64_t)m * n_cols;
+    for (int64_t e = tid; e < (int64_t)n_rows * n_cols; e += QRG_THREADS) B[e] = a[e * ld + m];
+    __syncthreads();
+    const int k = n_cols < n_rows ? n_cols : n_rows;
+    for (int j = 0; j < k; ++j) {
+        // ---- dlarfg on column j
+        double part = 0.0;
+        for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) { const double x = B[(int64_t)i * n_cols + j]; part = __builtin_fma(x, x, part); }
+        const double xn2 = block_sum(part, red);
+        if (tid == 0) {
+            const double alpha = B[(int64_t)j * n_cols + j];
+            double t = 0.0, beta = alpha;
+            if (xn2 != 0.0) { beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha); t = (beta - alpha) / beta; }
+            s_t = t; s_beta = beta;
+            v[j] = (xn2 != 0.0) ? 1.0 / (alpha - beta) : 0.0;            // the scale, read by everybody below
+        }
+        __syncthreads();
+        const double t = s_t, beta = s_beta, scale = v[j];
+        __syncthreads();
+        for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) {
+            const double x = B[(int64_t)i * n_cols + j] * (xn2 != 0.0 ? scale : 1.0);
+            B[(int64_t)i * n_cols + j] = x;
+            v[i] = x;
+        }
+        if (tid == 0) { tau[j] = t; rdiag[(int64_t)j * ld + m] = beta; }
+        __syncthreads();
+        // ---- dlarf on the columns right of j
+        for (int c = j + 1 + tid; c < n_cols; c += QRG_THREADS) {
+            double w = B[(int64_t)j * n_cols + c];
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w);
+            w *= t;
+            B[(int64_t)j * n_cols + c] -= w;
+            for (int i = j + 1; i < n_rows; ++i) B[(int64_t)i * n_cols + c] = __builtin_fma(-w, v[i], B[(int64_t)i * n_cols + c]);
+        }
+        if (tid == 0) B[(int64_t)j * n_cols + j] = beta;
+        __syncthreads();
+    }
+    for (int j = k - 1; j >= 0; --j) {                     // ---- dorg2r
+        const double t = tau[j];
+        for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) v[i] = B[(int64_t)i * n_cols + j];
+        __syncthreads();
+        for (int c = j + 1 + tid; c < n_cols; c += QRG_THREADS) {
+            double w = B[(int64_t)j * n_cols + c];
+            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w);
+            w *= t;
+            B[(int64_t)j * n_cols + c] -= w;
+            for (int i = j + 1; i < n_rows; ++i) B[(int64_t)i * n_cols + c] = __builtin_fma(-w, v[i], B[(int64_t)i * n_cols + c]);
+        }
+        for (int i = tid; i < n_rows; i += QRG_THREADS)
+            B[(int64_t)i * n_cols + j] = (i > j) ? -t * v[i] : ((i == j) ? 1.0 - t : 0.0);
+        __syncthreads();
+    }
+    for (int64_t e = tid; e < (int64_t)n_rows * n_cols; e += QRG_THREADS) a[e * ld + m] = B[e];
+}
+
+void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
+                              hipStream_t st)
+{
+    double *taus = scratch + (size_t)n_traj * n_rows * n_cols;
+    hipLaunchKernelGGL(batched_qr_global_kernel, dim3((unsigned)n_traj), dim3(QRG_THREADS), sizeof(double) * (size_t)n_rows, st,
+                       n_rows, n_cols, n_traj, ld, a, rdiag, scratch, taus);
+}
+
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (size_t)n_rows * QR_STRIDE;

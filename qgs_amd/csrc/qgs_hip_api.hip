@@ -1226,8 +1226,16 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
 {
     if (check_common(m, n_traj, ld)) return -1;
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows) return fail("batched QR needs 1 <= n_cols <= n_rows");
-    if (n_cols > 64 || n_rows > 300) return fail("batched QR supports n_cols <= 64 (one column per lane) and n_rows <= 300 (LDS)");
+    if (n_rows > 16384) return fail("batched QR: n_rows too large");
     HIPCHK(hipSetDevice(m->device));
+    if (n_cols > 64 || n_rows > 300) {
+        // beyond one column per lane / the LDS (e.g. the full 228-vector Lyapunov basis of MAOOAM 6x6): global-memory kernel
+        if (m->work.ensure(sizeof(double) * (size_t)n_traj * ((size_t)n_rows + 1) * (size_t)n_cols)) return -1;
+        qgs::launch_batched_qr_global(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->work.f64(), (hipStream_t)stream);
+        note_kernel(m, "batched_qr_global_kernel", nullptr);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     static const bool lds_only = [] { const char *e = std::getenv("QGS_HIP_QR"); return e && !std::strcmp(e, "lds"); }();
     if (!lds_only && m->kernel_kind != 1 && n_rows <= 64) {
         // shape-specialised kernel, columns in registers (codegen generate_qr_kernel), compiled once per shape

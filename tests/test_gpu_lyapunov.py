@@ -18,13 +18,18 @@ def test_batched_qr_matches_lapack():
     f, _ = tendencies_from_tensor(2, np.array([[1, 0, 1]], dtype=np.int32), np.array([1.0]))
     m = f.hip_model()
     rng = np.random.RandomState(0)
-    for n_rows, n_cols, n in ((36, 36, 70), (20, 5, 3), (7, 1, 64)):
+    # shapes: register-resident generated kernels (rows <= 64), the LDS kernel (cols <= 64, rows <= 300), the global-memory kernel
+    for n_rows, n_cols, n in ((36, 36, 70), (20, 5, 3), (7, 1, 64), (64, 64, 2), (228, 40, 3), (100, 80, 2), (228, 228, 2), (320, 10, 2)):
         a = rng.randn(n, n_rows, n_cols)
         ld = (n + 63) // 64 * 64
         d = torch.zeros((n_rows, n_cols, ld), dtype=torch.float64, device='cuda')
         d[:, :, :n] = torch.from_numpy(np.ascontiguousarray(a.transpose(1, 2, 0))).cuda()
         rd = torch.zeros((n_cols, ld), dtype=torch.float64, device='cuda')
         m.batched_qr_device(n, ld, n_rows, n_cols, d.data_ptr(), rd.data_ptr())
+        torch.cuda.synchronize()
+        expect = 'qgs_spec_qr_%dx%d' % (n_rows, n_cols) if n_rows <= 64 else ('' if (n_cols <= 64 and n_rows <= 300) else 'batched_qr_global_kernel')
+        if expect:
+            assert m.last_kernel_info()['name'] == expect
         q = d[:, :, :n].cpu().numpy().transpose(2, 0, 1)
         r_diag = rd[:, :n].cpu().numpy().T
         for i in range(n):
@@ -60,3 +65,27 @@ def test_lyapunov_estimator_vs_reference(name):
         else:
             assert tt == grid[-1]
     est.terminate()
+
+
+def test_full_lyapunov_spectrum_at_ndim228():
+    """MAOOAM 6x6: the full basis of 228 vectors (the reference's default n_vec = n_dim) -- the QR of a 228 x 228 matrix per
+    member runs in the global-memory kernel.  No golden at this size (the reference needs hours); checked: the backward
+    vectors are orthonormal and the exponents finite and ordered like a spectrum (largest first on average)."""
+    from conftest import load_golden
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
+    g = load_golden('t228')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    est = LyapunovsEstimator(num_threads=1)
+    est.set_func(f, Df)
+    np.random.seed(5)
+    ic = np.random.RandomState(1).rand(2, g.ndim) * 0.01
+    est.compute_lyapunovs(0., 0.4, 1.0, 0.1, 0.05, ic=ic, write_steps=2, n_vec=None, forward=False)
+    tt, traj, exps, vecs = est.get_lyapunovs()
+    assert vecs.shape[:3] == (2, g.ndim, g.ndim) and exps.shape[:2] == (2, g.ndim)
+    assert np.isfinite(exps).all() and np.isfinite(vecs).all()
+    for i in range(2):
+        q = vecs[i, :, :, -1]
+        assert np.abs(q.T @ q - np.eye(g.ndim)).max() < 1e-11
+    est.terminate()
+    f.operands.release()
