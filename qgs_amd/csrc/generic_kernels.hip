@@ -1,6 +1,8 @@
 // generic_kernels.hip -- see generic_kernels.h.  gfx950 only.
 #include "generic_kernels.h"
 
+#include <algorithm>
+
 namespace qgs {
 
 namespace {
@@ -725,11 +727,12 @@ __global__ void __launch_bounds__(256) unpack_records_kernel(int64_t n_inner, in
                                                              const double *__restrict__ in, double *__restrict__ out)
 {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t q = blockIdx.y;
     if (m >= n_traj) return;
-    double *o = out + (m * n_inner + q) * n_records;
-    const double *i = in + q * ld + m;
-    for (int64_t r = 0; r < n_records; ++r) o[r] = i[r * n_inner * ld];
+    for (int64_t q = blockIdx.y; q < n_inner; q += gridDim.y) {        // gridDim.y is capped at 65 535
+        double *o = out + (m * n_inner + q) * n_records;
+        const double *i = in + q * ld + m;
+        for (int64_t r = 0; r < n_records; ++r) o[r] = i[r * n_inner * ld];
+    }
 }
 
 }  // namespace
@@ -1017,8 +1020,8 @@ void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t 
                            n_inner, n_traj, ld, in, out);
         return;
     }
-    hipLaunchKernelGGL(unpack_records_kernel, dim3(blocks_for(n_traj, 256), (unsigned)n_inner), dim3(256), 0, st, n_inner,
-                       n_traj, ld, n_records, in, out);
+    hipLaunchKernelGGL(unpack_records_kernel, dim3(blocks_for(n_traj, 256), (unsigned)std::min<int64_t>(n_inner, 65535)), dim3(256), 0, st,
+                       n_inner, n_traj, ld, n_records, in, out);
 }
 
 void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)

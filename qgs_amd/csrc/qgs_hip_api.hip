@@ -932,7 +932,7 @@ int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner
                        double *d_out, void *stream)
 {
     if (check_common(m, n_traj, ld)) return -1;
-    if (n_inner < 1 || n_inner > 65535 || n_records < 1) return fail("bad n_inner / n_records");
+    if (n_inner < 1 || n_inner > (int64_t)65535 * 64 || n_records < 1) return fail("bad n_inner / n_records");
     HIPCHK(hipSetDevice(m->device));
     qgs::launch_unpack_records(n_inner, n_traj, ld, n_records, d_in, d_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
@@ -1378,7 +1378,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
 {
     if (!m || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
     if (!time || n_time < 1) return fail("bad time grid");
-    if ((int64_t)m->ndim * n_tg > 65535) return fail("ndim * n_tg > 65535 is not supported by the record unpack kernel");
+    if ((int64_t)m->ndim * n_tg > (int64_t)65535 * 64) return fail("ndim * n_tg too large for the layout conversion kernels");
     HIPCHK(hipSetDevice(m->device));
     const int64_t ld = round_ld(n_traj);
     const int64_t n_records = qgs_n_records(time, n_time, write_steps);

@@ -130,7 +130,7 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
     m.set_kernel(0)
 
 
-@pytest.mark.parametrize('n_traj,n_tg', [(1, 5), (17, 4), (40, 7)])
+@pytest.mark.parametrize('n_traj,n_tg', [(1, 5), (17, 4), (40, 7), (1, 300)])      # 228 x 300 > 65 535 (modes x columns)
 def test_lds_resident_tangent_ndim228_vs_oracle(models, n_traj, n_tg):
     """MAOOAM 6x6: the JIT LDS-resident tangent and adjoint kernels (16 members x 4 columns per workgroup; ragged
     member and column tiles) against the oracle: tangent forward with records, adjoint backward with `inverse`."""
