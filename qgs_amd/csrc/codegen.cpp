@@ -1455,14 +1455,18 @@ void emit_lds_derived(std::ostringstream &o, const char *ind, int nbase, const s
 // 60.9 instead of 55.1 ms for 65 536 members x 100 steps at ndim 228); a loop-free kernel built from the same phases
 // spills far worse (the scheduler hoists the LDS reads of all phases: 14.6 KB of scratch, 30x slower) -- which is also why
 // the exit is guarded by a run-time argument and not by something the compiler can prove.
+// dense: general lower-triangular tableau (tab = b[S], a[S*S]), kernel qgs_spec_rkldsd<W>.  The input of stage q is
+// P_q = y + dt * sum_{j<q} a_qj k_j: the next stage's input is completed in registers as before (its base is P_{st+1} instead
+// of y), the partial sums of the stages after it are read-modify-written in a private global buffer pwork[workgroup][q][mode][64]
+// (the LDS is full of stage state at these sizes; the buffer is L2 / Infinity-Cache resident).
 void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
-                        const std::vector<std::pair<int, int>> &der, bool tend_kernel = false)
+                        const std::vector<std::pair<int, int>> &der, bool tend_kernel = false, bool dense = false)
 {
     const int W = opt.lds_waves, cap = std::max(2, opt.lds_cap);
     const int nnode = ndim + (int)der.size();
     const std::vector<std::vector<int>> dshare = lds_derived_shares(ndim, der, W);
     const std::function<std::string(int)> dval = [](int f) { return "xs[" + std::to_string(f - 1) + "][lane]"; };
-    const std::string kname = std::string(tend_kernel ? "qgs_spec_tendlds" : "qgs_spec_rklds") + std::to_string(W);
+    const std::string kname = std::string(tend_kernel ? "qgs_spec_tendlds" : (dense ? "qgs_spec_rkldsd" : "qgs_spec_rklds")) + std::to_string(W);
     RowTerms rt(ndim + 1);
     for (int i = 1; i <= ndim; ++i) {
         for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
@@ -1479,6 +1483,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "    f64* __restrict__ y_out,        // final state, X[mode][member] (may be null)\n"
       << "    f64* __restrict__ ywork,        // private [workgroup][mode][64]: state at the start of the current step, re-read at\n"
       << "                                    // the end of every stage instead of being held in registers\n"
+      << (dense ? "    f64* __restrict__ pwork,        // private [workgroup][stage][mode][64]: partial sums of the later stages' inputs\n" : "")
       << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S"
@@ -1493,6 +1498,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);\n"
       << "    f64* const yw = ywork + (i64)blockIdx.x * " << ndim * 64 << " + lane;   // row d of this member at yw[(d-1)*64]\n";
+    if (dense) o << "    f64* const pw = pwork + (i64)blockIdx.x * S * " << ndim * 64 << " + lane;   // slot q of this workgroup at pw + q * " << ndim * 64 << "\n";
     LdsStats stats;
     for (int w = 0; w < W; ++w) {
         const std::vector<int> &own = owns[w];
@@ -1522,7 +1528,10 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         o << I3 << "for (int st = 0; st < S; ++st) {\n";
         o << I4 << "const bool last = (st == S - 1);\n";
         o << I4 << "const f64 hb = dt * tab[st];\n";
-        o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
+        if (dense) {
+            o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + (st + 1) * S + st];\n"
+              << I4 << "const f64* basep = (st == 0) ? yw : pw + (i64)(last ? st : st + 1) * " << ndim * 64 << ";   // P_{st+1}; P_1's base is y itself\n";
+        } else o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
         // opaque per-stage values: the compiler must not hoist the re-reads of the step-start state out of the stage
         // loop (they would occupy registers for the whole step), nor turn the last-stage select into a branch that
         // sinks those loads to their use
@@ -1551,7 +1560,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
-                            for (int d : own) h << I4 << "const f64 yg" << d << " = yw[yoff + " << (d - 1) * 64 << "];\n";
+                            for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
         o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
         g_ktab = nullptr;
@@ -1561,6 +1570,15 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
               << I4 << "    if (live) {\n";
             for (int d : own) o << I4 << "        y_out[" << (d - 1) << " * ld + m] = k" << d << ";\n";
             o << I4 << "    }\n" << I4 << "    return;\n" << I4 << "}\n";
+        }
+        if (dense) {
+            // partial sums of the stages after the next one: P_q (+)= dt a_q,st k  (stage 0 starts them from y = yg)
+            o << I4 << "for (int q = st + 2; q < S; ++q) {\n"
+              << I4 << "    const f64 hq = dt * tab[S + q * S + st];\n"
+              << I4 << "    f64* pq = pw + (i64)q * " << ndim * 64 << ";\n";
+            for (int d : own)
+                o << I4 << "    pq[" << (d - 1) * 64 << "] = __builtin_fma(hq, k" << d << ", st == 0 ? yg" << d << " : pq[" << (d - 1) * 64 << "]);\n";
+            o << I4 << "}\n";
         }
         for (int d : own) {
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
@@ -1830,6 +1848,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
     case Kernel::RkDense: return "qgs_spec_rkd_s" + std::to_string(S);
     case Kernel::TglDense: return "qgs_spec_tgld_s" + std::to_string(S);
+    case Kernel::RkLdsDense: return "qgs_spec_rkldsd" + std::to_string(opt.lds_waves);
     }
     return "";
 }
@@ -1871,6 +1890,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
         break;
     case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t); break;
     case Kernel::TendLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, true); break;
+    case Kernel::RkLdsDense: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, false, true); break;
     case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt, der.j); break;
     case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt, der.j); break;
     }

@@ -83,6 +83,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
 //   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
 //                            registers phase by phase; run-time stage count, optional stage store
+//   qgs_spec_rkldsd<W>       the LDS-resident stepper for a general lower-triangular tableau
 //   qgs_spec_tendlds<W>      f(x) with the same machinery (one evaluation)
 //   qgs_spec_tgllds<W> / qgs_spec_adjlds<W>   tangent / adjoint model of large systems, 16 members x 4 columns per
 //                            workgroup, stage state and tangent vector in LDS
@@ -93,7 +94,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds, RkDense, TglDense };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds, RkDense, TglDense, RkLdsDense };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

@@ -1057,6 +1057,25 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
     if (use_lds_spec(m, n_traj, n_time - 1, s, a))
         return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
                              n_records, backward, 1, s, st);
+    if (m->kernel_kind != 1 && m->lds_spec_possible && s >= 2 && s <= 64 && !qgs::tableau_is_subdiagonal(s, a) &&
+        tableau_is_lower_triangular(s, a) &&
+        lds_kernel_wanted(m, qgs::Kernel::RkLdsDense, (double)n_traj * (double)(n_time - 1) * (double)s * (double)m->T.size())) {
+        // general tableau at LDS-resident sizes: same kernel text, partial stage sums in a private global buffer
+        hipFunction_t f;
+        std::string name;
+        if (get_function(m, qgs::Kernel::RkLdsDense, 0, &f, &name)) return -1;
+        const int64_t blocks = (n_traj + 63) / 64;
+        if (m->b_ywork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)blocks)) return -1;
+        if (m->b_vwork.ensure(sizeof(double) * (size_t)s * m->ndim * 64 * (size_t)blocks)) return -1;
+        double *yw = m->b_ywork.f64(), *pw = m->b_vwork.f64(), *y_out = nullptr, *stg = nullptr;
+        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
+        int bw = backward, wf = 1, S = s;
+        void *args[] = {(void *)&d_ic, &y_out, &yw, &pw, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_full,
+                        &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S};
+        note_kernel(m, name, f);
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
+        return 0;
+    }
     if (m->kernel_kind != 1 && m->spec_possible && !m->prefer_lds && s >= 2 && s <= 8 && tableau_is_lower_triangular(s, a) &&
         (size_t)(s - 2) * m->ndim * 512 <= (size_t)QGS_LDS_STATE_BYTES) {
         // general explicit tableau: register-resident tendencies, partial stage sums in LDS (codegen emit_rk_dense_kernel)
@@ -1422,6 +1441,11 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
         bool cached;
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
         if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::TendLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        for (int S : stages)
+            if (S >= 3) {                                   // some 3+-stage scheme requested: also the general-tableau flavour
+                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLdsDense, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+                break;
+            }
         if (!m.J.empty() && !m.spec_jac_possible && lds_tgl_bytes(&m) <= (size_t)QGS_LDS_STATE_BYTES)
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
                 if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;

@@ -113,7 +113,9 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
     a3 = np.zeros((3, 3)); a3[1, 0] = .5; a3[2, 1] = 1.          # sub-diagonal 3-stage scheme
     b2, c2 = np.array([0., 1.]), np.array([0., .5])
     a2 = np.zeros((2, 2)); a2[1, 0] = .5
-    cases = [(1, 5, RK4['b'], RK4['c'], RK4['a']), (-1, 1, RK4['b'], RK4['c'], RK4['a']), (1, 0, b2, c2, a2), (1, 4, b3, c3, a3)]
+    ak = np.array([[0., 0, 0], [.5, 0, 0], [-1., 2., 0]])               # Kutta's third-order scheme: not sub-diagonal
+    cases = [(1, 5, RK4['b'], RK4['c'], RK4['a']), (-1, 1, RK4['b'], RK4['c'], RK4['a']), (1, 0, b2, c2, a2), (1, 4, b3, c3, a3),
+             (1, 3, b3, c3, ak), (-1, 0, b3, c3, ak)]
     refs = [ora.integrate_runge_kutta_jit(t, ic, d, ws, b, c, a, threads=4) for d, ws, b, c, a in cases]
     tg = rng.randn(min(n_traj, 3), g.ndim, 2)
     rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
@@ -121,7 +123,8 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
         m.set_kernel(kind)
         for (d, ws, b, c, a), ref in zip(cases, refs):
             out = m.rk_integrate(t, ic, d, ws, b, c, a)
-            assert m.last_kernel_info()['name'] == kname
+            dense = a is ak
+            assert m.last_kernel_info()['name'] == (kname if not dense else ('gen_rk_kernel' if kind == 1 else 'qgs_spec_rkldsd16'))
             assert out.shape == ref.shape and rel_err(out, ref) < 1e-12, (kind, d, ws, len(b))
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
