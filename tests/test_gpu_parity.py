@@ -466,9 +466,10 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     t2 = np.array([0., 0.1, 0.2])
 
     def stepper_name(m, ndim, n, b=RK4['b'], c=RK4['c'], a=RK4['a']):
-        ic = torch.full((ndim, n), 0.01, dtype=torch.float64, device='cuda')
-        rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')
-        m.rk_integrate_device(n, n, ic.data_ptr(), t2, 1, 0, b, c, a, rec.data_ptr(), st)
+        ld = (n + 63) // 64 * 64
+        ic = torch.full((ndim, ld), 0.01, dtype=torch.float64, device='cuda')
+        rec = torch.empty((1, ndim, ld), dtype=torch.float64, device='cuda')
+        m.rk_integrate_device(n, ld, ic.data_ptr(), t2, 1, 0, b, c, a, rec.data_ptr(), st)
         torch.cuda.synchronize()
         return m.last_kernel_info()['name']
 
@@ -496,8 +497,11 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     t228 = models('t228')
     t228.set_kernel(0)
     assert stepper_name(t228, 228, 4096) == 'qgs_spec_rklds16'
+    assert stepper_name(t228, 228, 1) == 'qgs_spec_rklds16'          # rows too long for the register wave kernel: LDS-resident even for one trajectory
     d38, q38 = models('d38'), models('q38')
     d38.set_kernel(0)
     q38.set_kernel(0)
     assert stepper_name(d38, 38, 65536) == 'qgs_spec_rk_s4'
     assert stepper_name(q38, 38, 4096) == 'qgs_spec_rklds16'
+    assert stepper_name(q38, 38, 1) == 'qgs_spec_rklds16'
+    assert stepper_name(d38, 38, 1) == 'gen_rk_wave_kernel'
