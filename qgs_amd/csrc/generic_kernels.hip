@@ -495,6 +495,72 @@ __global__ void __launch_bounds__(64 * NWV) gen_rk_wave_kernel(DevTensor T, RkAr
     }
 }
 
+// Long rows (more than 32 terms: MAOOAM 6x6 has up to 237): G lanes share a row.  Thread (row, sub) streams the terms
+// sub, sub + G, ... of its row from the CSR arrays, the G partial sums are combined with shuffles (G is a power of two and
+// divides 64, so a row never straddles wavefronts), lane sub == 0 does the Runge-Kutta update.  G is chosen so that
+// ndim * G threads fill a workgroup of up to 1024: one MAOOAM 6x6 trajectory advances with 912 lanes instead of 228.
+__global__ void __launch_bounds__(1024) gen_rk_waveg_kernel(DevTensor T, RkArgs p, int G, const double *__restrict__ y_in,
+                                                            double *__restrict__ y_out, double *__restrict__ rec,
+                                                            double *__restrict__ stages, const double *__restrict__ dtime,
+                                                            const double *__restrict__ tab, DerivedChains D)
+{
+    __shared__ double xs[2 * WAVE_XS_STRIDE];
+    const int ndim = p.ndim, s = p.s;
+    const int row = (int)threadIdx.x / G + 1, sub = (int)threadIdx.x % G;
+    const bool active = row <= ndim, owner = active && sub == 0;
+    const int64_t m = blockIdx.x;
+    const int64_t ld = p.ld, A = (int64_t)ndim * ld;
+    const int e0 = active ? T.rowptr[row] : 0, e1 = active ? T.rowptr[row + 1] : 0;
+    double y = active ? y_in[(int64_t)(row - 1) * ld + m] : 0.0;
+    if (threadIdx.x == 0) { xs[0] = 1.0; xs[WAVE_XS_STRIDE] = 1.0; }
+    if (owner) xs[row] = y;
+    WaveDerived wd;
+    wd.load(D);
+    __syncthreads();
+    wd.eval(xs);
+    int64_t iw = 0, next_rec = -1;
+    if (p.write_steps > 0) { iw = (p.step_begin + p.write_steps - 1) / p.write_steps; next_rec = iw * p.write_steps; }
+    int cur = 0;
+    for (int64_t ti = p.step_begin; ti < p.step_end; ++ti) {
+        const double dt = dtime[ti + 1] - dtime[ti];
+        if (ti == next_rec) {
+            if (owner) rec[rec_index(iw, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y;
+            ++iw; next_rec += p.write_steps;
+        }
+        double acc = y;
+        for (int st = 0; st < s; ++st) {
+            const char *xb = (const char *)(xs + cur * WAVE_XS_STRIDE);
+            double *xo = xs + (cur ^ 1) * WAVE_XS_STRIDE;
+            if (stages && owner) stages[((ti - p.step_begin) * s + st) * A + (int64_t)(row - 1) * ld + m] = *(const double *)(xb + row * 8);
+            double k0 = 0.0, k1 = 0.0;
+            int e = e0 + sub;
+            for (; e + G < e1; e += 2 * G) {               // two independent chains per lane
+                const uint32_t qa = T.idx[e], qb = T.idx[e + G];
+                k0 = __builtin_fma(T.val[e], *(const double *)(xb + (qa >> 16) * 8u) * *(const double *)(xb + (qa & 0xffffu) * 8u), k0);
+                k1 = __builtin_fma(T.val[e + G], *(const double *)(xb + (qb >> 16) * 8u) * *(const double *)(xb + (qb & 0xffffu) * 8u), k1);
+            }
+            if (e < e1) {
+                const uint32_t qa = T.idx[e];
+                k0 = __builtin_fma(T.val[e], *(const double *)(xb + (qa >> 16) * 8u) * *(const double *)(xb + (qa & 0xffffu) * 8u), k0);
+            }
+            double k = k0 + k1;
+            for (int off = G >> 1; off > 0; off >>= 1) k += __shfl_xor(k, off);
+            acc = __builtin_fma(dt * tab[st], k, acc);
+            const bool last = (st == s - 1);
+            const double xn = last ? acc : __builtin_fma(dt * tab[s + st], k, y);
+            if (owner) xo[row] = xn;
+            if (last) y = acc;
+            cur ^= 1;
+            __syncthreads();
+            wd.eval(xo);
+        }
+    }
+    if (owner) {
+        if (y_out) y_out[(int64_t)(row - 1) * ld + m] = y;
+        if (p.write_final) rec[rec_index(p.n_records - 1, p.n_records, p.backward) * A + (int64_t)(row - 1) * ld + m] = y;
+    }
+}
+
 template <int NWV, int REG_TERMS>
 hipError_t launch_wave(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
                        const double *dtime, const double *tab, hipStream_t st, const DerivedChains &D)
@@ -769,6 +835,14 @@ hipError_t launch_gen_rk_wave(const DevTensor &T, int max_row_terms, const RkArg
                               const DerivedChains &D)
 {
     const int nwv = (p.ndim + 63) / 64;
+    if (max_row_terms > 32) {                              // long rows: G lanes per row
+        int G = 1;
+        while (G < 16 && p.ndim * (2 * G) <= 1024) G *= 2;
+        const int threads = (p.ndim * G + 63) / 64 * 64;
+        hipLaunchKernelGGL(gen_rk_waveg_kernel, dim3((unsigned)p.n_traj), dim3(threads), 0, st, T, p, G, y_in, y_out, rec, stages, dtime,
+                           tab_spec, D);
+        return hipGetLastError();
+    }
 #define QGS_WAVE_CASE(N)                                                                                          \
     if (nwv == N) {                                                                                               \
         if (max_row_terms <= 16) return launch_wave<N, 16>(T, p, y_in, y_out, rec, stages, dtime, tab_spec, st, D); \

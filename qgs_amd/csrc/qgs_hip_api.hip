@@ -601,22 +601,17 @@ bool use_spec(const qgs_model *m, int s, const double *a)
 
 // wavefront-per-trajectory stepper for small ensembles: below QGS_HIP_WAVE_MAX_TRAJ members (default 4096, see
 // DESIGN.md 3.5) it beats one-member-per-lane because the lanes of the few wavefronts would do all rows serially
-bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work);
-
 bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
 {
     if (m->kernel_kind != 0) return false;                 // explicit generic / specialised request
-    int64_t limit = (m->max_row_terms <= 16) ? 2048 : (m->max_row_terms <= 32 ? 1024 : 256);   // measured crossovers (tools/latency_bench.py)
+    // measured crossovers (tools/latency_bench.py): rows in registers (<= 16 / <= 32 terms) 2048 / 1024 members; longer rows
+    // run the lane-group kernel (G lanes per row, terms streamed), which beats the LDS-resident JIT stepper up to ~600
+    // members (MAOOAM 6x6: 29 vs 102 us per RK4 step for one trajectory, 8.0 vs 20.4 ms per 200 steps at 256 members,
+    // 30 vs 20 ms at 1024; T4 MAOOAM: 12 vs 27 us per step)
+    int64_t limit = (m->max_row_terms <= 16) ? 2048 : (m->max_row_terms <= 32 ? 1024 : 512);
     if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
-    if (!(n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.t.size()) && m->wave_der_ok_t &&
-          qgs::tableau_is_subdiagonal(s, a)))
-        return false;
-    // rows too long for the register variants are streamed from memory every stage; the LDS-resident JIT stepper, when the
-    // model has one, is faster even for ONE trajectory (MAOOAM 6x6: 102 vs 138 us per RK4 step; T4 MAOOAM: 27 vs 193 us)
-    if (m->max_row_terms > 32 && m->lds_spec_possible && std::getenv("QGS_HIP_WAVE_MAX_TRAJ") == nullptr &&
-        lds_kernel_wanted(m, qgs::Kernel::RkLds, 0.0))
-        return false;
-    return true;
+    return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.t.size()) && m->wave_der_ok_t &&
+           qgs::tableau_is_subdiagonal(s, a);
 }
 
 // below this many (member, column) pairs the wavefront-per-pair kernel would be preferred to the LDS-resident tangent

@@ -497,11 +497,11 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     t228 = models('t228')
     t228.set_kernel(0)
     assert stepper_name(t228, 228, 4096) == 'qgs_spec_rklds16'
-    assert stepper_name(t228, 228, 1) == 'qgs_spec_rklds16'          # rows too long for the register wave kernel: LDS-resident even for one trajectory
+    assert stepper_name(t228, 228, 1) == 'gen_rk_wave_kernel'        # lane-group variant (4 lanes per row)
     d38, q38 = models('d38'), models('q38')
     d38.set_kernel(0)
     q38.set_kernel(0)
     assert stepper_name(d38, 38, 65536) == 'qgs_spec_rk_s4'
     assert stepper_name(q38, 38, 4096) == 'qgs_spec_rklds16'
-    assert stepper_name(q38, 38, 1) == 'qgs_spec_rklds16'
+    assert stepper_name(q38, 38, 1) == 'gen_rk_wave_kernel'
     assert stepper_name(d38, 38, 1) == 'gen_rk_wave_kernel'
