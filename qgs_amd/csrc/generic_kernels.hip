@@ -958,7 +958,7 @@ void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x,
 // one workgroup of 256 threads per matrix, the matrix in a contiguous scratch copy B[row][col] in global memory (column
 // index fastest, so the threads of the column loops read consecutive doubles), the pivot column staged in LDS.  Same
 // Householder conventions as above.  Functional rather than fast: these are few-member workloads.
-constexpr int QRG_THREADS = 256;
+constexpr int QRG_THREADS = 1024, QRG_COLS = 256, QRG_SUB = QRG_THREADS / QRG_COLS;    // 4 threads per column, each a quarter of the rows
 
 __device__ __forceinline__ double block_sum(double v, double *red)
 {
@@ -972,6 +972,34 @@ __device__ __forceinline__ double block_sum(double v, double *red)
     return t;
 }
 
+// a_c -= tau * u (u^T a_c) for the columns c > j, u = (1, v[j+1:]); thread (sub, cc) takes the rows j+1+sub, j+1+sub+4, ...
+// of the columns cc, cc + 256, ...; the four partial dot products of a column meet in LDS.
+__device__ __forceinline__ void qrg_apply(double *B, const double *v, double *part, int j, int n_rows, int n_cols, double t)
+{
+    const int cc = threadIdx.x % QRG_COLS, sub = threadIdx.x / QRG_COLS;
+    for (int c0 = j + 1; c0 < n_cols; c0 += QRG_COLS) {
+        const int c = c0 + cc;
+        const bool on = c < n_cols;
+        double w0 = (on && sub == 0) ? B[(int64_t)j * n_cols + c] : 0.0, w1 = 0.0;
+        if (on) {
+            int i = j + 1 + sub;
+            for (; i + QRG_SUB < n_rows; i += 2 * QRG_SUB) {
+                w0 = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w0);
+                w1 = __builtin_fma(v[i + QRG_SUB], B[(int64_t)(i + QRG_SUB) * n_cols + c], w1);
+            }
+            if (i < n_rows) w0 = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w0);
+        }
+        part[sub * QRG_COLS + cc] = w0 + w1;
+        __syncthreads();
+        const double w = t * ((part[cc] + part[QRG_COLS + cc]) + (part[2 * QRG_COLS + cc] + part[3 * QRG_COLS + cc]));
+        if (on) {
+            if (sub == 0) B[(int64_t)j * n_cols + c] -= w;
+            for (int i = j + 1 + sub; i < n_rows; i += QRG_SUB) B[(int64_t)i * n_cols + c] = __builtin_fma(-w, v[i], B[(int64_t)i * n_cols + c]);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
                                                                         double *__restrict__ a, double *__restrict__ rdiag,
                                                                         double *__restrict__ scratch, double *__restrict__ taus)
@@ -979,7 +1007,8 @@ __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_ro
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *v = (double *)smem;                            // pivot column (n_rows)
     __shared__ double red[QRG_THREADS / WAVE];
-    __shared__ double s_t, s_beta;
+    __shared__ double part[QRG_THREADS];
+    __shared__ double s_t, s_beta, s_scale;
     const int64_t m = blockIdx.x;
     const int tid = threadIdx.x;
     double *B = scratch + (int64_t)m * n_rows * n_cols;
@@ -989,48 +1018,34 @@ __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_ro
     const int k = n_cols < n_rows ? n_cols : n_rows;
     for (int j = 0; j < k; ++j) {
         // ---- dlarfg on column j
-        double part = 0.0;
-        for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) { const double x = B[(int64_t)i * n_cols + j]; part = __builtin_fma(x, x, part); }
-        const double xn2 = block_sum(part, red);
+        double p2 = 0.0;
+        for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) { const double x = B[(int64_t)i * n_cols + j]; p2 = __builtin_fma(x, x, p2); }
+        const double xn2 = block_sum(p2, red);
         if (tid == 0) {
             const double alpha = B[(int64_t)j * n_cols + j];
-            double t = 0.0, beta = alpha;
-            if (xn2 != 0.0) { beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha); t = (beta - alpha) / beta; }
-            s_t = t; s_beta = beta;
-            v[j] = (xn2 != 0.0) ? 1.0 / (alpha - beta) : 0.0;            // the scale, read by everybody below
+            double t = 0.0, beta = alpha, scale = 1.0;
+            if (xn2 != 0.0) { beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
+            s_t = t; s_beta = beta; s_scale = scale;
+            tau[j] = t;
+            rdiag[(int64_t)j * ld + m] = beta;
         }
         __syncthreads();
-        const double t = s_t, beta = s_beta, scale = v[j];
-        __syncthreads();
+        const double t = s_t, scale = s_scale;
         for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) {
-            const double x = B[(int64_t)i * n_cols + j] * (xn2 != 0.0 ? scale : 1.0);
+            const double x = B[(int64_t)i * n_cols + j] * scale;
             B[(int64_t)i * n_cols + j] = x;
             v[i] = x;
         }
-        if (tid == 0) { tau[j] = t; rdiag[(int64_t)j * ld + m] = beta; }
         __syncthreads();
-        // ---- dlarf on the columns right of j
-        for (int c = j + 1 + tid; c < n_cols; c += QRG_THREADS) {
-            double w = B[(int64_t)j * n_cols + c];
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w);
-            w *= t;
-            B[(int64_t)j * n_cols + c] -= w;
-            for (int i = j + 1; i < n_rows; ++i) B[(int64_t)i * n_cols + c] = __builtin_fma(-w, v[i], B[(int64_t)i * n_cols + c]);
-        }
-        if (tid == 0) B[(int64_t)j * n_cols + j] = beta;
+        qrg_apply(B, v, part, j, n_rows, n_cols, t);       // ---- dlarf on the columns right of j
+        if (tid == 0) B[(int64_t)j * n_cols + j] = s_beta;
         __syncthreads();
     }
     for (int j = k - 1; j >= 0; --j) {                     // ---- dorg2r
         const double t = tau[j];
         for (int i = j + 1 + tid; i < n_rows; i += QRG_THREADS) v[i] = B[(int64_t)i * n_cols + j];
         __syncthreads();
-        for (int c = j + 1 + tid; c < n_cols; c += QRG_THREADS) {
-            double w = B[(int64_t)j * n_cols + c];
-            for (int i = j + 1; i < n_rows; ++i) w = __builtin_fma(v[i], B[(int64_t)i * n_cols + c], w);
-            w *= t;
-            B[(int64_t)j * n_cols + c] -= w;
-            for (int i = j + 1; i < n_rows; ++i) B[(int64_t)i * n_cols + c] = __builtin_fma(-w, v[i], B[(int64_t)i * n_cols + c]);
-        }
+        qrg_apply(B, v, part, j, n_rows, n_cols, t);
         for (int i = tid; i < n_rows; i += QRG_THREADS)
             B[(int64_t)i * n_cols + j] = (i > j) ? -t * v[i] : ((i == j) ? 1.0 - t : 0.0);
         __syncthreads();

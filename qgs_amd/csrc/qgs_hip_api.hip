@@ -1284,6 +1284,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         return 0;
     }
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
+    note_kernel(m, "batched_qr_kernel", nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
