@@ -505,3 +505,60 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     assert stepper_name(q38, 38, 4096) == 'qgs_spec_rklds16'
     assert stepper_name(q38, 38, 1) == 'gen_rk_wave_kernel'
     assert stepper_name(d38, 38, 1) == 'gen_rk_wave_kernel'
+
+
+def _random_system(seed, ndim, rank, nnz):
+    """A random polynomial system in the tensor form of the reference: coordinates (i, j, k[, l, m]) with i >= 1, index 0 =
+    the constant slot, duplicates and repeated factors allowed; the Jacobian tensor is built the way the reference does it
+    (jacobian_from_tensor, qgtensor.py:700-722: the tensor plus its copies with axis 1 swapped with every later axis)."""
+    rng = np.random.RandomState(seed)
+    coo = rng.randint(0, ndim + 1, size=(nnz, rank))
+    coo[:, 0] = rng.randint(1, ndim + 1, size=nnz)
+    coo[: nnz // 4, 2:] = 0                                      # a good share of linear / constant terms
+    val = rng.randn(nnz) * 0.2
+    jc, jv = [coo], [val]
+    for ax in range(2, rank):
+        sw = coo.copy()
+        sw[:, [1, ax]] = sw[:, [ax, 1]]
+        jc.append(sw)
+        jv.append(val)
+    return coo.astype(np.int32), val, np.vstack(jc).astype(np.int32), np.concatenate(jv)
+
+
+@pytest.mark.parametrize('seed,ndim,rank,nnz', [(1, 5, 3, 40), (2, 11, 3, 150), (3, 4, 5, 60), (4, 9, 5, 200), (5, 70, 3, 900), (6, 66, 5, 700), (7, 66, 5, 120),
+                                                 (8, 1, 3, 3), (9, 64, 3, 600), (10, 65, 3, 600), (11, 30, 3, 3000), (12, 2, 5, 12), (13, 130, 3, 4000)])
+def test_random_polynomial_systems(seed, ndim, rank, nnz):
+    """The code generators and the generic kernels on tensors that do not come from a qgs model: random coordinates with
+    duplicate entries, squares and higher powers of one variable, rows without terms.  f, Df, RK4 (records, backward), a
+    general tableau and the tangent / adjoint model against the oracle, in every kernel family the size allows
+    (register-resident up to 64 variables, LDS-resident above)."""
+    from qgs_amd import _lib
+    from oracle.oracle import OracleModel
+    coo, val, jcoo, jval = _random_system(seed, ndim, rank, nnz)
+    m = _lib.HipModel(ndim, coo, val, jcoo, jval)
+    ora = OracleModel(ndim, coo, val, jcoo, jval)
+    rng = np.random.RandomState(100 + seed)
+    x = rng.rand(70, ndim) * 0.3
+    t = np.concatenate((np.arange(0., 0.05, 0.01), [0.05]))
+    kutta3 = (np.array([1. / 6, 2. / 3, 1. / 6]), np.array([0., .5, 1.]), np.array([[0., 0, 0], [.5, 0, 0], [-1., 2., 0]]))
+    tg = rng.randn(6, ndim, 3)
+    ref_f, ref_J = ora.f(0., x), ora.Df(0., x[:6])
+    ref_rk = ora.integrate_runge_kutta_jit(t, x, 1, 2, RK4['b'], RK4['c'], RK4['a'])
+    ref_rkb = ora.integrate_runge_kutta_jit(t, x, -1, 0, RK4['b'], RK4['c'], RK4['a'])
+    ref_k3 = ora.integrate_runge_kutta_jit(t, x, 1, 0, *kutta3)
+    ref_tg = ora.integrate_runge_kutta_tgls_jit(t, x[:6], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    ref_ad = ora.integrate_runge_kutta_tgls_jit(t, x[:6], tg, -1, 0, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+    # seed 6: ~600 distinct quartic monomials do not fit the LDS next to 66 variables -> generic kernels only
+    assert m.specialised_available == (seed != 6)
+    for kind in ((0, 1, 2) if m.specialised_available else (0, 1)):
+        m.set_kernel(kind)
+        assert rel_err(m.tendencies(x), ref_f) < 1e-13, kind
+        assert np.abs(m.jacobian(x[:6]) - ref_J).max() < 1e-13 * max(1., np.abs(ref_J).max()), kind
+        assert rel_err(m.rk_integrate(t, x, 1, 2, RK4['b'], RK4['c'], RK4['a']), ref_rk) < 1e-12, kind
+        assert rel_err(m.rk_integrate(t, x, -1, 0, RK4['b'], RK4['c'], RK4['a']), ref_rkb) < 1e-12, kind
+        assert rel_err(m.rk_integrate(t, x, 1, 0, *kutta3), ref_k3) < 1e-12, kind
+        tr, fm = m.rk_tgls_integrate(t, x[:6], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+        assert rel_err(tr, ref_tg[0]) < 1e-12 and rel_err(fm, ref_tg[1]) < 1e-11, kind
+        tr, fm = m.rk_tgls_integrate(t, x[:6], tg, -1, 0, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+        assert rel_err(tr, ref_ad[0]) < 1e-12 and rel_err(fm, ref_ad[1]) < 1e-11, kind
+    m.close()
