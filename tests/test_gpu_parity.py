@@ -308,6 +308,75 @@ def test_full_size_properties(models):
     assert rel_err(alone, ref) < 1e-12
 
 
+def test_full_size_properties_config3(models):
+    """BASELINE config 3 size (65 536 members of the 228-variable model, LDS-resident stepper): members integrated alone
+    give bitwise the batch's answer, forward-then-backward returns to the start, a sample agrees with the oracle."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden('t228'), models('t228')
+    m.set_kernel(2)
+    n = 65536
+    ic = np.random.RandomState(3).rand(n, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 2.0, 0.1), [2.0]))
+    full = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert m.last_kernel_info()['name'] == 'qgs_spec_rklds16'
+    assert np.isfinite(full).all()
+    pick = np.array([0, 15, 16, 63, 64, 1000, 32767, 65535])
+    alone = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert np.array_equal(alone, full[pick])
+    back = m.rk_integrate(t, full, -1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    err = np.abs(back - ic).max()
+    assert err < 5e-5                       # RK4 truncation of the fastest 6x6 modes at dt = 0.1 ...
+    t2 = np.concatenate((np.arange(0., 2.0, 0.05), [2.0]))
+    half = m.rk_integrate(t2, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    err2 = np.abs(m.rk_integrate(t2, half, -1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0] - ic).max()
+    assert err2 < err / 12.                 # ... which falls as dt^4 (16x for dt / 2)
+    ora = OracleModel(g.ndim, g['coo'], g['val'])
+    ref = ora.integrate_runge_kutta_jit(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert rel_err(alone, ref) < 1e-12
+
+
+def test_full_size_properties_config4_config5(models):
+    """BASELINE config 4 size (16 384 members x 36 tangent columns, MAOOAM-36) and one rank's share of config 5
+    (131 072 members): batch independence (bitwise), the propagator applied to a vector equals the tangent run of that
+    vector, <M u, w> = <u, M^T w> with the adjoint run, a sample against the oracle."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden('m36'), models('m36')
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    m.set_kernel(2)
+    n, nd = 16384, g.ndim
+    rng = np.random.RandomState(4)
+    ic = rng.rand(n, nd) * 0.01
+    t = np.concatenate((np.arange(0., 1.0, 0.1), [1.0]))
+    eye = np.ascontiguousarray(np.broadcast_to(np.eye(nd), (n, nd, nd)))
+    tr, fm = m.rk_tgls_integrate(t, ic, eye, 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    tr, fm = tr[:, :, 0], fm[..., 0]
+    assert np.isfinite(fm).all()
+    pick = np.array([0, 63, 64, 5000, 16383])
+    tr1, fm1 = m.rk_tgls_integrate(t, ic[pick], eye[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    assert np.array_equal(tr1[:, :, 0], tr[pick]) and np.array_equal(fm1[..., 0], fm[pick])
+    u, w = rng.randn(len(pick), nd, 1), rng.randn(len(pick), nd, 1)
+    _, mu = m.rk_tgls_integrate(t, ic[pick], u, 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    assert rel_err(mu[..., 0], fm[pick] @ u) < 1e-12
+    # adjoint run: backwards in time along the same trajectory (integrate.py:555-614), started from the end state
+    _, mtw = m.rk_tgls_integrate(t, tr[pick], w, -1, 0, RK4['b'], RK4['c'], RK4['a'], True, -1.)
+    lhs = np.einsum('nik,nik->n', mu[..., 0], w)
+    rhs = np.einsum('nik,nik->n', u, mtw[..., 0])
+    assert np.abs(lhs - rhs).max() < 1e-6 * np.abs(lhs).max()          # exact up to the O(dt^4) mismatch of the two trajectories
+    rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t, ic[pick], eye[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)
+    assert rel_err(tr[pick], rtr[:, :, 0]) < 1e-12 and rel_err(fm[pick], rfm[..., 0]) < 1e-11
+    del fm, eye
+    # config 5, one rank of eight
+    n = 131072
+    ic = rng.rand(n, nd) * 0.01
+    t = np.concatenate((np.arange(0., 2.0, 0.1), [2.0]))
+    full = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    pick = np.array([0, 65535, 65536, 131071])
+    alone = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert np.array_equal(alone, full[pick])
+    ref = ora.integrate_runge_kutta_jit(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
+    assert rel_err(alone, ref) < 1e-12
+
+
 def test_linearity_of_tangent_model(models):
     """TL(a*u + b*v) = a*TL(u) + b*TL(v) along the same trajectory (columns are independent lanes)."""
     g, m = load_golden('m36'), models('m36')
