@@ -29,9 +29,11 @@ std::string hexlit(double v)
 struct KTable {
     std::vector<double> vals;
     size_t cursor = 0;
+    size_t pad_to = 0;      // group-64 mode: the run-ahead loads may touch this many entries
 };
 thread_local KTable *g_ktab = nullptr;
-thread_local bool g_asm_lit = false;      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
+thread_local bool g_asm_lit = false;
+thread_local bool g_kdpp = false;         // coefficient statements as QGS_KFMA(acc, @K..@, factor): lane-broadcast operands (resolve_ktab group 64)      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
 
 std::string lit(double v)
 {
@@ -45,6 +47,13 @@ std::string lit(double v)
     }
     if (!g_ktab) return hexlit(v);
     return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
+}
+
+// acc = fma(c, factor, acc) with a tabulated coefficient c
+std::string coef_fma(const std::string &acc, double c, const std::string &factor)
+{
+    if (g_kdpp && g_ktab) return "QGS_KFMA(" + acc + ", " + lit(c) + ", " + factor + ");";
+    return acc + " = __builtin_fma(" + lit(c) + ", " + factor + ", " + acc + ");";
 }
 
 // Replace the @K<value>@ placeholders of one stage's text by sequential table references.
@@ -108,6 +117,64 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
                 std::string l;
                 for (long b = opened + 1; b <= last_block; ++b) l += load_block((size_t)(b + D));
                 opened = last_block;
+                if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
+            }
+            pos = eol + 1;
+        }
+        return out;
+    }
+    if (group >= 64) {
+        // Lane-broadcast operands (LDS-resident kernels).  The scalar cache cannot keep up with ~2 000 lines of
+        // coefficients per workgroup and stage (a quarter of the run time at ndim 228).  Here 16 consecutive coefficients are
+        // fetched by ONE vector load -- lane l reads entry 16 g + (l & 15), so every row of 16 lanes holds the whole group --
+        // and `v_fmac_f64_dpp ... row_newbcast:n` hands entry n to all lanes as the multiplier of the FMA itself (no extra
+        // instruction; measured at 90 % of the plain FMA rate, tools/ubench/dpp_fmac.hip).  A group costs 2 VGPRs, the loads
+        // run D groups ahead; `ktl` = table + (lane & 15).  Same de-duplication inside the group as below.
+        const int D = std::max(1, group - 64);
+        size_t total = 0;
+        for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
+        const char *ind = "                ";
+        // upper bound of the number of groups (de-duplication only lowers it); a load beyond the table's end reads padding
+        const size_t ngroups_max = (total + 15) / 16;
+        t.pad_to = std::max(t.pad_to, 16 * ngroups_max);
+        auto load_group = [&](size_t g) {
+            if (g >= ngroups_max) return std::string();
+            return std::string(ind) + "const f64 cv" + std::to_string(g) + " = ktl[" + std::to_string(16 * g) + "];\n";
+        };
+        for (int g = 0; g < D; ++g) out += load_group((size_t)g);
+        long opened = -1;
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t eol = text.find('\n', pos);
+            if (eol == std::string::npos) eol = text.size();
+            std::string line = text.substr(pos, eol - pos), res;
+            long first_group = -1;
+            size_t lp = 0;
+            while (true) {
+                size_t a = line.find("@K", lp);
+                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
+                size_t b = line.find('@', a + 2);
+                res.append(line, lp, a - lp);
+                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
+                bool ok = true, reused = false;
+                size_t n = 0;
+                if (dedupe && t.cursor > 0) {
+                    const size_t g0 = (t.cursor - 1) / 16 * 16;
+                    for (size_t q = t.cursor; q-- > g0;)
+                        if (std::fabs(t.vals[q]) == std::fabs(v) && v != 0.0) { n = q; reused = true; break; }
+                }
+                if (!reused) n = next_ref(v, &ok);
+                const bool neg = std::signbit(t.vals[n]) != std::signbit(v);
+                res += "cv" + std::to_string(n / 16) + ", " + std::to_string(n % 16) + (neg ? ", \"-\"" : ", \"\"");
+                (void)ok;
+                if (first_group < 0) first_group = (long)(n / 16);
+                lp = b + 1;
+            }
+            out += res + "\n";
+            if (first_group > opened) {
+                std::string l;
+                for (long g = opened + 1; g <= first_group; ++g) l += load_group((size_t)(g + D));
+                opened = first_group;
                 if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
             }
             pos = eol + 1;
@@ -214,7 +281,7 @@ std::string interleave(const std::vector<std::vector<std::string>> &lists)
 
 void emit_ktable(std::ostringstream &o, const std::string &name, const KTable &t)
 {
-    const size_t padded = std::max<size_t>(8, (t.vals.size() + 7) / 8 * 8);      // whole 8-double blocks
+    const size_t padded = std::max<size_t>(std::max<size_t>(8, t.pad_to), (t.vals.size() + 7) / 8 * 8);      // whole 8-double blocks
     o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << padded << "] = {";
     for (size_t n = 0; n < padded; ++n) o << (n ? ", " : "") << (n < t.vals.size() ? hexlit(t.vals[n]) : std::string("0.0"));
     o << "};\n";
@@ -416,6 +483,9 @@ typedef double f64;
 typedef long long i64;
 typedef const double __attribute__((address_space(4))) kf64;   // coefficient tables: scalar (s_load) fetches
 typedef double v8d __attribute__((ext_vector_type(8)));
+typedef const double __attribute__((address_space(1))) gf64;   // coefficient tables read by vector loads (lane-broadcast operands)
+// acc += (+-)cv[lane n of every row of 16] * f  -- the coefficient is broadcast by the FMA's own DPP operand
+#define QGS_KFMA(acc, cv, n, sg, f) asm("v_fmac_f64_dpp %0, " sg "%1, %2 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"((f64)(f)))
 typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
 #define QGS_WAVE 64
 // fp64 coefficient materialised by two s_mov_b32 right where it is used: the instruction stream (sequentially
@@ -1371,7 +1441,7 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
             for (const PTerm &t : g)
                 ps.push_back({std::signbit(t.c) != ref_neg, "x" + std::to_string(t.j) + sfx, "x" + std::to_string(t.k) + sfx});
             emit_group(so, ind, gname, ps);
-            so << ind << "k" << g[0].row << " = __builtin_fma(" << lit(g[0].c) << ", " << gname << ", k" << g[0].row << ");\n";
+            so << ind << coef_fma("k" + std::to_string(g[0].row), g[0].c, gname) << "\n";
             st.instr += (int64_t)g.size() + 1;
             ++st.coef;
         }
@@ -1394,7 +1464,7 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
                 ++st.instr;
             }
             for (size_t q = a; q < b; ++q) {
-                so << ind << "k" << singles[q].row << " = __builtin_fma(" << lit(singles[q].c) << ", " << factor << ", k" << singles[q].row << ");\n";
+                so << ind << coef_fma("k" + std::to_string(singles[q].row), singles[q].c, factor) << "\n";
                 ++st.instr;
                 ++st.coef;
             }
@@ -1543,15 +1613,18 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
         o << I4 << "}\n";
         const bool table = opt.lds_coeff_table;
+        const bool dpp = table && opt.lds_coeff_dpp && !(opt.lds_debug & 2);
         if (table) {
             g_ktab = &tables[w];
-            o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
+            g_kdpp = dpp;
+            if (dpp) o << I4 << "gf64* ktl = (gf64*)(kf64*)" << kname << "_kt" << w << " + (lane & 15); asm volatile(\"\" : \"+v\"(ktl));\n";
+            else o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
         } else g_asm_lit = true;
         std::ostringstream so;
         std::vector<PTerm> terms;
         for (int i : own) {
             const Row &r = rows[i];
-            if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << lit(r.c0) << ";\n";
+            if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << (dpp ? hexlit(r.c0) : lit(r.c0)) << ";\n";
             else so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
@@ -1562,8 +1635,9 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
-        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
+        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : (dpp ? 64 + opt.lds_dpp_ahead : opt.ktab_group), opt.lds_coeff_dedupe) : so.str());
         g_ktab = nullptr;
+        g_kdpp = false;
         g_asm_lit = false;
         if (tend_kernel) {
             o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"

@@ -48,6 +48,10 @@ struct CodegenOptions {
     bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
+    bool lds_coeff_dpp = false;  // stepper: coefficients fetched 16 per vector load and broadcast by the FMA's DPP operand (v_fmac_f64_dpp
+                                 // row_newbcast) instead of through the scalar cache.  Correct, not faster: 54.3 vs 52.8 ms at ndim
+                                 // 228 (the inline-asm FMAs cost 8 more VGPRs -> more spills, and run at 90 % of the plain rate)
+    int lds_dpp_ahead = 3;       // ... groups of 16 coefficients requested ahead of the one being consumed (2 VGPRs each)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
     int lds_debug = 0;         // timing experiments only (WRONG results): 1 = no barriers in the stage loop, 2 = every coefficient
                                // is table entry 0 (no coefficient stream)

@@ -576,6 +576,8 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) cg.lds_debug = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_LDS_DEDUPE")) cg.lds_coeff_dedupe = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_DPP")) cg.lds_coeff_dpp = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_DPP_AHEAD")) cg.lds_dpp_ahead = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_TGL_DEDUPE")) cg.tgl_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK_V")) cg.tgl_park_v = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_INTERLEAVE")) cg.tgl_interleave = std::max(1, std::atoi(e));
