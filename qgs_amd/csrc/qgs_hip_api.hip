@@ -733,6 +733,22 @@ int check_common(const qgs_model *m, int64_t n_traj, int64_t ld)
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
+// QGS_HIP_PREBUILD_SHARD="i/n": this process compiles only every n-th code object of the pre-build lists (the i-th ones), so
+// that n processes walking the same lists share the work (__graft_entry__.build()).  The ordinal runs over all
+// qgs_prebuild* calls of the process.
+static bool prebuild_mine()
+{
+    static int ordinal = 0, shard = 0, shards = 1, parsed = 0;
+    if (!parsed) {
+        parsed = 1;
+        if (const char *e = std::getenv("QGS_HIP_PREBUILD_SHARD")) {
+            int a = 0, b = 1;
+            if (std::sscanf(e, "%d/%d", &a, &b) == 2 && b >= 1 && a >= 0 && a < b) { shard = a; shards = b; }
+        }
+    }
+    return (ordinal++ % shards) == shard;
+}
+
 extern "C" {
 
 const char *qgs_last_error(void) { return g_err.c_str(); }
@@ -1446,16 +1462,16 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     if (m.lds_spec_possible) {
         std::vector<char> code;
         bool cached;
-        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
-        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::TendLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::TendLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
         for (int S : stages)
             if (S >= 3) {                                   // some 3+-stage scheme requested: also the general-tableau flavour
-                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLdsDense, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+                if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLdsDense, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
                 break;
             }
         if (!m.J.empty() && !m.spec_jac_possible && lds_tgl_bytes(&m) <= (size_t)QGS_LDS_STATE_BYTES)
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
-                if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+                if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
     if (!m.spec_possible || m.prefer_lds) return 0;       // prefer_lds: the register-resident kernels would only spill (and take minutes to compile)
     const bool jac_spec = !m.J.empty() && m.spec_jac_possible;
@@ -1470,7 +1486,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     for (auto &ks : list) {
         std::vector<char> code;
         bool cached;
-        if (compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;
+        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;
     }
     return 0;
 }
@@ -1480,6 +1496,7 @@ int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 64");
     std::vector<char> code;
     bool cached;
+    if (!prebuild_mine()) return 0;
     return compile_source(qgs::generate_qr_kernel(n_rows, n_cols), (arch && *arch) ? arch : target_arch(-1), code, &cached);
 }
 
