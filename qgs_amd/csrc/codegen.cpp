@@ -1679,6 +1679,9 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
     o << "}\n";
     out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
+    // general-tableau flavour: CodeGenPrepare takes 3.3 min on this kernel at ndim 228 and changes nothing in the result
+    // (same registers, same scratch); qgs_hip_api.hip reads the line below and passes the flags to hiprtc
+    if (dense) out << "// qgs-compile-flags: -mllvm -disable-cgp\n";
     if (opt.lds_coeff_table)
         for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();

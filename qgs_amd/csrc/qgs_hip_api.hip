@@ -114,6 +114,21 @@ std::vector<std::string> extra_flags()
     return extra;
 }
 
+// Flags a generated source asks for itself: a line "// qgs-compile-flags: <flags>" (codegen.cpp; the general-tableau
+// LDS-resident stepper spends 3.3 of its 3.5 min of compilation in CodeGenPrepare at ndim 228 and produces the same code
+// without that pass).
+std::vector<std::string> flags_for(const std::string &src)
+{
+    std::vector<std::string> extra = extra_flags();
+    const char *tag = "// qgs-compile-flags:";
+    const size_t p = src.find(tag);
+    if (p != std::string::npos) {
+        std::istringstream is(src.substr(p + std::strlen(tag), src.find('\n', p) - p - std::strlen(tag)));
+        for (std::string tok; is >> tok;) extra.push_back(tok);
+    }
+    return extra;
+}
+
 std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra)
 {
     std::string opts_key = arch + "|O3|c++17|v1";
@@ -125,13 +140,13 @@ std::string cache_path(const std::string &src, const std::string &arch, const st
 
 bool source_is_cached(const std::string &src, const std::string &arch)
 {
-    std::ifstream f(cache_path(src, arch, extra_flags()), std::ios::binary);
+    std::ifstream f(cache_path(src, arch, flags_for(src)), std::ios::binary);
     return (bool)f;
 }
 
 int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
 {
-    const std::vector<std::string> extra = extra_flags();
+    const std::vector<std::string> extra = flags_for(src);
     const std::string path = cache_path(src, arch, extra);
     {
         std::ifstream f(path, std::ios::binary);
@@ -141,6 +156,10 @@ int compile_source(const std::string &src, const std::string &arch, std::vector<
         }
     }
     if (from_cache) *from_cache = false;
+    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // developer knob: keep the generated source next to nothing else
+        std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
+        f << src;
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "qgs_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail("hiprtcCreateProgram failed");
