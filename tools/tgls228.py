@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import model_configs
 from qgs_amd.functions.tendencies import create_tendencies
 p = model_configs.params_t228(); f, Df = create_tendencies(p); m = f.hip_model(); ndim = 228
+m.set_kernel(int(os.environ.get('TGLS228_KIND', '0')))        # 2: force the specialised kernels (JIT if not cached)
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 t = np.concatenate((np.arange(0., 0.1, 0.01), [0.1]))
 dev = torch.device('cuda', 0); st = torch.cuda.current_stream().cuda_stream
