@@ -70,6 +70,30 @@ def test_prebuild_generates_code_objects(tmp_path, monkeypatch):
     assert all(os.path.getsize(os.path.join(tmp_path, f)) > 1000 for f in objs)
 
 
+def test_prebuild_shards_cover_every_code_object(tmp_path):
+    """build() pre-builds in parallel: with QGS_HIP_PREBUILD_SHARD=i/n a process compiles every n-th code object of the
+    list; the shards are disjoint and together produce all of them."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "from qgs_amd import _lib\n"
+            "coo = np.array([[1, 0, 1], [1, 1, 2], [2, 0, 0], [2, 1, 1]], dtype=np.int32)\n"
+            "val = np.array([-0.5, 2.0, 0.25, -1.0])\n"
+            "jcoo = np.array([[1, 1, 0], [1, 1, 2], [1, 2, 1], [2, 1, 1]], dtype=np.int32)\n"
+            "jval = np.array([-0.5, 2.0, 2.0, -2.0])\n"
+            "_lib.prebuild(2, coo, val, jcoo, jval, stage_counts=(2,))\n" % REPO)
+    seen = []
+    for i in range(2):
+        d = tmp_path / ('shard%d' % i)
+        d.mkdir()
+        env = dict(os.environ, QGS_HIP_CACHE_DIR=str(d), QGS_HIP_PREBUILD_SHARD='%d/2' % i, QGS_HIP_NO_TORCH_PRELOAD='1')
+        subprocess.check_call([sys.executable, '-c', code], env=env)
+        seen.append(sorted(f for f in os.listdir(d) if f.endswith('.hsaco')))
+    assert len(seen[0]) == 3 and len(seen[1]) == 3
+    assert not set(seen[0]) & set(seen[1])
+
+
 def test_package_never_imports_the_oracle():
     """oracle/ is test infrastructure: nothing under qgs_amd/ may import, load or reference it."""
     bad = []
