@@ -2,27 +2,37 @@
 """bench.py -- headline benchmark: ensemble trajectory-steps/s, fp64, MAOOAM-36 (BASELINE.json config 2).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
+
+works as typed for any N: with N > 1 and no launcher environment the process (which never touches a GPU)
+starts N child ranks (one per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) and relays rank 0's JSON line.
+It also runs as a rank under
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-One bench "step" = one pass of the hot path over one batch: every rank takes its own batch of
-`--members` (default 65 536) synthetic initial conditions that are already resident in HBM in the
-reference's (n_traj, ndim) layout, packs them mode-major, integrates `--rk-steps` (default 1000) classic
-RK4 steps of MAOOAM 2x2/2x4 (36 variables, the qgs_maooam.py parameter set) with write_steps=0 in ONE
-fused HIP kernel, unpacks the final states to (n_traj, ndim) and (N>1) gathers them onto rank 0 with RCCL (asynchronously,
-overlapping the next pass).
+One bench "step" = one pass of the hot path over one batch: every rank takes its own batch of `--members`
+(default 65 536) synthetic initial conditions that are already resident in HBM in the reference's (n_traj, ndim)
+layout, packs them mode-major, integrates `--rk-steps` (default 1000) classic RK4 steps of MAOOAM 2x2/2x4
+(36 variables, the qgs_maooam.py parameter set) with write_steps=0 in ONE fused HIP kernel, unpacks the final
+states to (n_traj, ndim) and (N>1) gathers them onto rank 0 with RCCL (asynchronously, overlapping the next pass).
 Members are independent, so ranks shard them with no data-path collective except that final gather
 ("scaling": "weak": per-GPU work is fixed).
 
 value = (members * rk_steps * N * K) / (max over ranks of the timed region)   [trajectory-steps / s]
 
-Extra objects on the JSON line: `roofline` (algorithmic HBM bytes of the stepper kernel / its measured
-duration, against 8 TB/s) and `cpu_baseline` (the C oracle = scalar restatement of the reference's
-numba loops, OpenMP over members, timed on this host on a bounded sample; rank 0, N=1 only).
+Extra objects on the JSON line (rank 0):
+  roofline      the stepper kernel against the bound that binds it, the FP64 vector rate (the state stays in
+                registers for the whole launch, so HBM sees 0.1 % of the algorithmic bytes); the SURVEY 8(d) byte
+                figure and the counter traffic are kept next to it
+  configs       (N = 1) the other single-GPU BASELINE configurations, timed in this same run with HIP events:
+                config 2 with write_steps=1, config 2 through the host-pointer API (H2D + D2H included),
+                config 3 (MAOOAM 6x6, ndim 228), config 4 (tangent model, 100 calls; batched QR separately)
+  cpu_baseline  (N = 1) the C restatement of the reference's numba loops (oracle/qgs_oracle.c) built here with
+                -O3 -march=native (FMA allowed), timed on 1 thread and on all physical cores
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -45,61 +55,265 @@ def rk4_tableau():
     return b, c, a
 
 
+def grid(steps, dt):
+    return np.concatenate((np.arange(0., steps * dt, dt), np.full((1,), steps * dt)))[:steps + 1]
+
+
 def load_model_tensors():
     """MAOOAM-36 tensors of the qgs_maooam.py parameter set (BASELINE config 2)."""
-    try:
-        from qgs_amd.params.params import QgParams
-        from qgs_amd.functions.tendencies import create_tendencies
-        p = QgParams()
-        p.set_atmospheric_channel_fourier_modes(2, 2)
-        p.set_oceanic_basin_fourier_modes(2, 4)
-        p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'n': 1.5, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
-        p.atemperature_params.set_params({'eps': 0.7, 'T0': 289.3, 'hlambda': 15.06, })
-        p.gotemperature_params.set_params({'gamma': 5.6e8, 'T0': 301.46})
-        p.atemperature_params.set_insolation(103.3333, 0)
-        p.gotemperature_params.set_insolation(310., 0)
-        f, Df = create_tendencies(p)
-        return p.ndim, f.coo, f.val, Df.coo, Df.val, 'qgs_amd.create_tendencies(QgParams: qgs_maooam.py set)'
-    except ImportError:
-        g = np.load(os.path.join(HERE, 'tests', 'golden', 'm36.npz'))
-        return int(g['ndim']), g['coo'], g['val'], g['jcoo'], g['jval'], 'tests/golden/m36.npz'
+    from qgs_amd.params.params import QgParams
+    from qgs_amd.functions.tendencies import create_tendencies
+    p = QgParams()
+    p.set_atmospheric_channel_fourier_modes(2, 2)
+    p.set_oceanic_basin_fourier_modes(2, 4)
+    p.set_params({'kd': 0.0290, 'kdp': 0.0290, 'n': 1.5, 'r': 1.e-7, 'h': 136.5, 'd': 1.1e-7})
+    p.atemperature_params.set_params({'eps': 0.7, 'T0': 289.3, 'hlambda': 15.06, })
+    p.gotemperature_params.set_params({'gamma': 5.6e8, 'T0': 301.46})
+    p.atemperature_params.set_insolation(103.3333, 0)
+    p.gotemperature_params.set_insolation(310., 0)
+    f, Df = create_tendencies(p)
+    return p.ndim, f.coo, f.val, Df.coo, Df.val, 'qgs_amd.create_tendencies(QgParams: qgs_maooam.py set)'
 
 
-def cpu_baseline(ndim, coo, val, rk_steps, dt, target_seconds=12.0):
-    """Time the CPU oracle (oracle/qgs_oracle.c) on a bounded sample of the same workload."""
-    from oracle.oracle import OracleModel, max_threads
-    m = OracleModel(ndim, coo, val)
-    b, c, a = rk4_tableau()
-    threads = max_threads()
-    time_grid = np.concatenate((np.arange(0., rk_steps * dt, dt), np.full((1,), rk_steps * dt)))
-    rng = np.random.RandomState(21217)
-    n_cal = max(threads * 4, 64)
-    ic = rng.rand(n_cal, ndim) * 0.01
-    m.integrate_runge_kutta_jit(time_grid[:11], ic, 1, 0, b, c, a, threads=threads)          # warm up the pool
-    t0 = time.perf_counter()
-    m.integrate_runge_kutta_jit(time_grid[:101], ic, 1, 0, b, c, a, threads=threads)
-    rate = n_cal * 100 / (time.perf_counter() - t0)
-    n_traj = int(max(threads, min(65536, rate * target_seconds / rk_steps)))
-    n_traj = max(threads, (n_traj // threads) * threads)
-    ic = rng.rand(n_traj, ndim) * 0.01
-    t0 = time.perf_counter()
-    out = m.integrate_runge_kutta_jit(time_grid, ic, 1, 0, b, c, a, threads=threads)
-    el = time.perf_counter() - t0
-    model = ''
+# ---------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` typed directly
+# ---------------------------------------------------------------------------------------------------------------
+def visible_gpus():
+    """Number of GPUs this process could use, WITHOUT initialising the HIP runtime (the parent must stay GPU-free:
+    it only starts child processes)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(n, argv):
+    import socket
+    m = visible_gpus()
+    if m < n:
+        print('bench.py: %d GPUs requested, %d visible' % (n, m), file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c]
+    if bad:
+        print('bench.py: ranks failed (rank, exit code): %r' % bad, file=sys.stderr)
+        return 1
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_info():
+    model, cores = '', set()
     try:
+        phys = core = None
         with open('/proc/cpuinfo') as f:
             for line in f:
-                if line.startswith('model name'):
+                if line.startswith('model name') and not model:
                     model = line.split(':', 1)[1].strip()
-                    break
+                elif line.startswith('physical id'):
+                    phys = line.split(':', 1)[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':', 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
     except OSError:
         pass
-    return {'value': n_traj * rk_steps / el, 'unit': 'traj-steps/s', 'cores': threads, 'kind': 'port',
-            'sample': '%d members x %d RK4 steps of the same MAOOAM-36 workload, %.1f s wall, OpenMP over members'
-                      % (n_traj, rk_steps, el),
-            'cpu': model, 'per_core': n_traj * rk_steps / el / threads}, ic, out[:, :, 0]
+    logical = os.cpu_count() or 1
+    try:
+        logical = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    physical = min(len(cores), logical) if cores else logical
+    return model, max(1, physical), logical
 
 
+def cpu_baseline(ndim, coo, val, rk_steps, dt, seconds_1=5.0, seconds_all=12.0):
+    """Time the C restatement of the reference's loops on this host: same COO loop order, built HERE with
+    -O3 -march=native (FMA allowed) -- a performance build next to the -O2 -ffp-contract=off parity build."""
+    try:
+        import numba  # noqa: F401
+        have_numba = True
+    except Exception:
+        have_numba = False
+    model_name, physical, logical = cpu_info()
+    os.environ.setdefault('OMP_PLACES', 'cores')          # one thread per physical core for the all-cores figure
+    os.environ.setdefault('OMP_PROC_BIND', 'spread')
+    from oracle.oracle import OracleModel
+    flavour = 'fast'
+    try:
+        m = OracleModel(ndim, coo, val, flavour='fast')
+    except Exception as e:                                # no compiler on this host: fall back to the parity build
+        print('bench.py: -O3 oracle build failed (%s); timing the parity build' % e, file=sys.stderr)
+        m = OracleModel(ndim, coo, val)
+        flavour = 'parity'
+    parity = OracleModel(ndim, coo, val)
+    b, c, a = rk4_tableau()
+    tg = grid(rk_steps, dt)
+    rng = np.random.RandomState(21217)
+
+    def timed(n_traj, threads):
+        ic = rng.rand(n_traj, ndim) * 0.01
+        t0 = time.perf_counter()
+        out = m.integrate_runge_kutta_jit(tg, ic, 1, 0, b, c, a, threads=threads)
+        return time.perf_counter() - t0, ic, out
+
+    m.integrate_runge_kutta_jit(tg[:11], rng.rand(physical * 2, ndim) * 0.01, 1, 0, b, c, a, threads=physical)   # pool warm-up
+    el, _, _ = timed(8, 1)
+    rate1 = 8 * rk_steps / el
+    n1 = int(max(8, min(4096, rate1 * seconds_1 / rk_steps)))
+    el1, _, _ = timed(n1, 1)
+    rate1 = n1 * rk_steps / el1
+    n_all = int(max(physical, min(65536, rate1 * physical * seconds_all / rk_steps)))
+    n_all = max(physical, n_all // physical * physical)
+    el_all, ic, out = timed(n_all, physical)
+    rate_all = n_all * rk_steps / el_all
+    # the performance build must still be the same algorithm: check it against the parity build
+    ns = min(16, n_all)
+    ref = parity.integrate_runge_kutta_jit(tg, ic[:ns], 1, 0, b, c, a, threads=min(ns, physical))
+    dev = float(np.abs(out[:ns] - ref).max() / np.abs(ref).max())
+    return {'value': rate_all, 'unit': 'traj-steps/s', 'cores': physical, 'kind': 'port',
+            'sample': '%d members x %d RK4 steps of the same MAOOAM-36 workload on %d threads (one per physical core), %.1f s wall; '
+                      '1 thread: %d members, %.1f s' % (n_all, rk_steps, physical, el_all, n1, el1),
+            'cpu': model_name, 'logical_cpus': logical, 'one_thread': rate1, 'per_core': rate_all / physical,
+            'build': 'oracle/qgs_oracle.c, gcc -O3 -march=native -fopenmp (FMA contraction allowed)' if flavour == 'fast'
+                     else 'oracle/qgs_oracle.c, gcc -O2 -ffp-contract=off (parity build)',
+            'fast_vs_parity_build_rel_diff': dev, 'numba_importable': have_numba,
+            'published_numba_single_core': 1.5e5}, ic[:ns], ref[:, :, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other single-GPU BASELINE configurations (rank 0, N = 1)
+# ---------------------------------------------------------------------------------------------------------------
+def event_ms(torch, fn, n, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts)), ts
+
+
+def extra_configs(torch, dev, model, ndim, nnz, jnnz):
+    from qgs_amd import _lib
+    out = {}
+    b, c, a = rk4_tableau()
+    st = torch.cuda.current_stream().cuda_stream
+    flops36 = 12 * nnz + 14 * ndim
+
+    # -- config 2 with the reference's default write_steps = 1 (integrate.py:210-212): 100 steps, full record ----
+    n, steps = 65536, 100
+    t = grid(steps, 0.1)
+    ic = torch.from_numpy(np.random.RandomState(1).rand(ndim, n) * 0.01).to(dev)
+    rec = torch.empty((steps + 1, ndim, n), dtype=torch.float64, device=dev)
+    ms, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 1, b, c, a, rec.data_ptr(), st), 5)
+    rec_bytes = float(rec.numel() * 8)
+    ms0, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 5)
+    out['config2_write_steps_1'] = {
+        'workload': 'MAOOAM-36, 65 536 members, 100 RK4 steps, write_steps=1: 101 records = %.2f GB (device layout)' % (rec_bytes / 1e9),
+        'kernel': model.last_kernel_info()['name'], 'ms': ms, 'ms_same_run_without_records': ms0,
+        'traj_steps_per_s': n * steps / (ms * 1e-3),
+        'roofline': {'bound': 'hbm', 'achieved': rec_bytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'note': 'record bytes actually written / kernel time; the kernel also does the fp64 work of the steps',
+                     'fp64_valu_frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+    del rec
+
+    # -- config 2 end to end through the host-pointer API: H2D + pack + kernel + unpack + D2H ----------------------
+    n, steps = 65536, 1000
+    t = grid(steps, 0.1)
+    ic_h = np.random.RandomState(21217).rand(n, ndim) * 0.01
+    model.rk_integrate(t, ic_h, 1, 0, b, c, a)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        model.rk_integrate(t, ic_h, 1, 0, b, c, a)
+        ts.append(time.perf_counter() - t0)
+    el = float(np.median(ts))
+    out['config2_end_to_end_host_api'] = {
+        'workload': 'MAOOAM-36, 65 536 members, 1000 RK4 steps, write_steps=0 through qgs_rk_integrate (NumPy in, NumPy out: '
+                    'H2D + D2H over PCIe included)',
+        'kernel': model.last_kernel_info()['name'], 'ms': el * 1e3, 'traj_steps_per_s': n * steps / el,
+        'roofline': {'bound': 'fp64_valu', 'achieved': flops36 * n * steps / el / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': flops36 * n * steps / el / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+
+    # -- config 4: tangent model, 16 384 members x 36 columns, 10 sub-steps per call, 100 calls; QR separately -------
+    n, steps, n_tg, calls = 16384, 10, ndim, 100
+    t = grid(steps, 0.01)
+    ic = torch.from_numpy(np.random.RandomState(2).rand(ndim, n) * 0.01).to(dev)
+    tg = torch.zeros((ndim, n_tg, n), dtype=torch.float64, device=dev)
+    for d in range(ndim):
+        tg[d, d, :] = 1.0
+    rec = torch.empty((1, ndim, n), dtype=torch.float64, device=dev)
+    recm = torch.empty((1, ndim, n_tg, n), dtype=torch.float64, device=dev)
+    rdiag = torch.empty((n_tg, n), dtype=torch.float64, device=dev)
+
+    def tgls_calls():
+        for _ in range(calls):
+            model.rk_tgls_integrate_device(n, n, n_tg, ic.data_ptr(), tg.data_ptr(), t, 1, 0, b, c, a, False, 1.,
+                                           rec.data_ptr(), recm.data_ptr(), st)
+    ms, _ = event_ms(torch, tgls_calls, 3)
+    ms_call = ms / calls
+    kname = model.last_kernel_info()
+    ms_qr, _ = event_ms(torch, lambda: model.batched_qr_device(n, n, ndim, n_tg, recm.data_ptr(), rdiag.data_ptr(), st), 5)
+    flops_tgls = 4 * (2 * jnnz) + 4 * 2 * ndim ** 3 + 7 * 2 * ndim * ndim + flops36     # SURVEY 8(a) row a8: 4.02e5 at ndim 36
+    rate = n * steps / (ms_call * 1e-3)
+    out['config4_tgls'] = {
+        'workload': 'MAOOAM-36 tangent model, 16 384 members x 36 tangent vectors (identity), 10 sub-steps per call, '
+                    '%d calls timed together (trajectory pass + tangent pass per call)' % calls,
+        'kernel': kname['name'], 'kernel_info': kname, 'ms_per_call': ms_call, 'traj_steps_per_s': rate,
+        'qr_kernel': model.last_kernel_info()['name'], 'qr_ms': ms_qr,
+        'roofline': {'bound': 'fp64_valu', 'achieved': rate * flops_tgls / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': rate * flops_tgls / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     'flops_per_traj_step': flops_tgls,
+                     'note': 'dense-matrix flop count of SURVEY 8(a) a8 (the kernel evaluates the sparse J w directly and '
+                             'executes fewer)',
+                     'hbm_algorithmic_frac': rate * 2 * 8 * (ndim + ndim * n_tg) / 1e9 / HBM_PEAK_GBS}}
+    del tg, recm, rdiag
+
+    # -- config 3: MAOOAM 6x6 (ndim 228), 65 536 members x 100 steps ----------------------------------------------------
+    g = np.load(os.path.join(HERE, 'tests', 'golden', 't228.npz'))
+    nd3 = int(g['ndim'])
+    m3 = _lib.HipModel(nd3, g['coo'], g['val'], g['jcoo'], g['jval'], device=dev.index or 0)
+    n, steps = 65536, 100
+    t = grid(steps, 0.1)
+    ic = torch.from_numpy(np.random.RandomState(3).rand(nd3, n) * 0.01).to(dev)
+    rec = torch.empty((1, nd3, n), dtype=torch.float64, device=dev)
+    ms, _ = event_ms(torch, lambda: m3.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 3)
+    flops228 = 12 * len(g['val']) + 14 * nd3
+    rate = n * steps / (ms * 1e-3)
+    out['config3_maooam228'] = {
+        'workload': 'MAOOAM 6x6 atm / 6x6 ocean (ndim 228, %d tensor entries; tests/golden/t228.npz), 65 536 members, 100 RK4 steps, '
+                    'write_steps=0' % len(g['val']),
+        'kernel': m3.last_kernel_info()['name'], 'kernel_info': m3.last_kernel_info(), 'ms': ms, 'traj_steps_per_s': rate,
+        'mode_updates_per_s': rate * nd3,
+        'roofline': {'bound': 'fp64_valu', 'achieved': rate * flops228 / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': rate * flops228 / 1e12 / FP64_VALU_PEAK_TFLOPS, 'flops_per_traj_step': flops228,
+                     'hbm_algorithmic_frac': rate * 2 * 8 * nd3 / 1e9 / HBM_PEAK_GBS}}
+    m3.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -109,8 +323,16 @@ def main():
     ap.add_argument('--rk-steps', type=int, default=1000, help='RK4 steps per pass')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'spec'], default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the configs 3 / 4 / write_steps=1 / host-API entries')
     ap.add_argument('--force-dist', action='store_true', help='initialise the RCCL process group even at world size 1 (plumbing check)')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+
+    under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if not under_launcher and args.gpus > 1:
+        # typed directly: this process stays off the GPU and starts one fresh child per rank
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -120,13 +342,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
         if rank == 0:
-            print('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world),
-                  file=sys.stderr)
-        if world == 1 and args.gpus > 1:
-            sys.exit(2)
-    if not torch.cuda.is_available():
+            print('bench.py: --gpus %d but the launcher started %d ranks' % (args.gpus, world), file=sys.stderr)
+        sys.exit(4)
+    n_vis = torch.cuda.device_count()
+    if n_vis < 1 or not torch.cuda.is_available():
         print('bench.py: no GPU visible; the HIP path has no CPU fallback', file=sys.stderr)
         sys.exit(1)
+    if local_rank >= n_vis:
+        print('bench.py: %d GPUs requested, %d visible' % (world, n_vis), file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist
@@ -144,7 +368,7 @@ def main():
     n_traj, rk_steps, dt = args.members, args.rk_steps, 0.1
     ld = (n_traj + 63) // 64 * 64
     b, c, a = rk4_tableau()
-    time_grid = np.concatenate((np.arange(0., rk_steps * dt, dt), np.full((1,), rk_steps * dt)))
+    time_grid = grid(rk_steps, dt)
 
     # synthetic initial conditions (the distribution qgs_maooam.py:108 uses), different per rank
     rng = np.random.RandomState(21217 + rank)
@@ -157,12 +381,11 @@ def main():
     ens = ShardedEnsemble(world * n_traj)                              # contiguous member blocks, one per rank
     assert ens.n_local == n_traj
     root = RootGather(ens, dst=0)
-    d_all = torch.empty((world * n_traj, ndim), dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
+    d_all = torch.empty((world * n_traj, ndim), dtype=torch.float64, device=dev) if (use_dist and rank == 0) else None
     pending = [None, None]                                             # in-flight gathers of d_out[0], d_out[1]
     stream = torch.cuda.current_stream().cuda_stream
 
     kern_events = []
-    gather_events = []
 
     def one_pass(record_events, k=0):
         d_out_rows = d_out[k % 2]
@@ -181,16 +404,7 @@ def main():
         if use_dist:
             # RCCL gather of the final states onto rank 0 over xGMI: the only collective.  It is asynchronous
             # (RCCL's own stream), so it overlaps the next pass; the timed region ends after the last one completed.
-            if record_events:
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-            if world > 1:
-                pending[k % 2], _ = root.start(d_out_rows, out=d_all, async_op=True)
-            else:
-                dist.all_gather_into_tensor(torch.empty_like(d_out_rows), d_out_rows)
-            if record_events:
-                g1.record()
-                gather_events.append((g0, g1))
+            pending[k % 2], _ = root.start(d_out_rows, out=d_all, async_op=True)
 
     def drain():
         for i in (0, 1):
@@ -221,17 +435,33 @@ def main():
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in kern_events])) if kern_events else float('nan')
     kinfo = model.last_kernel_info()
-    gather_ms = float(np.mean([g0.elapsed_time(g1) for g0, g1 in gather_events])) if gather_events else None
 
-    # correctness guard inside the bench (rank 0): a handful of members against the CPU oracle
+    # duration of ONE gather, outside the timed region: events around its start and its completion on the compute stream
+    gather_ms = None
+    if use_dist:
+        gts = []
+        for _ in range(5):
+            barrier()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            work, _ = root.start(d_out[0], out=d_all, async_op=True)
+            if work is not None:
+                work.wait()                                            # the compute stream now waits for RCCL's stream
+            g1.record()
+            g1.synchronize()
+            gts.append(g0.elapsed_time(g1))
+        gather_ms = float(np.median(gts))
+
     result = None
     if rank == 0:
         total_traj_steps = float(n_traj) * rk_steps * world * args.steps
         value = total_traj_steps / elapsed
-        bytes_per_traj_step = 2 * 8 * ndim                                 # state read once + written once per step
-        flops_per_traj_step = 12 * len(val) + 14 * ndim
+        bytes_per_traj_step = 2 * 8 * ndim                                 # state read once + written once per step (SURVEY 8d)
+        flops_per_traj_step = 12 * len(val) + 14 * ndim                    # 4 716 at MAOOAM-36
         alg_bytes = float(bytes_per_traj_step) * n_traj * rk_steps
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        alg_flops = float(flops_per_traj_step) * n_traj * rk_steps
+        tflops = alg_flops / (kern_ms * 1e-3) / 1e12
+        alg_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(HERE, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
@@ -248,28 +478,41 @@ def main():
             'config': {'workload': 'MAOOAM 2x2 atm / 2x4 ocean (36 modes) fp64, %d-member ensemble per GPU, %d RK4 steps '
                                    'per pass, write_steps=0 (BASELINE configs[1])' % (n_traj, rk_steps),
                        'members_per_gpu': n_traj, 'rk_steps_per_pass': rk_steps, 'ndim': ndim, 'tensor_nnz': int(len(val)),
-                       'dt': dt, 'tensor_source': tensor_src, 'parallelism': 'members sharded x%d, RCCL gather of final states onto rank 0 (async, overlapped)' % world,
+                       'dt': dt, 'tensor_source': tensor_src,
+                       'parallelism': 'members sharded x%d, RCCL gather of final states onto rank 0 (async, overlapped)' % world,
                        'kernel': kinfo},
             'mode_updates_per_s': value * ndim,
-            'gather_ms_per_step': gather_ms,        # host-side enqueue-to-enqueue time of the async RCCL gather (rank 0), None at N=1
-            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'gather_ms': gather_ms,        # one RCCL gather of the final states onto rank 0, start to completion (None without a process group)
+            'roofline': {'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': tflops / FP64_VALU_PEAK_TFLOPS,
                          'kernel': kinfo['name'], 'kernel_ms': kern_ms,
-                         'algorithmic_bytes_per_launch': alg_bytes,
-                         'fp64_tflops_algorithmic': flops_per_traj_step * n_traj * rk_steps / (kern_ms * 1e-3) / 1e12,
-                         'fp64_valu_peak_tflops': FP64_VALU_PEAK_TFLOPS},
+                         'algorithmic_flops_per_launch': alg_flops, 'flops_per_traj_step': flops_per_traj_step,
+                         'traffic': traffic,                                  # HBM bytes per launch from the PMC counters (profiles/)
+                         'hbm_algorithmic_bytes_per_launch': alg_bytes,
+                         'hbm_algorithmic_frac': alg_gbs / HBM_PEAK_GBS,     # SURVEY 8(d) byte figure / kernel time / 8 TB/s
+                         'traffic_over_algorithmic': (traffic / alg_bytes) if traffic else None,
+                         'note': 'the state stays in VGPRs for all steps of a launch, so HBM moves the initial and final states '
+                                 'only; the kernel is bound by fp64 VALU issue'},
         }
+        if not result['roofline']['frac'] <= 1.0:
+            print('bench.py: roofline fraction above 1 (%.3f): check the clock / flop count' % result['roofline']['frac'], file=sys.stderr)
+        if world == 1 and not args.no_extra_configs:
+            try:
+                result['configs'] = extra_configs(torch, dev, model, ndim, len(val), len(jval))
+            except Exception as e:                                           # never lose the headline line to a side measurement
+                result['configs'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             base, ic_s, ref_final = cpu_baseline(ndim, coo, val, rk_steps, dt)
             result['cpu_baseline'] = base
-            ns = min(64, ic_s.shape[0])
-            got = model.rk_integrate(time_grid, ic_s[:ns], 1, 0, b, c, a)[:, :, 0]
-            err = float(np.abs(got - ref_final[:ns]).max() / np.abs(ref_final[:ns]).max())
+            ns = ic_s.shape[0]
+            got = model.rk_integrate(time_grid, ic_s, 1, 0, b, c, a)[:, :, 0]
+            err = float(np.abs(got - ref_final).max() / np.abs(ref_final).max())
             result['parity_check'] = {'members': ns, 'rk_steps': rk_steps, 'max_rel_err_vs_oracle': err, 'tolerance': 1e-10}
             if not err < 1e-10:
                 print('bench.py: PARITY FAILURE vs oracle: %g' % err, file=sys.stderr)
                 result['value'] = 0.0
         print(json.dumps(result))
+        sys.stdout.flush()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_FAST = None
 
 _i64 = ctypes.c_int64
 _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags='C_CONTIGUOUS')
@@ -27,28 +28,46 @@ def build(force=False):
     return so
 
 
-def lib():
-    global _LIB
+def build_fast():
+    """Performance flavour of the same source for bench.py's `cpu_baseline` leg: -O3 -march=native, FMA contraction
+    allowed.  Built on the host that runs it (the flags are host-specific), into a scratch directory."""
+    import tempfile
+    out = os.path.join(tempfile.mkdtemp(prefix='qgs_oracle_fast_'), 'libqgs_oracle_fast.so')
+    subprocess.check_call([os.environ.get('CC', 'gcc'), '-O3', '-march=native', '-ffp-contract=fast', '-fopenmp', '-fPIC',
+                           '-std=c11', '-shared', '-o', out, os.path.join(_HERE, 'qgs_oracle.c')])
+    return out
+
+
+def _bind(L):
+    L.oracle_sparse_mul3.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p]
+    L.oracle_sparse_mul2.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p]
+    L.oracle_sparse_mul5.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p, _f64p]
+    L.oracle_sparse_mul4.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p]
+    L.oracle_tendencies_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
+    L.oracle_jacobian_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
+    L.oracle_n_records.argtypes = [_f64p, _i64, _i64]
+    L.oracle_n_records.restype = _i64
+    L.oracle_rk_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p, _i64, ctypes.c_int, _i64,
+                                        ctypes.c_int, _f64p, _f64p, _f64p, _i64, _f64p, ctypes.c_int]
+    L.oracle_rk_tgls_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _i32p, _f64p, _i64, _i64, _f64p, _f64p,
+                                           _f64p, _i64, ctypes.c_int, _i64, ctypes.c_int, _f64p, _f64p, _f64p,
+                                           ctypes.c_int, ctypes.c_double, _i64, _f64p, _f64p, ctypes.c_int]
+    L.oracle_max_threads.restype = ctypes.c_int
+    for fn in (L.oracle_sparse_mul3, L.oracle_sparse_mul2, L.oracle_sparse_mul5, L.oracle_sparse_mul4,
+               L.oracle_tendencies_r, L.oracle_jacobian_r, L.oracle_rk_integrate_r, L.oracle_rk_tgls_integrate_r):
+        fn.restype = None
+    return L
+
+
+def lib(flavour='parity'):
+    """'parity': oracle/libqgs_oracle.so (-O2 -ffp-contract=off, the checker).  'fast': see build_fast()."""
+    global _LIB, _FAST
+    if flavour == 'fast':
+        if _FAST is None:
+            _FAST = _bind(ctypes.CDLL(build_fast()))
+        return _FAST
     if _LIB is None:
-        L = ctypes.CDLL(build())
-        L.oracle_sparse_mul3.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p]
-        L.oracle_sparse_mul2.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p]
-        L.oracle_sparse_mul5.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p, _f64p]
-        L.oracle_sparse_mul4.argtypes = [_i64, _i32p, _f64p, _i64, _f64p, _f64p, _f64p, _f64p]
-        L.oracle_tendencies_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
-        L.oracle_jacobian_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p]
-        L.oracle_n_records.argtypes = [_f64p, _i64, _i64]
-        L.oracle_n_records.restype = _i64
-        L.oracle_rk_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _f64p, _f64p, _i64, ctypes.c_int, _i64,
-                                            ctypes.c_int, _f64p, _f64p, _f64p, _i64, _f64p, ctypes.c_int]
-        L.oracle_rk_tgls_integrate_r.argtypes = [ctypes.c_int, _i64, _i64, _i32p, _f64p, _i64, _i32p, _f64p, _i64, _i64, _f64p, _f64p,
-                                               _f64p, _i64, ctypes.c_int, _i64, ctypes.c_int, _f64p, _f64p, _f64p,
-                                               ctypes.c_int, ctypes.c_double, _i64, _f64p, _f64p, ctypes.c_int]
-        L.oracle_max_threads.restype = ctypes.c_int
-        for fn in (L.oracle_sparse_mul3, L.oracle_sparse_mul2, L.oracle_sparse_mul5, L.oracle_sparse_mul4,
-                   L.oracle_tendencies_r, L.oracle_jacobian_r, L.oracle_rk_integrate_r, L.oracle_rk_tgls_integrate_r):
-            fn.restype = None
-        _LIB = L
+        _LIB = _bind(ctypes.CDLL(build()))
     return _LIB
 
 
@@ -94,8 +113,10 @@ class OracleModel(object):
     tensor is the width of `coo`: 3 (QgsTensor: sparse_mul3 / sparse_mul2) or 5 (QgsTensorDynamicT / QgsTensorT4:
     sparse_mul5 / sparse_mul4, tendencies.py:98-109)."""
 
-    def __init__(self, ndim, coo, val, jcoo=None, jval=None):
+    def __init__(self, ndim, coo, val, jcoo=None, jval=None, flavour='parity'):
         self.ndim = int(ndim)
+        self._flavour = flavour
+        lib(flavour)
         self.coo, self.val = _c(coo, np.int32), _c(val)
         self.rank = int(self.coo.shape[1])
         assert self.rank in (3, 5)
@@ -107,14 +128,14 @@ class OracleModel(object):
         x = _c(x)
         xb = x.reshape(-1, self.ndim)
         out = np.empty_like(xb)
-        lib().oracle_tendencies_r(self.rank, self.ndim, len(self.val), self.coo, self.val, xb.shape[0], xb, out)
+        lib(self._flavour).oracle_tendencies_r(self.rank, self.ndim, len(self.val), self.coo, self.val, xb.shape[0], xb, out)
         return out.reshape(x.shape)
 
     def Df(self, t, x):
         x = _c(x)
         xb = x.reshape(-1, self.ndim)
         out = np.empty((xb.shape[0], self.ndim, self.ndim))
-        lib().oracle_jacobian_r(self.rank, self.ndim, len(self.jval), self.jcoo, self.jval, xb.shape[0], xb, out)
+        lib(self._flavour).oracle_jacobian_r(self.rank, self.ndim, len(self.jval), self.jcoo, self.jval, xb.shape[0], xb, out)
         return out[0] if x.ndim == 1 else out
 
     @staticmethod
@@ -128,7 +149,7 @@ class OracleModel(object):
         n_traj = ic.shape[0]
         nrec = self.n_records(time, write_steps)
         rec = np.zeros((n_traj, self.ndim, nrec))
-        lib().oracle_rk_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, n_traj, ic, time, len(time),
+        lib(self._flavour).oracle_rk_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, n_traj, ic, time, len(time),
                                   int(time_direction), int(write_steps), len(b), b, c, a, nrec, rec, int(threads))
         return rec
 
@@ -140,7 +161,7 @@ class OracleModel(object):
         nrec = self.n_records(time, write_steps)
         rec = np.zeros((n_traj, self.ndim, nrec))
         recm = np.zeros((n_traj, self.ndim, n_tg, nrec))
-        lib().oracle_rk_tgls_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, len(self.jval), self.jcoo,
+        lib(self._flavour).oracle_rk_tgls_integrate_r(self.rank, self.ndim, len(self.val), self.coo, self.val, len(self.jval), self.jcoo,
                                        self.jval, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
                                        int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
                                        nrec, rec, recm, int(threads))

@@ -263,6 +263,14 @@ class HipModel(object):
         lib().qgs_model_kernel_source(self._h, buf, int(n) + 1)
         return buf.value.decode()
 
+    def _check_ic(self, ic, tg_ic=None):
+        """The C side copies n_traj * ndim doubles from the pointer it is given: refuse shapes that do not hold them."""
+        if ic.ndim != 2 or ic.shape[1] != self.ndim or ic.shape[0] < 1:
+            raise ValueError('initial conditions must have shape (n_traj, %d), got %r' % (self.ndim, ic.shape))
+        if tg_ic is not None and (tg_ic.ndim != 3 or tg_ic.shape[:2] != (ic.shape[0], self.ndim) or tg_ic.shape[2] < 1):
+            raise ValueError('tangent initial conditions must have shape (%d, %d, n_tg), got %r'
+                             % (ic.shape[0], self.ndim, tg_ic.shape))
+
     # ---- host-layout calls (NumPy in, NumPy out) ----------------------------------------------
     def tendencies(self, x):
         x = _c(x)
@@ -280,6 +288,7 @@ class HipModel(object):
 
     def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a):
         time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
+        self._check_ic(ic)
         nrec = n_records(time, write_steps)
         traj = _RESULTS.empty((ic.shape[0], self.ndim, nrec))
         _check(lib().qgs_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
@@ -290,6 +299,7 @@ class HipModel(object):
         """Same run as `rk_integrate`; returns the ensemble mean and variance (n_dim, n_records) of every variable at every
         record (and optionally the final states) -- the trajectories never leave the device."""
         time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
+        self._check_ic(ic)
         nrec = n_records(time, write_steps)
         mean = np.empty((self.ndim, nrec))
         var = np.empty((self.ndim, nrec)) if variance else None
@@ -304,6 +314,7 @@ class HipModel(object):
 
     def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse):
         time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)
+        self._check_ic(ic, tg_ic)
         nrec = n_records(time, write_steps)
         n_traj, n_tg = ic.shape[0], tg_ic.shape[2]
         traj = _RESULTS.empty((n_traj, self.ndim, nrec))

@@ -33,6 +33,7 @@ struct KTable {
 };
 thread_local KTable *g_ktab = nullptr;
 thread_local bool g_asm_lit = false;
+thread_local bool g_ktab_samelines = false;   // timing experiment (lds_debug & 4): every group fetches table lines 0 / 1 (always hits)
 thread_local bool g_kdpp = false;         // coefficient statements as QGS_KFMA(acc, @K..@, factor): lane-broadcast operands (resolve_ktab group 64)      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
 
 std::string lit(double v)
@@ -203,8 +204,13 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
     const size_t nblocks = (total + 7) / 8;
     auto load_group = [&](size_t g, const char *ind) {
         std::string l;
-        for (size_t b = 2 * g; b < 2 * g + 2 && b < nblocks; ++b)
-            l += std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
+        for (size_t b = 2 * g; b < 2 * g + 2 && b < nblocks; ++b) {
+            if (g_ktab_samelines)          // opaque pointer per load: identical loads must not be merged
+                l += std::string(ind) + "kf64* kth" + std::to_string(b) + " = kt; asm volatile(\"\" : \"+s\"(kth" + std::to_string(b) + "));\n" +
+                     ind + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kth" + std::to_string(b) + " + " + std::to_string(8 * (b % 2)) + ");\n";
+            else
+                l += std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
+        }
         return l;
     };
     const char *ind = "                ";
@@ -1635,7 +1641,9 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
                         }, stats);
+        g_ktab_samelines = (opt.lds_debug & 4) != 0;
         o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : (dpp ? 64 + opt.lds_dpp_ahead : opt.ktab_group), opt.lds_coeff_dedupe) : so.str());
+        g_ktab_samelines = false;
         g_ktab = nullptr;
         g_kdpp = false;
         g_asm_lit = false;

@@ -10,10 +10,14 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <limits.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -26,6 +30,8 @@
 
 #include "codegen.h"
 #include "generic_kernels.h"
+
+extern char **environ;
 
 #ifndef QGS_LDS_STATE_BYTES
 #define QGS_LDS_STATE_BYTES (152 * 1024)   // stage state of the LDS-resident stepper: ndim * 64 members * 8 B (160 KB LDS per CU)
@@ -129,9 +135,103 @@ std::vector<std::string> flags_for(const std::string &src)
     return extra;
 }
 
+// ---- which compiler builds the specialised kernels -------------------------------------------------------------------
+// Default: the helper process qgs_kcompile next to this library (kcompile.cpp), which is bound to the system ROCm's hiprtc /
+// comgr.  A process that imported PyTorch has torch's older bundled pair mapped under the same sonames, and that pair
+// generates worse code for the fused stepper (324 instead of 282 VGPRs); going through the helper gives the same code
+// object everywhere.  QGS_HIP_INPROC_RTC=1 (or a missing helper) compiles with whatever hiprtc this process has mapped.
+// The identity of the compiler is part of the cache key, so objects of one never pass for the other's.
+std::string helper_path() { return lib_dir() + "/qgs_kcompile"; }
+
+// environment of the helper: no preloaded tool libraries (profilers), it must stay a plain compiler process
+std::vector<std::string> helper_env()
+{
+    std::vector<std::string> env;
+    for (char **e = environ; e && *e; ++e) {
+        const std::string kv(*e);
+        if (kv.rfind("LD_PRELOAD=", 0) == 0 || kv.rfind("HSA_TOOLS_LIB=", 0) == 0 || kv.rfind("ROCP_", 0) == 0 ||
+            kv.rfind("ROCPROFILER_", 0) == 0 || kv.rfind("LD_LIBRARY_PATH=", 0) == 0) continue;
+        env.push_back(kv);
+    }
+    return env;
+}
+
+// run the helper; stdout + stderr of the child end up in *output
+int run_helper(const std::vector<std::string> &args, std::string *output)
+{
+    int fds[2];
+    if (pipe(fds) != 0) return -1;
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_adddup2(&fa, fds[1], 1);
+    posix_spawn_file_actions_adddup2(&fa, fds[1], 2);
+    posix_spawn_file_actions_addclose(&fa, fds[0]);
+    posix_spawn_file_actions_addclose(&fa, fds[1]);
+    std::vector<char *> argv;
+    for (const auto &a : args) argv.push_back(const_cast<char *>(a.c_str()));
+    argv.push_back(nullptr);
+    const std::vector<std::string> env = helper_env();
+    std::vector<char *> envp;
+    for (const auto &e : env) envp.push_back(const_cast<char *>(e.c_str()));
+    envp.push_back(nullptr);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, args[0].c_str(), &fa, nullptr, argv.data(), envp.data());
+    posix_spawn_file_actions_destroy(&fa);
+    close(fds[1]);
+    if (rc != 0) { close(fds[0]); return -1; }
+    char buf[4096];
+    ssize_t n;
+    while ((n = read(fds[0], buf, sizeof buf)) > 0) if (output) output->append(buf, (size_t)n);
+    close(fds[0]);
+    int status = 0;
+    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+    return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : 1;
+}
+
+bool use_helper()
+{
+    static const bool yes = [] {
+        if (const char *e = std::getenv("QGS_HIP_INPROC_RTC")) if (*e == '1') return false;
+        if (access(helper_path().c_str(), X_OK) != 0) {
+            std::fprintf(stderr, "libqgs_hip: %s is missing (make -C qgs_amd/csrc); kernels that miss the cache are compiled by the "
+                                 "hiprtc this process has mapped\n", helper_path().c_str());
+            return false;
+        }
+        return true;
+    }();
+    return yes;
+}
+
+// e.g. "hiprtc9.0-libhiprtc.so.7.2.70200": API level + the library file the compiler resolved to
+std::string compiler_id()
+{
+    static const std::string id = [] {
+        if (use_helper()) {
+            std::string out;
+            if (run_helper({helper_path(), "--version"}, &out) == 0 && !out.empty()) {
+                while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+                return out;
+            }
+            std::fprintf(stderr, "libqgs_hip: %s --version failed: %s\n", helper_path().c_str(), out.c_str());
+        }
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        std::string file = "?";
+        Dl_info info;
+        if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
+            char real[PATH_MAX];
+            file = realpath(info.dli_fname, real) ? real : info.dli_fname;
+            const size_t k = file.find_last_of('/');
+            if (k != std::string::npos) file = file.substr(k + 1);
+        }
+        return "inproc-hiprtc" + std::to_string(major) + "." + std::to_string(minor) + "-" + file;
+    }();
+    return id;
+}
+
 std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra)
 {
-    std::string opts_key = arch + "|O3|c++17|v1";
+    std::string opts_key = arch + "|O3|c++17|v2|" + compiler_id();
     for (const auto &x : extra) opts_key += "|" + x;
     char name[64];
     std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
@@ -144,22 +244,8 @@ bool source_is_cached(const std::string &src, const std::string &arch)
     return (bool)f;
 }
 
-int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+int compile_in_process(const std::string &src, const std::string &arch, const std::vector<std::string> &extra, std::vector<char> &code)
 {
-    const std::vector<std::string> extra = flags_for(src);
-    const std::string path = cache_path(src, arch, extra);
-    {
-        std::ifstream f(path, std::ios::binary);
-        if (f) {
-            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            if (!code.empty()) { if (from_cache) *from_cache = true; return 0; }
-        }
-    }
-    if (from_cache) *from_cache = false;
-    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // developer knob: keep the generated source next to nothing else
-        std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
-        f << src;
-    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "qgs_spec.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS)
         return fail("hiprtcCreateProgram failed");
@@ -180,8 +266,47 @@ int compile_source(const std::string &src, const std::string &arch, std::vector<
     code.resize(n);
     hiprtcGetCode(prog, code.data());
     hiprtcDestroyProgram(&prog);
+    return 0;
+}
+
+int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+{
+    const std::vector<std::string> extra = flags_for(src);
+    const std::string path = cache_path(src, arch, extra);
+    {
+        std::ifstream f(path, std::ios::binary);
+        if (f) {
+            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+            if (!code.empty()) { if (from_cache) *from_cache = true; return 0; }
+        }
+    }
+    if (from_cache) *from_cache = false;
+    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // developer knob: keep the generated source
+        std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
+        f << src;
+    }
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    if (use_helper()) {
+        const std::string srcfile = tmp + ".hip";
+        {
+            std::ofstream f(srcfile, std::ios::binary);
+            f << src;
+            if (!f) return fail("cannot write " + srcfile + " (kernel cache directory not writable?)");
+        }
+        std::vector<std::string> args = {helper_path(), arch, srcfile, tmp};
+        args.insert(args.end(), extra.begin(), extra.end());
+        std::string out;
+        const int rc = run_helper(args, &out);
+        std::remove(srcfile.c_str());
+        if (rc != 0) { std::remove(tmp.c_str()); return fail("kernel compilation failed (" + helper_path() + "):\n" + out.substr(0, 4000)); }
+        std::ifstream f(tmp, std::ios::binary);
+        code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+        if (code.empty()) { std::remove(tmp.c_str()); return fail("kernel compilation produced no code object"); }
+        std::rename(tmp.c_str(), path.c_str());                   // atomic publish into the cache
+        return 0;
+    }
+    if (compile_in_process(src, arch, extra, code)) return -1;
     {   // atomic publish into the cache
-        const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
         std::ofstream f(tmp, std::ios::binary);
         if (f) {
             f.write(code.data(), (std::streamsize)code.size());

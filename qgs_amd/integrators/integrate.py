@@ -47,14 +47,15 @@ def record_times(time, write_steps, forward):
     return time[-1]
 
 
-def hip_model_of(func, what='f'):
-    """The GPU handle behind a tendencies callable; arbitrary Python callables cannot run on the device."""
+def hip_model_of(func, what='f', device=None):
+    """The GPU handle behind a tendencies callable (on `device`, default the one the callable was created for);
+    arbitrary Python callables cannot run on the device."""
     get = getattr(func, 'hip_model', None)
     if get is None:
         raise TypeError("%s must come from qgs_amd.functions.tendencies (create_tendencies / tendencies_from_tensor): "
                         "a plain Python callable carries no tensor to stage on the GPU, and qgs_amd has no CPU "
                         "integration path" % what)
-    return get()
+    return get(device)
 
 
 def dimension_of(func):

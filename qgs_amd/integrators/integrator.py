@@ -20,8 +20,9 @@ from qgs_amd.integrators import integrate as _fn
 class _EnsembleIntegrator(object):
     """State shared by the trajectory and the tangent-linear integrators."""
 
-    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None):
+    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, device=None):
         self.num_threads = multiprocessing.cpu_count() if num_threads is None else num_threads
+        self.device = device               # GPU index of the engine (None: the device the tendencies were created for)
         self.b, self.c, self.a = _fn.resolve_tableau(b, c, a)
         self.ic = None
         self._time = None
@@ -43,7 +44,7 @@ class _EnsembleIntegrator(object):
         """(Re)acquire the GPU engine for the current `func` (reference: restart the worker processes)."""
         self.terminate()
         if self.func is not None:
-            self._model = _fn.hip_model_of(self.func)
+            self._model = _fn.hip_model_of(self.func, device=self.device)
 
     def set_bca(self, b=None, c=None, a=None, ic_init=True):
         """Set the Butcher tableau; `ic_init` resets the stored initial conditions."""
@@ -148,7 +149,8 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
 
     Parameters, attributes and methods as in the reference (integrator.py:27-450):
     ``RungeKuttaIntegrator(num_threads=None, b=None, c=None, a=None, number_of_dimensions=None)``; attributes
-    ``num_threads, b, c, a, n_dim, n_traj, n_records, ic, func``.
+    ``num_threads, b, c, a, n_dim, n_traj, n_records, ic, func``.  One keyword beyond the reference: ``device``, the index
+    of the GPU that integrates (multi-GPU jobs: one process per GPU, ``device=LOCAL_RANK``; see qgs_amd/parallel.py).
     """
 
     def set_func(self, f, ic_init=True):
@@ -199,8 +201,8 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
 class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
     """Integrate the trajectories together with their tangent linear / adjoint model (integrator.py:515-1100)."""
 
-    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None):
-        super(RungeKuttaTglsIntegrator, self).__init__(num_threads, b, c, a, number_of_dimensions)
+    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, device=None):
+        super(RungeKuttaTglsIntegrator, self).__init__(num_threads, b, c, a, number_of_dimensions, device)
         self.tg_ic = None
         self._recorded_fmatrix = None
         self.n_tg_traj = 0
@@ -220,7 +222,7 @@ class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
     def start(self):
         super(RungeKuttaTglsIntegrator, self).start()
         if self.func is not None and self.func_jac is not None:
-            if _fn.hip_model_of(self.func_jac, 'fjac') is not self._model:
+            if _fn.hip_model_of(self.func_jac, 'fjac', device=self.device) is not self._model:
                 raise TypeError('f and fjac must come from the same create_tendencies() call')
 
     def integrate(self, t0, t, dt, ic=None, tg_ic=None, forward=True, adjoint=False, inverse=False, boundary=None,

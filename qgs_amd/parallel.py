@@ -29,7 +29,8 @@ class ShardedEnsemble(object):
         import torch.distributed as dist
         self._dist = dist
         self.group = process_group
-        if dist.is_available() and dist.is_initialized():
+        self.distributed = bool(dist.is_available() and dist.is_initialized())
+        if self.distributed:
             self.rank = dist.get_rank(process_group)
             self.world_size = dist.get_world_size(process_group)
         else:
@@ -53,9 +54,9 @@ class ShardedEnsemble(object):
         (`all_gather_into_tensor`, one RCCL call); ragged shards are padded to the largest shard."""
         import torch
         dist = self._dist
-        if self.world_size == 1:
+        if not self.distributed:
             return local
-        local = local.contiguous()
+        local = local.contiguous()                 # (a one-rank group still goes through the collective: plumbing check)
         if len(set(self.counts)) == 1:
             out = torch.empty((self.n_total,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             dist.all_gather_into_tensor(out, local, group=self.group)
@@ -83,7 +84,7 @@ class RootGather(object):
         """Returns (work handle or None, list of per-rank views of `out` on the root)."""
         import torch
         dist = self.ens._dist
-        if self.ens.world_size == 1:
+        if not self.ens.distributed:
             return None, [local]
         parts = None
         if self.ens.rank == self.dst:
@@ -94,36 +95,72 @@ class RootGather(object):
         return work, parts
 
 
+def _integrate_shard_on_device(f, device, local_ic, time, forward, write_steps, b, c, a):
+    """One rank's block on its own GPU, results left in HBM: (n_local, n_dim, n_records) torch tensor on `device`.
+    pack -> fused stepper -> record unpack, all on the device (C-ABI device-layout entry points)."""
+    import torch
+    from qgs_amd import _lib
+    model = f.hip_model(device=device.index)
+    n, ndim = local_ic.shape
+    nrec = _lib.n_records(time, write_steps)
+    ld = (n + 63) // 64 * 64
+    with torch.cuda.device(device):
+        st = torch.cuda.current_stream(device).cuda_stream
+        d_rows = torch.from_numpy(local_ic).to(device)
+        d_modes = torch.empty((ndim, ld), dtype=torch.float64, device=device)
+        d_rec = torch.empty((nrec, ndim, ld), dtype=torch.float64, device=device)
+        d_out = torch.empty((n, ndim, nrec), dtype=torch.float64, device=device)
+        model.pack_states(n, ld, d_rows.data_ptr(), d_modes.data_ptr(), st)
+        model.rk_integrate_device(n, ld, d_modes.data_ptr(), time, 1 if forward else -1, write_steps, b, c, a, d_rec.data_ptr(), st)
+        model.unpack_records(n, ld, ndim, nrec, d_rec.data_ptr(), d_out.data_ptr(), st)
+    return d_out
+
+
 def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=None, a=None, process_group=None,
                        device=None, integrator_factory=None):
     """Integrate a (n_traj, n_dim) ensemble sharded over the ranks of `process_group`; every rank returns the
     full ``(time, traj)`` with traj of shape (n_traj, n_dim, n_records) (not squeezed).
 
-    Each rank integrates `ic[shard]` on its own GPU through `RungeKuttaIntegrator` and the trajectories are
-    gathered once at the end.  `integrator_factory` is a test seam: a callable returning an object with the
-    `RungeKuttaIntegrator` interface.
+    On GPUs (backend "nccl", or no process group at all) each rank integrates `ic[shard]` on ITS OWN device --
+    `device`, default the current CUDA device, i.e. LOCAL_RANK after `torch.cuda.set_device` -- and the results stay
+    in HBM until they have been gathered: H2D of the shard, pack, fused stepper, record unpack, one RCCL all-gather,
+    one D2H.  `integrator_factory` is a test seam for CPU process groups (gloo): a callable returning an object with
+    the `RungeKuttaIntegrator` interface; its NumPy results are gathered through host tensors.
     """
     import torch
+    from qgs_amd.integrators.integrate import record_times, resolve_tableau, time_grid
     ic = np.asarray(ic, dtype=np.float64)
     if ic.ndim == 1:
         ic = ic.reshape((1, -1))
     ens = ShardedEnsemble(ic.shape[0], process_group)
-    if integrator_factory is None:
-        from qgs_amd.integrators.integrator import RungeKuttaIntegrator
-        integ = RungeKuttaIntegrator(b=b, c=c, a=a)
-    else:
-        integ = integrator_factory(b=b, c=c, a=a)
-    integ.set_func(f)
     local_ic = np.ascontiguousarray(ic[ens.local_slice])
-    time = None
+    grid = time_grid(t0, t, dt)
+    time = record_times(grid, write_steps, forward)
+    if integrator_factory is None:
+        # ---- device-resident route ----
+        from qgs_amd import _lib
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        device = torch.device(device)
+        b, c, a = resolve_tableau(b, c, a)
+        nrec = _lib.n_records(grid, write_steps)
+        if ens.n_local > 0:
+            local = _integrate_shard_on_device(f, device, local_ic, grid, forward, write_steps, b, c, a)
+        else:
+            local = torch.zeros((0, ic.shape[1], nrec), dtype=torch.float64, device=device)
+        full = ens.gather(local)
+        return time, full.cpu().numpy()
+    # ---- host route (test seam) ----
+    integ = integrator_factory(b=b, c=c, a=a)
+    integ.set_func(f)
     if ens.n_local > 0:
         integ.integrate(t0, t, dt, ic=local_ic, forward=forward, write_steps=write_steps)
-        time, _ = integ.get_trajectories()
+        integ.get_trajectories()
         local = np.asarray(integ._recorded_traj)
     else:
         local = np.zeros((0, ic.shape[1], 1))
     integ.terminate()
-    if ens.world_size == 1:
+    if not ens.distributed:
         return time, local
     if device is None:
         backend = ens._dist.get_backend(process_group)
@@ -134,7 +171,4 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
     if ens.n_local == 0:
         local = np.zeros((0, ic.shape[1], int(nrec.item())))
     full = ens.gather(torch.from_numpy(np.ascontiguousarray(local)).to(device))
-    if time is None:
-        from qgs_amd.integrators.integrate import record_times, time_grid
-        time = record_times(time_grid(t0, t, dt), write_steps, forward)
     return time, full.cpu().numpy()

@@ -125,9 +125,14 @@ class LyapunovsEstimator(object):
         n_pre = len(self._pretime)
 
         # random orthonormal start basis, drawn like the reference (one draw per trajectory, in order)
-        q0 = np.stack([np.linalg.qr(np.random.random((ndim, nv)))[0] for _ in range(n)])        # (n, ndim, nv)
+        qr0 = [np.linalg.qr(np.random.random((ndim, nv))) for _ in range(n)]
+        q0 = np.stack([x[0] for x in qr0])                                                        # (n, ndim, nv)
         q = torch.zeros((ndim, nv, ld), dtype=f64, device=dev)
         q[:, :, :n] = torch.from_numpy(np.ascontiguousarray(q0.transpose(1, 2, 0))).to(dev)
+        # diag(R) of that first QR: with an empty spin-up the reference's `r = qr[1]` is still this one
+        # (lyapunov.py:524, 603), so the first recorded exponents come from it
+        rdiag0 = torch.ones((nv, ld), dtype=f64, device=dev)
+        rdiag0[:, :n] = torch.from_numpy(np.ascontiguousarray(np.stack([np.diag(x[1]) for x in qr0]).T)).to(dev)
 
         q_new = torch.empty((1, ndim, nv, ld), dtype=f64, device=dev)
         y_end = torch.empty((1, ndim, ld), dtype=f64, device=dev)
@@ -154,8 +159,8 @@ class LyapunovsEstimator(object):
                 tt, d = pre[ti], pre[ti + 1] - pre[ti]
                 sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
                 rdiag = propagate(ti, sub, 1)
-            if rdiag is None:       # no spin-up interval: R of the initial QR is not kept by the reference either
-                rdiag = torch.ones((nv, ld), dtype=f64, device=dev)
+            if rdiag is None:       # no spin-up interval
+                rdiag = rdiag0
             iw, last = 0, None
             for ti in range(len(tim) - 1):
                 tt, d = tim[ti], tim[ti + 1] - tim[ti]
@@ -182,7 +187,7 @@ class LyapunovsEstimator(object):
                 sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
                 rdiag = propagate(n_t - 1 + (len(post) - 1 - ti), sub, -1)          # posttraj[:, :, -1-ti]
             if rdiag is None:
-                rdiag = torch.ones((nv, ld), dtype=f64, device=dev)
+                rdiag = rdiag0
             iw, last, y_idx = self.n_records - 1, None, n_t - 1
             for ti in range(len(rtim) - 1):
                 tt, d = rtim[ti], rtim[ti + 1] - rtim[ti]
