@@ -8,6 +8,7 @@ the GPU through `qgs_rk_integrate` / `qgs_rk_tgls_integrate` for the whole ensem
 import numpy as np
 
 from qgs_amd.functions.util import reverse
+from qgs_amd.integrators import host_stepper
 
 
 def default_tableau():
@@ -47,21 +48,25 @@ def record_times(time, write_steps, forward):
     return time[-1]
 
 
+def on_device(func):
+    """True for the tendencies / Jacobian objects of qgs_amd.functions.tendencies (they carry the tensor the kernels are
+    generated from); False for a plain Python callable, which is integrated on the host (host_stepper.py)."""
+    return getattr(func, 'hip_model', None) is not None
+
+
 def hip_model_of(func, what='f', device=None):
-    """The GPU handle behind a tendencies callable (on `device`, default the one the callable was created for);
-    arbitrary Python callables cannot run on the device."""
+    """The GPU handle behind a tendencies callable (on `device`, default the one the callable was created for)."""
     get = getattr(func, 'hip_model', None)
     if get is None:
-        raise TypeError("%s must come from qgs_amd.functions.tendencies (create_tendencies / tendencies_from_tensor): "
-                        "a plain Python callable carries no tensor to stage on the GPU, and qgs_amd has no CPU "
-                        "integration path" % what)
+        raise TypeError("%s carries no tensor: plain Python callables are integrated by qgs_amd.integrators.host_stepper, "
+                        "not on the GPU" % what)
     return get(device)
 
 
 def dimension_of(func):
     nd = getattr(func, 'ndim', None)
     if nd is None:
-        raise TypeError('cannot determine the system dimension: the callable carries no tensor')
+        return host_stepper.discover_dimension(func)      # the reference's probing loop (integrator.py:346-359)
     return int(nd)
 
 
@@ -105,20 +110,34 @@ def restore_fmatrix_axes(recorded_fmatrix, tg_ic_user, n_dim):
     return recorded_fmatrix
 
 
-def check_boundary(boundary):
-    if boundary is not None:
-        raise NotImplementedError('only the zero boundary term (the default, integrate.py:235-237) runs on the device')
+def run_rk(f, time, ic, time_direction, write_steps, b, c, a, device=None):
+    """One ensemble integration, (n_traj, n_dim, n_records): the fused HIP stepper for tensor tendencies, the host stepper
+    for a user-written callable."""
+    if on_device(f):
+        return hip_model_of(f, device=device).rk_integrate(time, ic, time_direction, write_steps, b, c, a)
+    return host_stepper.integrate_runge_kutta(f, time, np.ascontiguousarray(ic, dtype=np.float64), time_direction, write_steps, b, c, a)
+
+
+def run_rk_tgls(f, fjac, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse, boundary, device=None):
+    """Trajectories + tangent / adjoint model.  On the device when `f`, `fjac` come from one create_tendencies() call and
+    the boundary term is the default zero; otherwise on the host (a `boundary` callable, or user-written `f` / `fjac`)."""
+    if on_device(f) and on_device(fjac) and boundary is None:
+        model = hip_model_of(f, device=device)
+        if hip_model_of(fjac, 'fjac', device=device) is not model:
+            raise TypeError('f and fjac must come from the same create_tendencies() call')
+        return model.rk_tgls_integrate(time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse)
+    return host_stepper.integrate_runge_kutta_tgls(f, fjac, time, np.ascontiguousarray(ic, dtype=np.float64), tg_ic, time_direction,
+                                                   write_steps, b, c, a, adjoint, inverse, boundary)
 
 
 def integrate_runge_kutta(f, t0, t, dt, ic=None, forward=True, write_steps=1, b=None, c=None, a=None):
     """Integrate dx/dt = f(t, x) for one state or an ensemble of states; returns ``(time, traj)`` with the
     reference's conventions: traj is ``np.squeeze`` of (n_traj, n_dim, n_records); time is a scalar when
     ``write_steps == 0``."""
-    model = hip_model_of(f)
-    ic = normalise_ic(ic, dimension_of(f))
+    ic = normalise_ic(ic, None if ic is not None else dimension_of(f))
     b, c, a = resolve_tableau(b, c, a)
     time = time_grid(t0, t, dt)
-    recorded = model.rk_integrate(time, ic, 1 if forward else -1, write_steps, b, c, a)
+    recorded = run_rk(f, time, ic, 1 if forward else -1, write_steps, b, c, a)
     return record_times(time, write_steps, forward), np.squeeze(recorded)
 
 
@@ -126,17 +145,13 @@ def integrate_runge_kutta_tgls(f, fjac, t0, t, dt, ic=None, tg_ic=None, forward=
                                boundary=None, write_steps=1, b=None, c=None, a=None):
     """Integrate the trajectory together with its tangent linear (or adjoint) model; returns
     ``(time, traj, fmatrix)`` like integrate.py:240-552."""
-    check_boundary(boundary)
-    model = hip_model_of(f)
-    if fjac is None or hip_model_of(fjac, 'fjac') is not model:
-        raise TypeError('f and fjac must come from the same create_tendencies() call')
-    n_dim = dimension_of(f)
-    ic = normalise_ic(ic, n_dim)
+    ic = normalise_ic(ic, None if ic is not None else dimension_of(f))
+    n_dim = ic.shape[1]
     tg_user = np.eye(n_dim) if tg_ic is None else np.asarray(tg_ic, dtype=np.float64)
     tg = normalise_tg_ic(tg_user, ic.shape[0], n_dim)
     b, c, a = resolve_tableau(b, c, a)
     time = time_grid(t0, t, dt)
-    traj, fm = model.rk_tgls_integrate(time, ic, tg, 1 if forward else -1, write_steps, b, c, a, adjoint,
-                                       -1. if inverse else 1.)
+    traj, fm = run_rk_tgls(f, fjac, time, ic, tg, 1 if forward else -1, write_steps, b, c, a, adjoint,
+                           -1. if inverse else 1., boundary)
     fm = restore_fmatrix_axes(fm, tg_user, n_dim)
     return record_times(time, write_steps, forward), np.squeeze(traj), np.squeeze(fm)

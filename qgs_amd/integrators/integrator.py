@@ -43,7 +43,7 @@ class _EnsembleIntegrator(object):
     def start(self):
         """(Re)acquire the GPU engine for the current `func` (reference: restart the worker processes)."""
         self.terminate()
-        if self.func is not None:
+        if self.func is not None and _fn.on_device(self.func):
             self._model = _fn.hip_model_of(self.func, device=self.device)
 
     def set_bca(self, b=None, c=None, a=None, ic_init=True):
@@ -166,11 +166,10 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
         if self.func is None:
             print('No function to integrate defined!')
             return 0
-        if self._model is None:
-            self.start()
         self._prepare(t0, t, dt, ic, forward, write_steps)
-        self._recorded_traj = self._model.rk_integrate(self._time, self.ic, self._time_direction, write_steps,
-                                                       self.b, self.c, self.a)
+        # tensor tendencies: the fused HIP stepper; a user-written callable (integrator.py:1237-1256): the host stepper
+        self._recorded_traj = _fn.run_rk(self.func, self._time, self.ic, self._time_direction, write_steps,
+                                         self.b, self.c, self.a, device=self.device)
 
     def integrate_moments(self, t0, t, dt, ic=None, forward=True, write_steps=1, variance=True):
         """Integrate like `integrate`, but bring back only the ensemble mean and variance over the members:
@@ -181,6 +180,8 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
         if self.func is None:
             print('No function to integrate defined!')
             return 0
+        if not _fn.on_device(self.func):
+            raise TypeError('integrate_moments reduces on the device: it needs tendencies from create_tendencies()')
         if self._model is None:
             self.start()
         self._prepare(t0, t, dt, ic, forward, write_steps)
@@ -221,7 +222,7 @@ class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
 
     def start(self):
         super(RungeKuttaTglsIntegrator, self).start()
-        if self.func is not None and self.func_jac is not None:
+        if self._model is not None and self.func_jac is not None and _fn.on_device(self.func_jac):
             if _fn.hip_model_of(self.func_jac, 'fjac', device=self.device) is not self._model:
                 raise TypeError('f and fjac must come from the same create_tendencies() call')
 
@@ -229,13 +230,12 @@ class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
                   write_steps=1):
         """As `RungeKuttaIntegrator.integrate`, plus `tg_ic` (None = identity; (n_dim,), (n_tg, n_dim),
         (n_traj, n_dim) or 3-D), `adjoint` (propagate with J^T), `inverse` (flip the sign of the tangent
-        tendencies) and `boundary` (only None = zero inhomogeneous term is supported on the device)."""
+        tendencies) and `boundary` (a callable ``boundary(t, x)`` adding an inhomogeneous term to the tangent tendencies,
+        integrate.py:600-603; None = zero).  With ``boundary=None`` and tensor tendencies everything runs on the device; a
+        boundary callable is evaluated on the host, stage by stage (host_stepper.py)."""
         if self.func is None or self.func_jac is None:
             print('No function to integrate defined!')
             return 0
-        _fn.check_boundary(boundary)
-        if self._model is None:
-            self.start()
         self._prepare(t0, t, dt, ic, forward, write_steps)
         tg_user = np.eye(self.n_dim) if tg_ic is None else np.asarray(tg_ic, dtype=np.float64)
         # NOTE the reference leaves `self.tg_ic` untouched for a 3-D tg_ic that is already (n_traj, n_dim, n_tg)
@@ -245,8 +245,8 @@ class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
         self._adjoint = adjoint
         self._boundary = boundary
         self._inverse = -1. if inverse else 1.
-        traj, fm = self._model.rk_tgls_integrate(self._time, self.ic, self.tg_ic, self._time_direction, write_steps,
-                                                 self.b, self.c, self.a, adjoint, self._inverse)
+        traj, fm = _fn.run_rk_tgls(self.func, self.func_jac, self._time, self.ic, self.tg_ic, self._time_direction, write_steps,
+                                   self.b, self.c, self.a, adjoint, self._inverse, boundary, device=self.device)
         self._recorded_traj = traj
         self._recorded_fmatrix = _fn.restore_fmatrix_axes(fm, tg_user, self.n_dim)
 

@@ -412,6 +412,92 @@ def gen_lyapunov(name):
     print('[lyap %s] wrote %s (%.1f KB)' % (name, path, os.path.getsize(path) / 1024.), flush=True)
 
 
+# Lorenz-84 as written in the reference's own usage example (qgs/integrators/integrator.py:1230-1256, 1285-1287): a user-written
+# system with its Jacobian and a boundary term for the tangent model.  tests/callables_l84.py holds the same three functions.
+L84 = dict(a=0.25, F=16., G=3., b=6.)
+
+
+def fL84(t, x):
+    a, F, G, b = L84['a'], L84['F'], L84['G'], L84['b']
+    xx = -x[1] ** 2 - x[2] ** 2 - a * x[0] + a * F
+    yy = x[0] * x[1] - b * x[0] * x[2] - x[1] + G
+    zz = b * x[0] * x[1] + x[0] * x[2] - x[2]
+    return np.array([xx, yy, zz])
+
+
+def DfL84(t, x):
+    a, b = L84['a'], L84['b']
+    return np.array([[-a, -2. * x[1], -2. * x[2]],
+                     [x[1] - b * x[2], -1. + x[0], -b * x[0]],
+                     [b * x[1] + x[2], b * x[0], -1. + x[0]]])
+
+
+def tboundary(t, x):
+    return np.array([0., x[1], 0.])
+
+
+def rp20_boundary(t, x):
+    return 0.01 * x
+
+
+def gen_callables():
+    """User-written callables through the reference's integrators (functional API, classes, boundary term): the cases of the
+    host stepper of qgs_amd (qgs_amd/integrators/host_stepper.py)."""
+    out = {}
+    ic = np.random.RandomState(11).randn(4, 3)
+    out['ic'] = ic
+    kutta3 = dict(b=np.array([1. / 6, 2. / 3, 1. / 6]), c=np.array([0., .5, 1.]), a=np.array([[0., 0, 0], [.5, 0, 0], [-1., 2., 0]]))
+    for tag, kw in [('fw_w10', dict(write_steps=10)), ('bw_w7', dict(forward=False, write_steps=7)), ('w0', dict(write_steps=0)),
+                    ('kutta3_w5', dict(write_steps=5, **kutta3))]:
+        tt, tr = integrate_runge_kutta(fL84, 0., 2., 0.01, ic=ic, **kw)
+        out['rk_%s_time' % tag], out['rk_%s_traj' % tag] = np.asarray(tt), tr
+    tt, tr = integrate_runge_kutta(fL84, 0., 1., 0.01, ic=ic[0], write_steps=20)
+    out['rk_single_time'], out['rk_single_traj'] = np.asarray(tt), tr
+    tg2 = np.random.RandomState(12).randn(2, 3)
+    out['tg2'] = tg2
+    for tag, kw in [('bnd_zero_tg', dict(tg_ic=np.zeros(3), boundary=tboundary, write_steps=10)),
+                    ('bnd_adj_inv_bw', dict(tg_ic=tg2, boundary=tboundary, write_steps=10, adjoint=True, inverse=True, forward=False)),
+                    ('nobnd_identity', dict(write_steps=25)),
+                    ('bnd_identity_w0', dict(boundary=tboundary, write_steps=0))]:
+        tt, tr, fm = integrate_runge_kutta_tgls(fL84, DfL84, 0., 2., 0.01, ic=ic, **kw)
+        out['tg_%s_time' % tag], out['tg_%s_traj' % tag], out['tg_%s_fm' % tag] = np.asarray(tt), tr, fm
+    # the classes, as in the usage example: dimension discovered by probing, results fed back as initial conditions
+    integ = RungeKuttaIntegrator(num_threads=2)
+    integ.set_func(fL84)
+    integ.integrate(0., 5., 0.01, write_steps=0)
+    tt, tr0 = integ.get_trajectories()
+    out['cls_spinup_time'], out['cls_spinup_traj'] = np.asarray(tt), tr0
+    integ.integrate(0., 2., 0.01, ic=tr0, write_steps=10)
+    tt, tr1 = integ.get_trajectories()
+    out['cls_fw_time'], out['cls_fw_traj'] = np.asarray(tt), tr1
+    integ.integrate(0., 2., 0.01, ic=tr1[:, -1], write_steps=10, forward=False)
+    tt, tr2 = integ.get_trajectories()
+    out['cls_bw_time'], out['cls_bw_traj'] = np.asarray(tt), tr2
+    integ.terminate()
+    tgls = RungeKuttaTglsIntegrator(num_threads=2)
+    tgls.set_func(fL84, DfL84)
+    tgls.initialize(1., 0.01, ic=ic)
+    out['cls_tg_ic'] = np.asarray(tgls.get_ic())
+    tgls.integrate(0., 2., 0.01, write_steps=10, tg_ic=np.zeros(3), boundary=tboundary)
+    tt, x, fm = tgls.get_trajectories()
+    out['cls_tg_time'], out['cls_tg_traj'], out['cls_tg_fm'] = np.asarray(tt), x, fm
+    tgls.terminate()
+    # tensor tendencies (RP-20) with a boundary term: the mixed path (tendencies on the device, boundary on the host)
+    p = params_rp20()
+    f, Df = create_tendencies(p)
+    ic2 = np.random.RandomState(13).rand(3, p.ndim) * 0.1
+    out['rp20_ic'] = ic2
+    tt, tr, fm = integrate_runge_kutta_tgls(f, Df, 0., 1., 0.1, ic=ic2, boundary=rp20_boundary, write_steps=2)
+    out['rp20_bnd_time'], out['rp20_bnd_traj'], out['rp20_bnd_fm'] = np.asarray(tt), tr, fm
+    tg1 = np.random.RandomState(14).randn(p.ndim)
+    out['rp20_tg1'] = tg1
+    tt, tr, fm = integrate_runge_kutta_tgls(f, Df, 0., 1., 0.1, ic=ic2, tg_ic=tg1, boundary=rp20_boundary, adjoint=True, write_steps=0)
+    out['rp20_bnd_adj_time'], out['rp20_bnd_adj_traj'], out['rp20_bnd_adj_fm'] = np.asarray(tt), tr, fm
+    path = os.path.join(HERE, 'callables.npz')
+    np.savez_compressed(path, **out)
+    print('[callables] wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.), flush=True)
+
+
 def copy_ref_data():
     """gzip copies of the reference tests' own DATA files (model_test/*.ref)."""
     dst = os.path.join(HERE, 'ref')
@@ -424,7 +510,7 @@ def copy_ref_data():
 
 
 if __name__ == '__main__':
-    names = sys.argv[1:] or (list(CONFIGS) + ['lyap'])
+    names = sys.argv[1:] or (list(CONFIGS) + ['lyap', 'callables'])
     copy_ref_data()
     for nm in names:
         if nm == 'lyap':
@@ -432,5 +518,7 @@ if __name__ == '__main__':
             gen_lyapunov('m36')
         elif nm.startswith('lyap_'):
             gen_lyapunov(nm[5:])
+        elif nm == 'callables':
+            gen_callables()
         else:
             gen(nm)

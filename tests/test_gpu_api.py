@@ -1,11 +1,12 @@
 """GPU: the drop-in Python API (create_tendencies objects, functional integrators, integrator classes)
 against API-level goldens captured from the reference (shapes, time axes, squeezing, tg_ic conventions)."""
+import os
 import pickle
 
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import GOLDEN_DIR, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -125,11 +126,28 @@ def test_initialize_draw_order_and_resume(setup):
     assert rel_err(two, whole) < 1e-13
 
 
-def test_plain_python_callable_is_rejected_loudly():
-    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
-    integ = RungeKuttaIntegrator(num_threads=1)
-    with pytest.raises(TypeError):
-        integ.set_func(lambda t, x: -x)
+def test_tensor_tendencies_with_a_boundary_callable():
+    """`boundary=` on tendencies from create_tendencies (integrate.py:600-603): the stage combination runs on the host, f and Df
+    are still the HIP kernels (called with the whole ensemble); against the reference's output for the same call."""
+    from callables_l84 import rp20_boundary
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.integrators.integrate import integrate_runge_kutta_tgls
+    from qgs_amd.integrators.integrator import RungeKuttaTglsIntegrator
+    gold = np.load(os.path.join(GOLDEN_DIR, 'callables.npz'))
+    g = load_golden('rp20')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    tt, tr, fm = integrate_runge_kutta_tgls(f, Df, 0., 1., 0.1, ic=gold['rp20_ic'], boundary=rp20_boundary, write_steps=2)
+    assert np.array_equal(tt, gold['rp20_bnd_time'])
+    assert rel_err(tr, gold['rp20_bnd_traj']) < 1e-12 and rel_err(fm, gold['rp20_bnd_fm']) < 1e-11
+    integ = RungeKuttaTglsIntegrator(num_threads=1)
+    integ.set_func(f, Df)
+    integ.integrate(0., 1., 0.1, ic=gold['rp20_ic'], tg_ic=gold['rp20_tg1'], boundary=rp20_boundary, adjoint=True, write_steps=0)
+    tt, tr, fm = integ.get_trajectories()
+    assert tt == float(gold['rp20_bnd_adj_time'])
+    assert rel_err(tr, gold['rp20_bnd_adj_traj']) < 1e-12 and rel_err(fm, gold['rp20_bnd_adj_fm']) < 1e-11
+    # boundary=None stays on the device
+    integ.integrate(0., 1., 0.1, ic=gold['rp20_ic'], write_steps=0)
+    assert integ._model.last_kernel_info()['name'] != ''
 
 
 def test_trajectories_statistics(setup):
