@@ -141,6 +141,27 @@ def cpu_info():
     return model, max(1, physical), logical
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, p = f.read().split()[:2]
+        if q != 'max':
+            return float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f:
+            q = float(f.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+            p = float(f.read())
+        if q > 0:
+            return q / p
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(ndim, coo, val, rk_steps, dt, seconds_1=5.0, seconds_all=12.0):
     """Time the C restatement of the reference's loops on this host: same COO loop order, built HERE with
     -O3 -march=native (FMA allowed) -- a performance build next to the -O2 -ffp-contract=off parity build."""
@@ -150,6 +171,10 @@ def cpu_baseline(ndim, coo, val, rk_steps, dt, seconds_1=5.0, seconds_all=12.0):
     except Exception:
         have_numba = False
     model_name, physical, logical = cpu_info()
+    quota = cgroup_cpu_quota()
+    physical_all = physical
+    if quota is not None:                                 # more threads than the container's CPU quota only fight each other
+        physical = max(1, min(physical, int(quota)))
     os.environ.setdefault('OMP_PLACES', 'cores')          # one thread per physical core for the all-cores figure
     os.environ.setdefault('OMP_PROC_BIND', 'spread')
     from oracle.oracle import OracleModel
@@ -181,14 +206,23 @@ def cpu_baseline(ndim, coo, val, rk_steps, dt, seconds_1=5.0, seconds_all=12.0):
     n_all = max(physical, n_all // physical * physical)
     el_all, ic, out = timed(n_all, physical)
     rate_all = n_all * rk_steps / el_all
+    # thread scaling in between (bounded samples), so that the all-cores figure can be judged
+    scaling = {1: rate1}
+    for th in (4, 16, 64):
+        if th < physical:
+            n_th = max(th, int(rate1 * th * 2.0 / rk_steps) // th * th)
+            el_th, _, _ = timed(n_th, th)
+            scaling[th] = n_th * rk_steps / el_th
+    scaling[physical] = rate_all
     # the performance build must still be the same algorithm: check it against the parity build
     ns = min(16, n_all)
     ref = parity.integrate_runge_kutta_jit(tg, ic[:ns], 1, 0, b, c, a, threads=min(ns, physical))
     dev = float(np.abs(out[:ns] - ref).max() / np.abs(ref).max())
     return {'value': rate_all, 'unit': 'traj-steps/s', 'cores': physical, 'kind': 'port',
-            'sample': '%d members x %d RK4 steps of the same MAOOAM-36 workload on %d threads (one per physical core), %.1f s wall; '
+            'sample': '%d members x %d RK4 steps of the same MAOOAM-36 workload on %d threads (one per physical core, capped by the container CPU quota), %.1f s wall; '
                       '1 thread: %d members, %.1f s' % (n_all, rk_steps, physical, el_all, n1, el1),
-            'cpu': model_name, 'logical_cpus': logical, 'one_thread': rate1, 'per_core': rate_all / physical,
+            'cpu': model_name, 'physical_cores': physical_all, 'logical_cpus': logical, 'cgroup_cpu_quota': quota,
+            'one_thread': rate1, 'per_core': rate_all / physical, 'rate_by_threads': {str(k): v for k, v in scaling.items()},
             'build': 'oracle/qgs_oracle.c, gcc -O3 -march=native -fopenmp (FMA contraction allowed)' if flavour == 'fast'
                      else 'oracle/qgs_oracle.c, gcc -O2 -ffp-contract=off (parity build)',
             'fast_vs_parity_build_rel_diff': dev, 'numba_importable': have_numba,
