@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
+#include <iterator>
 #include <map>
 #include <sstream>
 
@@ -33,6 +34,8 @@ struct KTable {
 };
 thread_local KTable *g_ktab = nullptr;
 thread_local bool g_asm_lit = false;
+thread_local int g_lit_mix = 0;            // > 0: every g_lit_mix-th tabulated coefficient becomes an s_mov literal pair instead (two supply paths)
+thread_local long g_lit_count = 0;
 thread_local bool g_ktab_samelines = false;   // timing experiment (lds_debug & 4): every group fetches table lines 0 / 1 (always hits)
 thread_local bool g_kdpp = false;         // coefficient statements as QGS_KFMA(acc, @K..@, factor): lane-broadcast operands (resolve_ktab group 64)      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
 
@@ -47,6 +50,13 @@ std::string lit(double v)
         return std::string(buf);
     }
     if (!g_ktab) return hexlit(v);
+    if (g_lit_mix > 0 && (++g_lit_count % g_lit_mix) == 0) {
+        unsigned long long u;
+        std::memcpy(&u, &v, sizeof u);
+        char buf[64];
+        std::snprintf(buf, sizeof buf, "QGS_LIT(0x%08x, 0x%08x)", (unsigned)(u >> 32), (unsigned)(u & 0xffffffffu));
+        return std::string(buf);
+    }
     return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
 }
 
@@ -254,6 +264,160 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
             if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
         }
         pos = eol + 1;
+    }
+    return out;
+}
+
+// Phase-aligned coefficient segments for the LDS-resident kernels (emit_lds_phases with markers).
+//
+// What bounded those kernels was not the amount of scalar-cache traffic but WHERE the waits fall.  SMEM returns out of
+// order, so every wait on the LGKM counter is lgkmcnt(0) -- and the LDS reads at the head of a phase count on the same
+// counter: with free-running groups of 16 coefficients a phase head found a coefficient load that had just been issued and
+// sat through a full scalar-cache miss (measured at ndim 228: 41.6 ms without the coefficient stream, 45.8 ms when every load
+// hits, 52.1 ms as shipped).  Here the stream is cut into segments of <= seg_max coefficients that never straddle a phase,
+// and everything a segment needs is requested one segment ahead, in one place:
+//     <first coefficient statement of segment s>        <- the only wait: covers SMEM(s) and, if s opens a phase, its LDS reads
+//     SMEM loads of segment s+1;  LDS reads of the next phase when s is the last segment of its phase     (pinned)
+//     <rest of segment s>
+// The text is the output of emit_lds_phases: "//@LOADS p" ... "//@ENDLOADS" bracket the LDS reads of phase p.
+std::string resolve_ktab_phased(const std::string &text, KTable &t, bool dedupe, int seg_max)
+{
+    struct Ph { std::vector<std::string> loads, stmts; };
+    std::vector<Ph> phs;
+    std::vector<std::string> preamble;
+    {
+        bool in_loads = false;
+        size_t pos = 0;
+        while (pos < text.size()) {
+            size_t eol = text.find('\n', pos);
+            if (eol == std::string::npos) eol = text.size();
+            const std::string line = text.substr(pos, eol - pos);
+            pos = eol + 1;
+            if (line.compare(0, 8, "//@LOADS") == 0) { phs.emplace_back(); in_loads = true; continue; }
+            if (line.compare(0, 11, "//@ENDLOADS") == 0) { in_loads = false; continue; }
+            if (phs.empty()) preamble.push_back(line);
+            else (in_loads ? phs.back().loads : phs.back().stmts).push_back(line);
+        }
+    }
+    if (phs.empty()) phs.emplace_back();
+    phs[0].stmts.insert(phs[0].stmts.begin(), preamble.begin(), preamble.end());
+    auto coef_values = [](const std::string &line) {
+        std::vector<double> v;
+        for (size_t a = line.find("@K"); a != std::string::npos;) {
+            const size_t b = line.find('@', a + 2);
+            v.push_back(std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr));
+            a = line.find("@K", b + 1);
+        }
+        return v;
+    };
+    // ---- segmentation: per phase, statements -> segments of at most `limit` table slots (balanced over the phase)
+    struct Seg { int phase; size_t first, last; std::vector<double> slots; bool last_of_phase = false; };   // statements [first, last)
+    std::vector<Seg> segs;
+    for (size_t p = 0; p < phs.size(); ++p) {
+        auto cut = [&](int limit, std::vector<Seg> *out) {
+            Seg cur{(int)p, 0, 0, {}};
+            size_t n_seg = 0;
+            for (size_t i = 0; i < phs[p].stmts.size(); ++i) {
+                std::vector<double> need;
+                for (double v : coef_values(phs[p].stmts[i])) {
+                    bool have = false;
+                    if (dedupe && v != 0.0) {
+                        for (double q : cur.slots) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
+                        for (double q : need) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
+                    }
+                    if (!have) need.push_back(v);
+                }
+                if (!cur.slots.empty() && (int)(cur.slots.size() + need.size()) > limit) {      // close the segment in front of this statement
+                    cur.last = i;
+                    if (out) out->push_back(cur);
+                    ++n_seg;
+                    cur = Seg{(int)p, i, i, {}};
+                    need.clear();
+                    for (double v : coef_values(phs[p].stmts[i])) {
+                        bool have = false;
+                        if (dedupe && v != 0.0) for (double q : need) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
+                        if (!have) need.push_back(v);
+                    }
+                }
+                cur.slots.insert(cur.slots.end(), need.begin(), need.end());
+            }
+            cur.last = phs[p].stmts.size();
+            cur.last_of_phase = true;
+            if (out) out->push_back(cur);
+            (void)n_seg;
+        };
+        size_t total = 0;
+        {
+            std::vector<Seg> tmp;
+            cut(1 << 30, &tmp);
+            total = tmp.empty() ? 0 : tmp[0].slots.size();
+        }
+        const size_t n_seg = std::max<size_t>(1, (total + seg_max - 1) / seg_max);
+        int limit = (int)std::min<size_t>((size_t)seg_max, (total + n_seg - 1) / n_seg + 1);
+        limit = std::max(limit, 2);
+        cut(limit, &segs);
+    }
+    // ---- table slots (the same sequence in every stage: the table is filled by the first call, checked by the others)
+    t.cursor = 0;
+    std::vector<size_t> base(segs.size(), 0);
+    for (size_t q = 0; q < segs.size(); ++q) {
+        base[q] = t.cursor;
+        for (double v : segs[q].slots) {
+            if (t.cursor == t.vals.size()) t.vals.push_back(v);
+            ++t.cursor;
+        }
+    }
+    t.pad_to = std::max(t.pad_to, t.cursor + 16);          // the last segments' vector loads may read past the end
+    const char *ind = "                ";
+    auto smem = [&](size_t q) {
+        std::string l;
+        if (q >= segs.size()) return l;
+        for (size_t b = 0; b * 8 < segs[q].slots.size(); ++b)
+            l += std::string(ind) + "const v8d ks" + std::to_string(q) + "_" + std::to_string(b) + " = *(const kv8u*)(kt + " +
+                 std::to_string(base[q] + 8 * b) + ");\n";
+        return l;
+    };
+    auto lds = [&](size_t p) {
+        std::string l;
+        if (p >= phs.size()) return l;
+        for (const auto &x : phs[p].loads) l += x + "\n";
+        return l;
+    };
+    auto pinned = [&](const std::string &body) {
+        if (body.empty()) return std::string();
+        return std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + body + ind + "__builtin_amdgcn_sched_barrier(0);\n";
+    };
+    std::string out = pinned(lds(0) + smem(0));
+    for (size_t q = 0; q < segs.size(); ++q) {
+        const Seg &sg = segs[q];
+        bool issued = false;
+        const std::string ahead = smem(q + 1) + (sg.last_of_phase ? lds((size_t)sg.phase + 1) : std::string());
+        for (size_t i = sg.first; i < sg.last; ++i) {
+            const std::string &line = phs[sg.phase].stmts[i];
+            std::string res;
+            size_t lp = 0;
+            bool has_coef = false;
+            while (true) {
+                const size_t a = line.find("@K", lp);
+                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
+                const size_t b = line.find('@', a + 2);
+                res.append(line, lp, a - lp);
+                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
+                size_t n = sg.slots.size();
+                for (size_t k = 0; k < sg.slots.size(); ++k)
+                    if (sg.slots[k] == v || (dedupe && v != 0.0 && std::fabs(sg.slots[k]) == std::fabs(v))) { n = k; break; }
+                if (n == sg.slots.size()) res += hexlit(v);          // cannot happen
+                else {
+                    const std::string ref = "ks" + std::to_string(q) + "_" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]";
+                    res += (std::signbit(sg.slots[n]) == std::signbit(v)) ? ref : "(-" + ref + ")";
+                }
+                has_coef = true;
+                lp = b + 1;
+            }
+            out += res + "\n";
+            if (has_coef && !issued) { out += pinned(ahead); issued = true; }
+        }
+        if (!issued) out += pinned(ahead);                  // a segment without a coefficient statement (only an empty last phase)
     }
     return out;
 }
@@ -493,6 +657,7 @@ typedef const double __attribute__((address_space(1))) gf64;   // coefficient ta
 // acc += (+-)cv[lane n of every row of 16] * f  -- the coefficient is broadcast by the FMA's own DPP operand
 #define QGS_KFMA(acc, cv, n, sg, f) asm("v_fmac_f64_dpp %0, " sg "%1, %2 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"((f64)(f)))
 typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
+typedef const v8d __attribute__((address_space(4), aligned(8))) kv8u;    // segment loads start at any table entry
 #define QGS_WAVE 64
 // fp64 coefficient materialised by two s_mov_b32 right where it is used: the instruction stream (sequentially
 // prefetched) carries the tensor, no scalar-cache traffic, and the compiler can neither hoist nor merge the constants
@@ -503,6 +668,14 @@ typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
 // Record bookkeeping shared by the steppers (reference integrate.py:190-223): record `iw` of the directed
 // run lands at index iw (forward) or n_records-1-iw (backward, the [::-1] of :223).
 const char *RECORD_HELPERS = R"(
+// 8-byte load through a buffer descriptor: address = base (SGPR descriptor) + soffset (SGPR) + voffset (VGPR), so per-row
+// address arithmetic stays on the scalar unit
+__device__ __forceinline__ f64 qgs_bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return __builtin_bit_cast(f64, r);
+}
 __device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward)
 {
     return backward ? (n_records - 1 - iw) : iw;
@@ -569,9 +742,13 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // y_i + dt a k_i).  Parked in LDS (ysh[mode][lane], 288 B per lane) after stage 0 it leaves three state arrays in
 // registers instead of four, which brings the kernel under 256 VGPRs = two wavefronts per SIMD (the LDS of a CU holds the
 // 8 x 18 KB).  Pays off when the ensemble offers more than one wavefront per SIMD (>= 131 072 members on an MI355X).
-// spread_rec: a record is not stored in one burst at the top of the step (36 x 512 B per wavefront, 18.9 MB for the
-// whole chip at 65 536 members, which the memory system needs 2.9 us to absorb while the step itself takes 4.6 us) but
-// row by row during stage 0: y_i goes out right after row i has been evaluated.
+// spread_rec (qgs_spec_rkr_s<S>, launched for write_steps == 1, the reference's default): EVERY step is a record, so
+// nothing about the record is conditional.  The burst version stores the 36 rows at the top of a step (36 x 512 B per
+// wavefront, 18.9 MB for the whole chip at 65 536 members, all wavefronts in lock step): the store queues fill and the
+// in-order wavefront sits behind them (measured 0.74 vs 0.61 ms per 100 steps).  y_i is constant for the whole step, so
+// here its store goes out somewhere in the step: row r right after its evaluation in stage (r - 1) mod S, one 512-byte
+// store every ~58 FMAs, addressed as scalar row pointer + lane offset (no 64-bit VALU address arithmetic).  Lanes past the
+// last member write their own padding column of the record (the buffer has ld >= 64 * gridDim.x columns per row).
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
                     const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool park_y = false,
                     bool spread_rec = false)
@@ -592,6 +769,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
     if (park_y) o << "    __shared__ f64 ysh[" << ndim << "][QGS_WAVE];\n    const int lane = threadIdx.x;\n";
+    if (spread_rec) o << "    const unsigned lane8 = threadIdx.x * 8u;\n";
     o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);   // tail lanes shadow the last member and never store\n";
@@ -604,10 +782,8 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
     o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
     o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
     if (spread_rec) {
-        o << "        const bool rec_now = (ti == next_rec);\n"
-          << "        f64* p = rec + m;\n"
-          << "        if (rec_now) { p += qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld; ++iw; next_rec += write_steps; }\n"
-          << "        const bool rec_lane = rec_now && live;\n";
+        // write_steps == 1: step ti is record ti; uniform (scalar) pointer to this workgroup's 64 columns of row 0
+        o << "        f64* const prow = rec + qgs_rec_index(ti, n_records, backward) * " << ndim << " * ld + (i64)blockIdx.x * QGS_WAVE;\n";
     } else {
         o << "        if (ti == next_rec) {\n"
           << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
@@ -653,7 +829,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
                     if (park_y && st > 0) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", ysh[" << (i - 1) << "][lane]);\n";
                     else ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
                 }
-                if (spread_rec && st == 0) ro << "            if (rec_lane) p[" << (i - 1) << " * ld] = y" << i << ";\n";
+                if (spread_rec && (i - 1) % S == st) ro << "            *(f64*)((char*)(prow + " << (i - 1) << " * ld) + lane8) = y" << i << ";\n";
                 lists.push_back(split_lines(ro.str()));
             }
             so << interleave(lists);
@@ -956,7 +1132,12 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
           << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
           << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
           << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
-          << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
+          << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n"
+          // the 64 lanes of a wavefront lie in one column (ld is a multiple of 64): the stage states are addressed as a uniform
+          // (scalar) row pointer + a 32-bit lane offset, so the 36 loads of a stage need no 64-bit VALU address arithmetic
+          << "    const i64 mbase = ((i64)blockIdx.x * QGS_WAVE) % ld;\n"
+          << "    const unsigned moff = (unsigned)(m - mbase) * 8u, ldb = (unsigned)ld * 8u;\n"
+          << "    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)stages, 0, 0x7fffffff, 0x00020000);\n";
     }
     o << "    " << decl_list("v", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
@@ -1013,8 +1194,17 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
             }
             for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = xsh[pb][" << (d - 1) << "][lane];\n";
         } else {
-            o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-            for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+            if (opt.tgl_buffer_loads) {
+                // buffer loads: base descriptor in SGPRs, row offset in an SGPR (SALU arithmetic), lane offset in one VGPR
+                o << "            const unsigned soff = (unsigned)((((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + mbase) * 8);\n";
+                // (running offset, opaque to the compiler: otherwise it keeps d * ldb for every d in loop-invariant SGPRs and spills them)
+                o << "            unsigned so = soff;\n";
+                for (int d = 1; d <= ndim; ++d)
+                    o << "            const f64 x" << d << " = qgs_bload(srs, moff, so); so += ldb; asm volatile(\"\" : \"+s\"(so));\n";
+            } else {
+                o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+                for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+            }
         }
         emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
@@ -1304,6 +1494,28 @@ std::vector<Phase> build_phases(int ndim, const std::vector<PTerm> &terms, int c
     return phases;
 }
 
+// The greedy above ends in a tail of phases with two or three modes each (the leftover edges): every one of them costs a
+// wait for its LDS reads with a handful of FMAs behind it.  Consecutive phases whose mode sets fit the register budget
+// together become one phase (the union is loaded at once; the terms stay the same).
+std::vector<Phase> merge_small_phases(std::vector<Phase> phases, int cap)
+{
+    std::vector<Phase> out;
+    for (Phase &ph : phases) {
+        if (!out.empty()) {
+            Phase &last = out.back();
+            std::vector<int> uni;
+            std::set_union(last.modes.begin(), last.modes.end(), ph.modes.begin(), ph.modes.end(), std::back_inserter(uni));
+            if ((int)uni.size() <= cap && (int)ph.modes.size() <= cap / 2) {
+                last.modes.swap(uni);
+                last.terms.insert(last.terms.end(), ph.terms.begin(), ph.terms.end());
+                continue;
+            }
+        }
+        out.push_back(std::move(ph));
+    }
+    return out;
+}
+
 // ---- shared machinery of the LDS-resident kernels (stepper and tangent model) --------------------------------------
 // Terms live in "node space": a node is one LDS-resident value (stepper: node m = mode m; tangent model: node j = w_j,
 // node ndim + k = x_k); a term is c * node_j * node_k accumulated into row `row`, j == 0 meaning a single factor.
@@ -1402,11 +1614,12 @@ std::vector<std::vector<int>> lds_partition(int n_rows, int n_nodes, const RowTe
 // `hook_phase` (== phases.size(): behind the last one).
 void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<Phase> &phases, const NodeFn &node,
                      const std::vector<std::string> &lane_vars, const std::string &lds_ptr, bool group, int hook_phase,
-                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st)
+                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st, bool markers = false)
 {
     int ph_id = 0, prod_id = 0;
     for (const Phase &ph : phases) {
         if (ph_id == hook_phase) hook(so);
+        if (markers) so << "//@LOADS " << ph_id << "\n";            // resolve_ktab_phased moves this block one segment ahead
         const std::string sfx = "_" + std::to_string(ph_id++);
         // Opaque lane offset per phase: otherwise the compiler merges the reads of one value in different phases and keeps
         // it in a register (or scratch) in between.  ds_read offsets are 16-bit immediates, so every 64 KB window of the
@@ -1427,6 +1640,7 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
             so << ind << "const f64 x" << mo << sfx << " = *(const f64*)(" << lds_ptr << " + " << (nd.offset & 65535) << " + "
                << bases[{nd.lane_kind, (int)(nd.offset >> 16)}] << ");\n";
         }
+        if (markers) so << "//@ENDLOADS\n";
         st.loads += (int64_t)ph.modes.size();
         ++st.phases;
         // Terms of one row with equal |coefficient| that fall into this phase are summed first
@@ -1622,6 +1836,8 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         const bool dpp = table && opt.lds_coeff_dpp && !(opt.lds_debug & 2);
         if (table) {
             g_ktab = &tables[w];
+            g_lit_mix = opt.lds_lit_mix;
+            g_lit_count = 0;
             g_kdpp = dpp;
             if (dpp) o << I4 << "gf64* ktl = (gf64*)(kf64*)" << kname << "_kt" << w << " + (lane & 15); asm volatile(\"\" : \"+v\"(ktl));\n";
             else o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
@@ -1634,16 +1850,22 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
             else so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        const std::vector<Phase> phases = build_phases(nnode, terms, cap);
+        std::vector<Phase> phases = build_phases(nnode, terms, cap);
+        if (opt.lds_merge_phases) phases = merge_small_phases(phases, cap);
+        // one wait per coefficient segment, LDS reads requested a segment ahead (resolve_ktab_phased)
+        const bool pipe = table && opt.lds_pipeline && !dpp && !(opt.lds_debug & 6);
         // step-start state of the own rows, consumed at the end of the stage
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
-                        }, stats);
+                        }, stats, pipe);
         g_ktab_samelines = (opt.lds_debug & 4) != 0;
+        if (pipe) o << resolve_ktab_phased(so.str(), tables[w], opt.lds_coeff_dedupe, opt.lds_segment);
+        else
         o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : (dpp ? 64 + opt.lds_dpp_ahead : opt.ktab_group), opt.lds_coeff_dedupe) : so.str());
         g_ktab_samelines = false;
+        g_lit_mix = 0;
         g_ktab = nullptr;
         g_kdpp = false;
         g_asm_lit = false;
@@ -1797,12 +2019,16 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
             so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        const std::vector<Phase> phases = build_phases(ndim + nx, terms, cap);
+        std::vector<Phase> phases = build_phases(ndim + nx, terms, cap);
+        if (opt.lds_merge_phases) phases = merge_small_phases(phases, cap);
+        const bool pipe = table && opt.lds_pipeline;
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8", "xl8"}, "(const char*)lds_all", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = vw[yoff + " << (d - 1) * 64 << "];\n";
-                        }, stats);
+                        }, stats, pipe);
+        if (pipe) o << resolve_ktab_phased(so.str(), tables[w], opt.lds_coeff_dedupe, opt.lds_segment);
+        else
         o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
         g_ktab = nullptr;
         g_asm_lit = false;

@@ -30,14 +30,16 @@ struct CodegenOptions {
     bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
     int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
     bool rk_coeff_dedupe = false;  // register-resident stepper: ditto (measured neutral with the system hiprtc build: 4.78 vs 4.78 ms; off)
-    int tgl_interleave = 1;    // tangent kernel: rows whose statements are emitted round-robin
-    bool tgl_park_v = false;   // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
+    bool tgl_buffer_loads = false; // tangent kernel: stage states through buffer loads (descriptor + SGPR row offset + VGPR lane offset): the
+                               // per-row 64-bit address arithmetic moves from the VALU to the scalar unit
+    int tgl_interleave = 2;    // tangent kernel: rows whose statements are emitted round-robin (config 4, 100 calls: 0.949 -> 0.933 ms with park_v)
+    bool tgl_park_v = true;    // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
     bool tgl_coeff_dedupe = true;  // tangent kernel: same de-duplication of coefficient fetches as lds_coeff_dedupe (config 4: 1.24 -> 1.20 ms)
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
     bool nt_record = false;    // plain stepper: non-temporal stores for the records
-    bool rk_spread_rec = false; // also emit qgs_spec_rkr_s<S>: records stored row by row during stage 0 instead of in one burst
-                               // (measured: 1.04 ms instead of 0.66-0.76 ms for 65 536 members x 100 records -- slower, off)
+    bool rk_spread_rec = true; // also emit qgs_spec_rkr_s<S> for write_steps == 1 (every step is a record): the 36 row stores of a step are
+                               // spread over its stages, unconditional, scalar row pointer + lane offset (codegen.cpp emit_rk_kernel)
     bool rk_park_y = false;    // also emit qgs_spec_rkp_s<S>: step-start state parked in LDS, 216 VGPRs, 2 wavefronts per SIMD
                                // (measured: no gain -- 9.8 vs 9.0 ms at 131 072 members, equal at 1 048 576: the lone wavefront
                                // already keeps the fp64 pipe 91 % busy)
@@ -53,6 +55,11 @@ struct CodegenOptions {
                                  // 228 (the inline-asm FMAs cost 8 more VGPRs -> more spills, and run at 90 % of the plain rate)
     int lds_dpp_ahead = 3;       // ... groups of 16 coefficients requested ahead of the one being consumed (2 VGPRs each)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
+    bool lds_pipeline = false;  // ... coefficient segments aligned with the phases, the next segment's coefficients and the next phase's
+                               //     LDS reads requested one segment ahead: one wait per segment (codegen.cpp resolve_ktab_phased)
+    int lds_segment = 16;      // ... coefficients per segment (two 8-double SGPR vectors, double-buffered)
+    bool lds_merge_phases = false; // ... consecutive small phases whose mode sets fit the factor cache together become one
+    int lds_lit_mix = 0;       // ... > 0: every n-th coefficient is an s_mov literal pair in the instruction stream instead of a table entry
     int lds_debug = 0;         // timing experiments only (WRONG results): 1 = no barriers in the stage loop, 2 = every coefficient
                                // is table entry 0 (no coefficient stream)
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read

@@ -719,10 +719,15 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) cg.lds_debug = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_PIPE")) cg.lds_pipeline = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_LITMIX")) cg.lds_lit_mix = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_SEGMENT")) cg.lds_segment = std::max(4, std::min(16, std::atoi(e)));
+    if (const char *e = std::getenv("QGS_HIP_LDS_MERGE")) cg.lds_merge_phases = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_DEDUPE")) cg.lds_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_DPP")) cg.lds_coeff_dpp = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_DPP_AHEAD")) cg.lds_dpp_ahead = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_TGL_DEDUPE")) cg.tgl_coeff_dedupe = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_TGL_BLOAD")) cg.tgl_buffer_loads = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK_V")) cg.tgl_park_v = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_INTERLEAVE")) cg.tgl_interleave = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_RK_DEDUPE")) cg.rk_coeff_dedupe = (*e == '1');
@@ -1203,9 +1208,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
             if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) { split = true; park = false; }
             if (!std::strcmp(e, "park") && s > 1 && m->der.t.empty()) { park = true; split = false; }
         }
-        // dense records (a record at least every 8th step): the variant that spreads the record stores over stage 0
-        bool spread = !split && !park && m->cg.rk_spread_rec && write_steps > 0 && write_steps <= 8;
-        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) spread = (*e == '1') && !split && !park && write_steps > 0;
+        // every step is a record (write_steps == 1, the reference's default): the variant with the record stores spread over the step
+        bool spread = !split && !park && m->cg.rk_spread_rec && write_steps == 1 && ld >= 64 * waves;
+        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) spread = spread && (*e == '1');
         hipFunction_t f;
         std::string name;
         if (get_function(m, split ? qgs::Kernel::RkSplit : (park ? qgs::Kernel::RkPark : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk)), s,

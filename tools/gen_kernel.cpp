@@ -30,16 +30,23 @@ int main(int argc, char **argv)
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) opt.lds_group = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) opt.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) opt.ktab_group = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_PIPE")) opt.lds_pipeline = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_LITMIX")) opt.lds_lit_mix = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) opt.lds_debug = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_SEGMENT")) opt.lds_segment = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_MERGE")) opt.lds_merge_phases = (*e == '1');
     const int S = argc > 3 ? std::atoi(argv[3]) : 4;
     qgs::Kernel k = qgs::Kernel::Tend;
     if (!std::strcmp(argv[2], "rk")) k = qgs::Kernel::Rk;
     else if (!std::strcmp(argv[2], "rksplit")) k = qgs::Kernel::RkSplit;
     else if (!std::strcmp(argv[2], "rkstages")) k = qgs::Kernel::RkStages;
+    else if (!std::strcmp(argv[2], "rkrec")) k = qgs::Kernel::RkRec;
+    else if (!std::strcmp(argv[2], "tgl")) k = qgs::Kernel::Tgl;
     else if (!std::strcmp(argv[2], "rklds")) k = qgs::Kernel::RkLds;
     else if (!std::strcmp(argv[2], "tgllds")) k = qgs::Kernel::TglLds;
     else if (!std::strcmp(argv[2], "adjlds")) k = qgs::Kernel::AdjLds;
     std::vector<qgs::Term> J;                       // Jacobian tensor = T + T.swapaxes(1, 2) (qgtensor.py:700-722)
-    if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds)
+    if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds || k == qgs::Kernel::Tgl)
         for (const qgs::Term &t : T) { J.push_back(t); J.push_back({t.i, t.k, t.j, t.v}); }
     std::cout << qgs::generate_kernel(ndim, T, J, k, S, opt);
     return 0;
