@@ -66,7 +66,7 @@ def test_prebuild_generates_code_objects(tmp_path, monkeypatch):
     jval = np.array([-0.5, 2.0, 2.0, -2.0])
     _lib.prebuild(2, coo, val, jcoo, jval, stage_counts=(2,))
     objs = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
-    assert len(objs) == 6          # one code object per kernel: f, Df, rk_s2, rkstages_s2, tgl_s2, tglx4_s2 (2 rows: no split)
+    assert len(objs) == 7          # one code object per kernel: f, Df, rk_s2, rkr_s2 (write_steps = 1), rkstages_s2, tgl_s2, tglx4_s2 (2 rows: no split)
     assert all(os.path.getsize(os.path.join(tmp_path, f)) > 1000 for f in objs)
 
 
