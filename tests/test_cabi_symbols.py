@@ -90,7 +90,7 @@ def test_prebuild_shards_cover_every_code_object(tmp_path):
         env = dict(os.environ, QGS_HIP_CACHE_DIR=str(d), QGS_HIP_PREBUILD_SHARD='%d/2' % i, QGS_HIP_NO_TORCH_PRELOAD='1')
         subprocess.check_call([sys.executable, '-c', code], env=env)
         seen.append(sorted(f for f in os.listdir(d) if f.endswith('.hsaco')))
-    assert len(seen[0]) == 3 and len(seen[1]) == 3
+    assert len(seen[0]) + len(seen[1]) == 7 and abs(len(seen[0]) - len(seen[1])) == 1
     assert not set(seen[0]) & set(seen[1])
 
 
