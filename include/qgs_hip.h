@@ -115,6 +115,14 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
                              int time_direction, int64_t write_steps, int s, const double *b, const double *c,
                              const double *a, double *mean, double *var, double *final_states);
 
+/* Page-lock (and later release) a caller-owned host block that receives large results, so that the device-to-host copies
+ * of the host-layout entry points run at the pinned PCIe rate (measured 57 instead of 50 GB/s for a 1.9 GB record, and
+ * without first-touch page faults inside the copy).  Optional: every entry point also accepts pageable memory.  The Python
+ * binding registers its recycled result blocks (qgs_amd/_lib.py _ResultPool).  Replaces nothing in the reference: its
+ * results travel between processes through pickling queues (qgs/integrators/integrator.py:388-395). */
+int qgs_host_register(void *ptr, int64_t bytes);
+int qgs_host_unregister(void *ptr);
+
 /* ---- device-layout entry points (pointers are device pointers on the model's device; the work
  *      is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT synchronised) ------ */
 

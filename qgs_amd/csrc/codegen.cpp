@@ -9,7 +9,6 @@
 #include <cstdio>
 #include <cstring>
 #include <functional>
-#include <iterator>
 #include <map>
 #include <sstream>
 
@@ -33,37 +32,16 @@ struct KTable {
     size_t pad_to = 0;      // group-64 mode: the run-ahead loads may touch this many entries
 };
 thread_local KTable *g_ktab = nullptr;
-thread_local bool g_asm_lit = false;
-thread_local int g_lit_mix = 0;            // > 0: every g_lit_mix-th tabulated coefficient becomes an s_mov literal pair instead (two supply paths)
-thread_local long g_lit_count = 0;
-thread_local bool g_ktab_samelines = false;   // timing experiment (lds_debug & 4): every group fetches table lines 0 / 1 (always hits)
-thread_local bool g_kdpp = false;         // coefficient statements as QGS_KFMA(acc, @K..@, factor): lane-broadcast operands (resolve_ktab group 64)      // coefficients as s_mov literals the compiler cannot hoist or merge (QGS_LIT)
 
 std::string lit(double v)
 {
-    if (g_asm_lit) {
-        unsigned long long u;
-        static_assert(sizeof u == sizeof v, "");
-        std::memcpy(&u, &v, sizeof u);
-        char buf[64];
-        std::snprintf(buf, sizeof buf, "QGS_LIT(0x%08x, 0x%08x)", (unsigned)(u >> 32), (unsigned)(u & 0xffffffffu));
-        return std::string(buf);
-    }
     if (!g_ktab) return hexlit(v);
-    if (g_lit_mix > 0 && (++g_lit_count % g_lit_mix) == 0) {
-        unsigned long long u;
-        std::memcpy(&u, &v, sizeof u);
-        char buf[64];
-        std::snprintf(buf, sizeof buf, "QGS_LIT(0x%08x, 0x%08x)", (unsigned)(u >> 32), (unsigned)(u & 0xffffffffu));
-        return std::string(buf);
-    }
     return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
 }
 
 // acc = fma(c, factor, acc) with a tabulated coefficient c
 std::string coef_fma(const std::string &acc, double c, const std::string &factor)
 {
-    if (g_kdpp && g_ktab) return "QGS_KFMA(" + acc + ", " + lit(c) + ", " + factor + ");";
     return acc + " = __builtin_fma(" + lit(c) + ", " + factor + ", " + acc + ");";
 }
 
@@ -89,109 +67,6 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
         *ok = (t.vals[t.cursor] == v);        // always true: every stage emits the same sequence
         return t.cursor++;
     };
-    if (group == 8) {
-        // block-granular pipeline: the load of block b+3 is issued right after the first statement that uses block b
-        // (four 8-double blocks live = 64 SGPRs, as in the group-of-16 scheme, but 24 coefficients of run-ahead
-        // instead of 16)
-        const int D = 3;
-        size_t total = 0;
-        for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
-        const size_t nblocks = (total + 7) / 8;
-        const char *ind = "                ";
-        auto load_block = [&](size_t b) {
-            if (b >= nblocks) return std::string();
-            return std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
-        };
-        for (int b = 0; b < D; ++b) out += load_block((size_t)b);
-        long opened = -1;
-        size_t pos = 0;
-        while (pos < text.size()) {
-            size_t eol = text.find('\n', pos);
-            if (eol == std::string::npos) eol = text.size();
-            std::string line = text.substr(pos, eol - pos), res;
-            long last_block = -1;
-            size_t lp = 0;
-            while (true) {
-                size_t a = line.find("@K", lp);
-                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
-                size_t b = line.find('@', a + 2);
-                res.append(line, lp, a - lp);
-                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
-                bool ok;
-                const size_t n = next_ref(v, &ok);
-                res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
-                last_block = (long)(n / 8);
-                lp = b + 1;
-            }
-            out += res + "\n";
-            if (last_block > opened) {
-                std::string l;
-                for (long b = opened + 1; b <= last_block; ++b) l += load_block((size_t)(b + D));
-                opened = last_block;
-                if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
-            }
-            pos = eol + 1;
-        }
-        return out;
-    }
-    if (group >= 64) {
-        // Lane-broadcast operands (LDS-resident kernels).  The scalar cache cannot keep up with ~2 000 lines of
-        // coefficients per workgroup and stage (a quarter of the run time at ndim 228).  Here 16 consecutive coefficients are
-        // fetched by ONE vector load -- lane l reads entry 16 g + (l & 15), so every row of 16 lanes holds the whole group --
-        // and `v_fmac_f64_dpp ... row_newbcast:n` hands entry n to all lanes as the multiplier of the FMA itself (no extra
-        // instruction; measured at 90 % of the plain FMA rate, tools/ubench/dpp_fmac.hip).  A group costs 2 VGPRs, the loads
-        // run D groups ahead; `ktl` = table + (lane & 15).  Same de-duplication inside the group as below.
-        const int D = std::max(1, group - 64);
-        size_t total = 0;
-        for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
-        const char *ind = "                ";
-        // upper bound of the number of groups (de-duplication only lowers it); a load beyond the table's end reads padding
-        const size_t ngroups_max = (total + 15) / 16;
-        t.pad_to = std::max(t.pad_to, 16 * ngroups_max);
-        auto load_group = [&](size_t g) {
-            if (g >= ngroups_max) return std::string();
-            return std::string(ind) + "const f64 cv" + std::to_string(g) + " = ktl[" + std::to_string(16 * g) + "];\n";
-        };
-        for (int g = 0; g < D; ++g) out += load_group((size_t)g);
-        long opened = -1;
-        size_t pos = 0;
-        while (pos < text.size()) {
-            size_t eol = text.find('\n', pos);
-            if (eol == std::string::npos) eol = text.size();
-            std::string line = text.substr(pos, eol - pos), res;
-            long first_group = -1;
-            size_t lp = 0;
-            while (true) {
-                size_t a = line.find("@K", lp);
-                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
-                size_t b = line.find('@', a + 2);
-                res.append(line, lp, a - lp);
-                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
-                bool ok = true, reused = false;
-                size_t n = 0;
-                if (dedupe && t.cursor > 0) {
-                    const size_t g0 = (t.cursor - 1) / 16 * 16;
-                    for (size_t q = t.cursor; q-- > g0;)
-                        if (std::fabs(t.vals[q]) == std::fabs(v) && v != 0.0) { n = q; reused = true; break; }
-                }
-                if (!reused) n = next_ref(v, &ok);
-                const bool neg = std::signbit(t.vals[n]) != std::signbit(v);
-                res += "cv" + std::to_string(n / 16) + ", " + std::to_string(n % 16) + (neg ? ", \"-\"" : ", \"\"");
-                (void)ok;
-                if (first_group < 0) first_group = (long)(n / 16);
-                lp = b + 1;
-            }
-            out += res + "\n";
-            if (first_group > opened) {
-                std::string l;
-                for (long g = opened + 1; g <= first_group; ++g) l += load_group((size_t)(g + D));
-                opened = first_group;
-                if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
-            }
-            pos = eol + 1;
-        }
-        return out;
-    }
     if (group != 16) {
         size_t pos = 0;
         while (true) {
@@ -202,8 +77,7 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
             const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
             bool ok;
             const size_t n = next_ref(v, &ok);
-            if (group < 0) out += "kt[0]";                       // timing experiment: no coefficient stream
-            else out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
+            out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
             pos = b + 1;
         }
         return out;
@@ -214,13 +88,8 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
     const size_t nblocks = (total + 7) / 8;
     auto load_group = [&](size_t g, const char *ind) {
         std::string l;
-        for (size_t b = 2 * g; b < 2 * g + 2 && b < nblocks; ++b) {
-            if (g_ktab_samelines)          // opaque pointer per load: identical loads must not be merged
-                l += std::string(ind) + "kf64* kth" + std::to_string(b) + " = kt; asm volatile(\"\" : \"+s\"(kth" + std::to_string(b) + "));\n" +
-                     ind + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kth" + std::to_string(b) + " + " + std::to_string(8 * (b % 2)) + ");\n";
-            else
-                l += std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
-        }
+        for (size_t b = 2 * g; b < 2 * g + 2 && b < nblocks; ++b)
+            l += std::string(ind) + "const v8d kq" + std::to_string(b) + " = *(const kv8*)(kt + " + std::to_string(8 * b) + ");\n";
         return l;
     };
     const char *ind = "                ";
@@ -264,160 +133,6 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
             if (!l.empty()) out += std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + l + ind + "__builtin_amdgcn_sched_barrier(0);\n";
         }
         pos = eol + 1;
-    }
-    return out;
-}
-
-// Phase-aligned coefficient segments for the LDS-resident kernels (emit_lds_phases with markers).
-//
-// What bounded those kernels was not the amount of scalar-cache traffic but WHERE the waits fall.  SMEM returns out of
-// order, so every wait on the LGKM counter is lgkmcnt(0) -- and the LDS reads at the head of a phase count on the same
-// counter: with free-running groups of 16 coefficients a phase head found a coefficient load that had just been issued and
-// sat through a full scalar-cache miss (measured at ndim 228: 41.6 ms without the coefficient stream, 45.8 ms when every load
-// hits, 52.1 ms as shipped).  Here the stream is cut into segments of <= seg_max coefficients that never straddle a phase,
-// and everything a segment needs is requested one segment ahead, in one place:
-//     <first coefficient statement of segment s>        <- the only wait: covers SMEM(s) and, if s opens a phase, its LDS reads
-//     SMEM loads of segment s+1;  LDS reads of the next phase when s is the last segment of its phase     (pinned)
-//     <rest of segment s>
-// The text is the output of emit_lds_phases: "//@LOADS p" ... "//@ENDLOADS" bracket the LDS reads of phase p.
-std::string resolve_ktab_phased(const std::string &text, KTable &t, bool dedupe, int seg_max)
-{
-    struct Ph { std::vector<std::string> loads, stmts; };
-    std::vector<Ph> phs;
-    std::vector<std::string> preamble;
-    {
-        bool in_loads = false;
-        size_t pos = 0;
-        while (pos < text.size()) {
-            size_t eol = text.find('\n', pos);
-            if (eol == std::string::npos) eol = text.size();
-            const std::string line = text.substr(pos, eol - pos);
-            pos = eol + 1;
-            if (line.compare(0, 8, "//@LOADS") == 0) { phs.emplace_back(); in_loads = true; continue; }
-            if (line.compare(0, 11, "//@ENDLOADS") == 0) { in_loads = false; continue; }
-            if (phs.empty()) preamble.push_back(line);
-            else (in_loads ? phs.back().loads : phs.back().stmts).push_back(line);
-        }
-    }
-    if (phs.empty()) phs.emplace_back();
-    phs[0].stmts.insert(phs[0].stmts.begin(), preamble.begin(), preamble.end());
-    auto coef_values = [](const std::string &line) {
-        std::vector<double> v;
-        for (size_t a = line.find("@K"); a != std::string::npos;) {
-            const size_t b = line.find('@', a + 2);
-            v.push_back(std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr));
-            a = line.find("@K", b + 1);
-        }
-        return v;
-    };
-    // ---- segmentation: per phase, statements -> segments of at most `limit` table slots (balanced over the phase)
-    struct Seg { int phase; size_t first, last; std::vector<double> slots; bool last_of_phase = false; };   // statements [first, last)
-    std::vector<Seg> segs;
-    for (size_t p = 0; p < phs.size(); ++p) {
-        auto cut = [&](int limit, std::vector<Seg> *out) {
-            Seg cur{(int)p, 0, 0, {}};
-            size_t n_seg = 0;
-            for (size_t i = 0; i < phs[p].stmts.size(); ++i) {
-                std::vector<double> need;
-                for (double v : coef_values(phs[p].stmts[i])) {
-                    bool have = false;
-                    if (dedupe && v != 0.0) {
-                        for (double q : cur.slots) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
-                        for (double q : need) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
-                    }
-                    if (!have) need.push_back(v);
-                }
-                if (!cur.slots.empty() && (int)(cur.slots.size() + need.size()) > limit) {      // close the segment in front of this statement
-                    cur.last = i;
-                    if (out) out->push_back(cur);
-                    ++n_seg;
-                    cur = Seg{(int)p, i, i, {}};
-                    need.clear();
-                    for (double v : coef_values(phs[p].stmts[i])) {
-                        bool have = false;
-                        if (dedupe && v != 0.0) for (double q : need) if (std::fabs(q) == std::fabs(v)) { have = true; break; }
-                        if (!have) need.push_back(v);
-                    }
-                }
-                cur.slots.insert(cur.slots.end(), need.begin(), need.end());
-            }
-            cur.last = phs[p].stmts.size();
-            cur.last_of_phase = true;
-            if (out) out->push_back(cur);
-            (void)n_seg;
-        };
-        size_t total = 0;
-        {
-            std::vector<Seg> tmp;
-            cut(1 << 30, &tmp);
-            total = tmp.empty() ? 0 : tmp[0].slots.size();
-        }
-        const size_t n_seg = std::max<size_t>(1, (total + seg_max - 1) / seg_max);
-        int limit = (int)std::min<size_t>((size_t)seg_max, (total + n_seg - 1) / n_seg + 1);
-        limit = std::max(limit, 2);
-        cut(limit, &segs);
-    }
-    // ---- table slots (the same sequence in every stage: the table is filled by the first call, checked by the others)
-    t.cursor = 0;
-    std::vector<size_t> base(segs.size(), 0);
-    for (size_t q = 0; q < segs.size(); ++q) {
-        base[q] = t.cursor;
-        for (double v : segs[q].slots) {
-            if (t.cursor == t.vals.size()) t.vals.push_back(v);
-            ++t.cursor;
-        }
-    }
-    t.pad_to = std::max(t.pad_to, t.cursor + 16);          // the last segments' vector loads may read past the end
-    const char *ind = "                ";
-    auto smem = [&](size_t q) {
-        std::string l;
-        if (q >= segs.size()) return l;
-        for (size_t b = 0; b * 8 < segs[q].slots.size(); ++b)
-            l += std::string(ind) + "const v8d ks" + std::to_string(q) + "_" + std::to_string(b) + " = *(const kv8u*)(kt + " +
-                 std::to_string(base[q] + 8 * b) + ");\n";
-        return l;
-    };
-    auto lds = [&](size_t p) {
-        std::string l;
-        if (p >= phs.size()) return l;
-        for (const auto &x : phs[p].loads) l += x + "\n";
-        return l;
-    };
-    auto pinned = [&](const std::string &body) {
-        if (body.empty()) return std::string();
-        return std::string(ind) + "__builtin_amdgcn_sched_barrier(0);\n" + body + ind + "__builtin_amdgcn_sched_barrier(0);\n";
-    };
-    std::string out = pinned(lds(0) + smem(0));
-    for (size_t q = 0; q < segs.size(); ++q) {
-        const Seg &sg = segs[q];
-        bool issued = false;
-        const std::string ahead = smem(q + 1) + (sg.last_of_phase ? lds((size_t)sg.phase + 1) : std::string());
-        for (size_t i = sg.first; i < sg.last; ++i) {
-            const std::string &line = phs[sg.phase].stmts[i];
-            std::string res;
-            size_t lp = 0;
-            bool has_coef = false;
-            while (true) {
-                const size_t a = line.find("@K", lp);
-                if (a == std::string::npos) { res.append(line, lp, std::string::npos); break; }
-                const size_t b = line.find('@', a + 2);
-                res.append(line, lp, a - lp);
-                const double v = std::strtod(line.substr(a + 2, b - a - 2).c_str(), nullptr);
-                size_t n = sg.slots.size();
-                for (size_t k = 0; k < sg.slots.size(); ++k)
-                    if (sg.slots[k] == v || (dedupe && v != 0.0 && std::fabs(sg.slots[k]) == std::fabs(v))) { n = k; break; }
-                if (n == sg.slots.size()) res += hexlit(v);          // cannot happen
-                else {
-                    const std::string ref = "ks" + std::to_string(q) + "_" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]";
-                    res += (std::signbit(sg.slots[n]) == std::signbit(v)) ? ref : "(-" + ref + ")";
-                }
-                has_coef = true;
-                lp = b + 1;
-            }
-            out += res + "\n";
-            if (has_coef && !issued) { out += pinned(ahead); issued = true; }
-        }
-        if (!issued) out += pinned(ahead);                  // a segment without a coefficient statement (only an empty last phase)
     }
     return out;
 }
@@ -653,29 +368,13 @@ typedef double f64;
 typedef long long i64;
 typedef const double __attribute__((address_space(4))) kf64;   // coefficient tables: scalar (s_load) fetches
 typedef double v8d __attribute__((ext_vector_type(8)));
-typedef const double __attribute__((address_space(1))) gf64;   // coefficient tables read by vector loads (lane-broadcast operands)
-// acc += (+-)cv[lane n of every row of 16] * f  -- the coefficient is broadcast by the FMA's own DPP operand
-#define QGS_KFMA(acc, cv, n, sg, f) asm("v_fmac_f64_dpp %0, " sg "%1, %2 row_newbcast:" #n " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(cv), "v"((f64)(f)))
 typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
-typedef const v8d __attribute__((address_space(4), aligned(8))) kv8u;    // segment loads start at any table entry
 #define QGS_WAVE 64
-// fp64 coefficient materialised by two s_mov_b32 right where it is used: the instruction stream (sequentially
-// prefetched) carries the tensor, no scalar-cache traffic, and the compiler can neither hoist nor merge the constants
-#define QGS_LIT(hi, lo) ({ unsigned l_, h_; asm volatile("s_mov_b32 %0, " #lo "\n\ts_mov_b32 %1, " #hi : "=s"(l_), "=s"(h_)); \
-    __builtin_bit_cast(f64, ((unsigned long long)h_ << 32) | l_); })
 )";
 
 // Record bookkeeping shared by the steppers (reference integrate.py:190-223): record `iw` of the directed
 // run lands at index iw (forward) or n_records-1-iw (backward, the [::-1] of :223).
 const char *RECORD_HELPERS = R"(
-// 8-byte load through a buffer descriptor: address = base (SGPR descriptor) + soffset (SGPR) + voffset (VGPR), so per-row
-// address arithmetic stays on the scalar unit
-__device__ __forceinline__ f64 qgs_bload(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff)
-{
-    typedef unsigned u2 __attribute__((ext_vector_type(2)));
-    const u2 r = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
-    return __builtin_bit_cast(f64, r);
-}
 __device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward)
 {
     return backward ? (n_records - 1 - iw) : iw;
@@ -738,10 +437,6 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // Fused S-stage explicit RK stepper for sub-diagonal tableaus, one member per lane, all state in
 // registers for the whole run.  Storage: y (step start), acc (running y + dt*sum b_i k_i),
 // xa/xb (ping-pong stage inputs).  k_i is consumed row by row as it is produced.
-// park_y: the step-start state y is only the *input* of stage 0; in the later stages it is read once per row (x_next_i =
-// y_i + dt a k_i).  Parked in LDS (ysh[mode][lane], 288 B per lane) after stage 0 it leaves three state arrays in
-// registers instead of four, which brings the kernel under 256 VGPRs = two wavefronts per SIMD (the LDS of a CU holds the
-// 8 x 18 KB).  Pays off when the ensemble offers more than one wavefront per SIMD (>= 131 072 members on an MI355X).
 // spread_rec (qgs_spec_rkr_s<S>, launched for write_steps == 1, the reference's default): EVERY step is a record, so
 // nothing about the record is conditional.  The burst version stores the 36 rows at the top of a step (36 x 512 B per
 // wavefront, 18.9 MB for the whole chip at 65 536 members, all wavefronts in lock step): the store queues fill and the
@@ -750,17 +445,15 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // store every ~58 FMAs, addressed as scalar row pointer + lane offset (no 64-bit VALU address arithmetic).  Lanes past the
 // last member write their own padding column of the record (the buffer has ld >= 64 * gridDim.x columns per row).
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
-                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool park_y = false,
-                    bool spread_rec = false)
+                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool spread_rec = false)
 {
     std::ostringstream o;
     KTable table;
-    park_y = park_y && S > 1 && !store_stages;
-    spread_rec = spread_rec && !store_stages && !park_y;
-    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (park_y ? "qgs_spec_rkp_s" : (spread_rec ? "qgs_spec_rkr_s" : "qgs_spec_rk_s"))) + std::to_string(S);
+    spread_rec = spread_rec && !store_stages;
+    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (spread_rec ? "qgs_spec_rkr_s" : "qgs_spec_rk_s")) + std::to_string(S);
     o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only")
-      << (park_y ? ", step-start state parked in LDS (two wavefronts per SIMD)" : "") << "\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(64, " << (park_y ? 2 : opt.min_waves_per_simd) << ") " << kname << "(\n"
+      << (spread_rec ? ", every step a record (write_steps == 1)" : "") << "\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
       << "    const f64* __restrict__ y_in,   // X[mode][member] state at step `step_begin`\n"
       << "    f64* __restrict__ y_out,        // state after step `step_end-1` (may be null)\n"
       << "    f64* __restrict__ rec,          // R[record][mode][member] (may be null when no record is due)\n"
@@ -768,7 +461,6 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const f64* __restrict__ dtime,  // directed time grid\n"
       << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
-    if (park_y) o << "    __shared__ f64 ysh[" << ndim << "][QGS_WAVE];\n    const int lane = threadIdx.x;\n";
     if (spread_rec) o << "    const unsigned lane8 = threadIdx.x * 8u;\n";
     o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = m0 < n_traj;\n"
@@ -789,16 +481,12 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
           << "            f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ld + m;\n"
           << "            ++iw; next_rec += write_steps;\n"
           << "            if (live) {\n";
-        for (int d = 1; d <= ndim; ++d) {
-            if (opt.nt_record) o << "                __builtin_nontemporal_store(y" << d << ", p + " << (d - 1) << " * ld);\n";
-            else o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
-        }
+        for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
         o << "            }\n        }\n";
     }
     o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
-    if (park_y) for (int d = 1; d <= ndim; ++d) o << "        ysh[" << (d - 1) << "][lane] = y" << d << ";\n";
     for (int st = 0; st < S; ++st) {
         const std::string in = (st == 0) ? "y" : ((st % 2 == 1) ? "xa" : "xb");
         const std::string outn = (st % 2 == 0) ? "xa" : "xb";
@@ -817,24 +505,14 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
         }
         std::ostringstream so;
-        const int W = std::max(1, opt.interleave_plain);
-        for (int c0 = 1; c0 <= ndim; c0 += W) {
-            std::vector<std::vector<std::string>> lists;
-            for (int i = c0; i <= std::min(ndim, c0 + W - 1); ++i) {
-                const std::string rn = "r" + std::to_string(i);
-                std::ostringstream ro;
-                emit_tend_row(ro, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
-                ro << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
-                if (!last) {
-                    if (park_y && st > 0) ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", ysh[" << (i - 1) << "][lane]);\n";
-                    else ro << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
-                }
-                if (spread_rec && (i - 1) % S == st) ro << "            *(f64*)((char*)(prow + " << (i - 1) << " * ld) + lane8) = y" << i << ";\n";
-                lists.push_back(split_lines(ro.str()));
-            }
-            so << interleave(lists);
+        for (int i = 1; i <= ndim; ++i) {
+            const std::string rn = "r" + std::to_string(i);
+            emit_tend_row(so, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
+            so << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
+            if (!last) so << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
+            if (spread_rec && (i - 1) % S == st) so << "            *(f64*)((char*)(prow + " << (i - 1) << " * ld) + lane8) = y" << i << ";\n";
         }
-        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group, opt.rk_coeff_dedupe) : so.str());
+        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
         g_ktab = nullptr;
         o << "        }\n";
     }
@@ -1103,17 +781,11 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
       << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
       << "    int backward, int write_final, int adjoint, f64 inverse)\n{\n";
-    // Parking: `v` (needed after stage 0 only as the base of w_next) and `acc` (one read-modify-write per row and
-    // stage) live in LDS, [row][lane], so that x, w_in and w_out (216 VGPRs) fit the 256 architectural registers
-    // without accumulation-register moves or scratch.  36.9 KB per wavefront-workgroup: 4 per CU = one per SIMD,
-    // which is what the 400+-register variant gets as well.
-    const bool park = opt.tgl_park_lds && S > 1 && !shx && !dense;
     if (dense && S > 2) o << "    __shared__ f64 psw[" << (S - 2) << "][" << ndim << "][QGS_WAVE];\n";
-    if (park) o << "    __shared__ f64 vsh[" << ndim << "][QGS_WAVE];\n    __shared__ f64 accsh[" << ndim << "][QGS_WAVE];\n";
     // park_v: the step-start vector v is the input of stage 0 and afterwards only the base of w_next_i = v_i + dt a k_i, read
     // once per row and stage.  Parked in LDS after stage 0 the kernel holds four vectors in registers instead of five and
     // the accumulation-register traffic (v_accvgpr moves are VALU slots) shrinks.
-    const bool park_v = opt.tgl_park_v && S > 2 && !park && !dense;
+    const bool park_v = opt.tgl_park_v && S > 2 && !dense;
     if (park_v) o << "    __shared__ f64 vpk[" << C << "][" << ndim << "][QGS_WAVE];\n";
     if (shx) {
         o << "    __shared__ f64 xsh[2][" << ndim << "][QGS_WAVE];     // stage states of the 64 members, double-buffered\n";
@@ -1132,16 +804,10 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
           << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
           << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
           << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
-          << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n"
-          // the 64 lanes of a wavefront lie in one column (ld is a multiple of 64): the stage states are addressed as a uniform
-          // (scalar) row pointer + a 32-bit lane offset, so the 36 loads of a stage need no 64-bit VALU address arithmetic
-          << "    const i64 mbase = ((i64)blockIdx.x * QGS_WAVE) % ld;\n"
-          << "    const unsigned moff = (unsigned)(m - mbase) * 8u, ldb = (unsigned)ld * 8u;\n"
-          << "    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)stages, 0, 0x7fffffff, 0x00020000);\n";
+          << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
     }
     o << "    " << decl_list("v", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
-    if (park) for (int d = 1; d <= ndim; ++d) o << "    vsh[" << (d - 1) << "][lane] = v" << d << ";\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
     if (dense) {
         for (int i = 1; i < S; ++i)
@@ -1169,7 +835,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "            if (live) {\n";
     for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
     o << "            }\n        }\n";
-    if (!park) o << "        " << decl_list("acc", ndim) << "\n";
+    o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("wa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("wb", ndim) << "\n";
     if (park_v) for (int d = 1; d <= ndim; ++d) o << "        vpk[" << (shx ? "wave" : "0") << "][" << (d - 1) << "][lane] = v" << d << ";\n";
@@ -1194,17 +860,8 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
             }
             for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = xsh[pb][" << (d - 1) << "][lane];\n";
         } else {
-            if (opt.tgl_buffer_loads) {
-                // buffer loads: base descriptor in SGPRs, row offset in an SGPR (SALU arithmetic), lane offset in one VGPR
-                o << "            const unsigned soff = (unsigned)((((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + mbase) * 8);\n";
-                // (running offset, opaque to the compiler: otherwise it keeps d * ldb for every d in loop-invariant SGPRs and spills them)
-                o << "            unsigned so = soff;\n";
-                for (int d = 1; d <= ndim; ++d)
-                    o << "            const f64 x" << d << " = qgs_bload(srs, moff, so); so += ldb; asm volatile(\"\" : \"+s\"(so));\n";
-            } else {
-                o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-                for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
-            }
+            o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+            for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
         }
         emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
@@ -1232,24 +889,12 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                                << (st == 0 ? "v" + std::to_string(i) : slot) << ");\n";
                         }
                     }
-                } else if (!park) {
+                } else {
                     so << "                acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
                     if (!last) {
                         if (park_v && st > 0)
                             so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", vpk[" << (shx ? "wave" : "0") << "][" << (i - 1) << "][lane]);\n";
                         else so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
-                    }
-                } else {
-                    const std::string acc_l = "accsh[" + std::to_string(i - 1) + "][lane]";
-                    const std::string v_l = "vsh[" + std::to_string(i - 1) + "][lane]";
-                    const std::string vsrc = (st == 0) ? "v" + std::to_string(i) : v_l;
-                    const std::string asrc = (st == 0) ? "v" + std::to_string(i) : acc_l;
-                    if (!last) {
-                        so << "                " << acc_l << " = __builtin_fma(hb, " << rn << ", " << asrc << ");\n";
-                        so << "                " << outn << i << " = __builtin_fma(ha, " << rn << ", " << vsrc << ");\n";
-                    } else {
-                        so << "                v" << i << " = __builtin_fma(hb, " << rn << ", " << asrc << ");\n";
-                        so << "                " << v_l << " = v" << i << ";\n";
                     }
                 }
                 row_lines.push_back(split_lines(so.str()));
@@ -1276,7 +921,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         }
         o << "        }\n";
     }
-    if (!park) for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = acc" << d << ";\n";
+    for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = acc" << d << ";\n";
     o << "    }\n";
     o << "    if (live) {\n        if (w_out_p) {\n";
     for (int d = 1; d <= ndim; ++d) o << "            w_out_p[" << (d - 1) << " * L + l] = v" << d << ";\n";
@@ -1286,131 +931,6 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     o << "        }\n    }\n}\n";
     if (opt.const_table)
         for (int pass = 0; pass < 2; ++pass) emit_ktable(out, kname + "_kt" + std::to_string(pass), tables[pass]);
-    out << o.str();
-}
-
-// Row-split tangent / adjoint kernel: R wavefronts share 64 (member, column) lanes, each evaluates the rows
-// of its partition of (J w) or (J^T w) and the partitions exchange the new tangent stage vector through LDS
-// (one barrier per stage).  Per wave: x (full), w_in (full), and v / acc / w_out of the own rows only, which
-// brings the 444-VGPR single-wave kernel under 256 VGPRs, i.e. two wavefronts per SIMD.
-void emit_tgl_split_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
-                           const std::vector<std::vector<WX>> &adj, int S, int R, const CodegenOptions &opt)
-{
-    // partition by the combined tangent + adjoint cost of a row index
-    std::vector<std::pair<int64_t, int>> cost;
-    for (int i = 1; i <= ndim; ++i) cost.push_back({(int64_t)tgl[i].size() + (int64_t)adj[i].size(), i});
-    std::sort(cost.begin(), cost.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) {
-        return a.first != b.first ? a.first > b.first : a.second < b.second;
-    });
-    std::vector<int64_t> load(R, 0);
-    std::vector<int> owner(ndim + 1, 0);
-    for (auto &ci : cost) {
-        int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-        owner[ci.second] = w;
-        load[w] += ci.first;
-    }
-    const std::string kname = "qgs_spec_tglsplit" + std::to_string(R) + "_s" + std::to_string(S);
-    std::ostringstream o;
-    std::vector<KTable> tables(2 * R);
-    o << "\n// tangent / adjoint model, rows split over " << R << " wavefronts per 64 lanes\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * R << ", 2) " << kname << "(\n"
-      << "    const f64* __restrict__ w_in_p, f64* __restrict__ w_out_p, f64* __restrict__ rec, const f64* __restrict__ stages,\n"
-      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
-      << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
-      << "    int backward, int write_final, int adjoint, f64 inverse)\n{\n";
-    o << "    __shared__ f64 xs[2][" << ndim << "][QGS_WAVE];\n";
-    o << "    const int lane = threadIdx.x & 63;\n"
-      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-      << "    const i64 L = n_tg * ld;\n"
-      << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
-      << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
-      << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
-      << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
-    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
-    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
-    for (int w = 0; w < R; ++w) {
-        std::vector<int> own, other;
-        for (int i = 1; i <= ndim; ++i) (owner[i] == w ? own : other).push_back(i);
-        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {\n";
-        o << "        " << decl_list("v", ndim) << "\n";
-        for (int d = 1; d <= ndim; ++d) o << "        v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
-        emit_settle_loads(o, "        ", "v", all_rows(ndim));
-        o << "        QGS_REC_INIT\n";
-        o << "        for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
-        o << "            const f64 dt = dtime[ti + 1] - dtime[ti];\n";
-        o << "            const int par0 = (int)(((ti - step_begin) * " << S << ") & 1);\n";
-        o << "            if (ti == next_rec) {\n"
-          << "                f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * L + l;\n"
-          << "                ++iw; next_rec += write_steps;\n"
-          << "                if (live) {\n";
-        for (int d : own) o << "                    p[" << (d - 1) << " * L] = v" << d << ";\n";
-        o << "                }\n            }\n";
-        o << "            f64 ";
-        for (size_t n = 0; n < own.size(); ++n) o << "acc" << own[n] << (n + 1 < own.size() ? ", " : ";\n");
-        if (S > 1) o << "            " << decl_list("wa", ndim) << "\n";
-        if (S > 2) o << "            " << decl_list("wb", ndim) << "\n";
-        for (int st = 0; st < S; ++st) {
-            const std::string in = (st == 0) ? "v" : ((st % 2 == 1) ? "wa" : "wb");
-            const std::string outn = (st % 2 == 0) ? "wa" : "wb";
-            const bool last = (st == S - 1);
-            o << "            {   // stage " << st << "\n";
-            o << "                const f64 hb = dt * tb" << st << " * inverse;\n";
-            if (!last) o << "                const f64 ha = dt * ta" << st << " * inverse;\n";
-            o << "                const int pb = (par0 + " << st << ") & 1;\n";
-            o << "                const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-            for (int d = 1; d <= ndim; ++d) o << "                const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
-            for (int pass = 0; pass < 2; ++pass) {
-                o << "                if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
-                KTable &tb = tables[2 * w + pass];
-                if (opt.const_table) {
-                    g_ktab = &tb;
-                    o << "                    kf64* kt = (kf64*)" << kname << "_kt" << (2 * w + pass) << "; asm volatile(\"\" : \"+s\"(kt));\n";
-                }
-                std::ostringstream so;
-                const int W = std::max(1, opt.interleave);
-                for (size_t c0 = 0; c0 < own.size(); c0 += W) {
-                    std::vector<std::vector<std::string>> lists;
-                    for (size_t q = c0; q < std::min(own.size(), c0 + W); ++q) {
-                        const int i = own[q];
-                        const std::string rn = "r" + std::to_string(i);
-                        std::ostringstream ro;
-                        emit_wx_row(ro, "                    ", pass == 0 ? tgl[i] : adj[i], rn, names("x"), names(in), opt,
-                                    w * 1000000 + pass * 100000 + st * 1000 + i);
-                        ro << "                    acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "v" : "acc") << i << ");\n";
-                        if (!last) {
-                            ro << "                    " << outn << i << " = __builtin_fma(ha, " << rn << ", v" << i << ");\n";
-                            ro << "                    xs[pb][" << (i - 1) << "][lane] = " << outn << i << ";\n";
-                        } else {
-                            ro << "                    xs[pb][" << (i - 1) << "][lane] = acc" << i << ";\n";
-                        }
-                        lists.push_back(split_lines(ro.str()));
-                    }
-                    so << interleave(lists);
-                }
-                o << (opt.const_table ? resolve_ktab(so.str(), tb, 0) : so.str());
-                g_ktab = nullptr;
-                o << "                }\n";
-            }
-            o << "                __syncthreads();\n";
-            if (!last) {
-                for (int j : other) o << "                " << outn << j << " = xs[pb][" << (j - 1) << "][lane];\n";
-            } else {
-                for (int i : own) o << "                v" << i << " = acc" << i << ";\n";
-                for (int j : other) o << "                v" << j << " = xs[pb][" << (j - 1) << "][lane];\n";
-            }
-            o << "            }\n";
-        }
-        o << "        }\n";
-        o << "        if (live) {\n            if (w_out_p) {\n";
-        for (int d : own) o << "                w_out_p[" << (d - 1) << " * L + l] = v" << d << ";\n";
-        o << "            }\n            if (write_final) {\n"
-          << "                f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
-        for (int d : own) o << "                p[" << (d - 1) << " * L] = v" << d << ";\n";
-        o << "            }\n        }\n    }\n";
-    }
-    o << "}\n";
-    if (opt.const_table)
-        for (int t = 0; t < 2 * R; ++t) emit_ktable(out, kname + "_kt" + std::to_string(t), tables[t]);
     out << o.str();
 }
 
@@ -1492,28 +1012,6 @@ std::vector<Phase> build_phases(int ndim, const std::vector<PTerm> &terms, int c
         phases.push_back(std::move(ph));
     }
     return phases;
-}
-
-// The greedy above ends in a tail of phases with two or three modes each (the leftover edges): every one of them costs a
-// wait for its LDS reads with a handful of FMAs behind it.  Consecutive phases whose mode sets fit the register budget
-// together become one phase (the union is loaded at once; the terms stay the same).
-std::vector<Phase> merge_small_phases(std::vector<Phase> phases, int cap)
-{
-    std::vector<Phase> out;
-    for (Phase &ph : phases) {
-        if (!out.empty()) {
-            Phase &last = out.back();
-            std::vector<int> uni;
-            std::set_union(last.modes.begin(), last.modes.end(), ph.modes.begin(), ph.modes.end(), std::back_inserter(uni));
-            if ((int)uni.size() <= cap && (int)ph.modes.size() <= cap / 2) {
-                last.modes.swap(uni);
-                last.terms.insert(last.terms.end(), ph.terms.begin(), ph.terms.end());
-                continue;
-            }
-        }
-        out.push_back(std::move(ph));
-    }
-    return out;
 }
 
 // ---- shared machinery of the LDS-resident kernels (stepper and tangent model) --------------------------------------
@@ -1614,12 +1112,11 @@ std::vector<std::vector<int>> lds_partition(int n_rows, int n_nodes, const RowTe
 // `hook_phase` (== phases.size(): behind the last one).
 void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<Phase> &phases, const NodeFn &node,
                      const std::vector<std::string> &lane_vars, const std::string &lds_ptr, bool group, int hook_phase,
-                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st, bool markers = false)
+                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st)
 {
     int ph_id = 0, prod_id = 0;
     for (const Phase &ph : phases) {
         if (ph_id == hook_phase) hook(so);
-        if (markers) so << "//@LOADS " << ph_id << "\n";            // resolve_ktab_phased moves this block one segment ahead
         const std::string sfx = "_" + std::to_string(ph_id++);
         // Opaque lane offset per phase: otherwise the compiler merges the reads of one value in different phases and keeps
         // it in a register (or scratch) in between.  ds_read offsets are 16-bit immediates, so every 64 KB window of the
@@ -1640,7 +1137,6 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
             so << ind << "const f64 x" << mo << sfx << " = *(const f64*)(" << lds_ptr << " + " << (nd.offset & 65535) << " + "
                << bases[{nd.lane_kind, (int)(nd.offset >> 16)}] << ");\n";
         }
-        if (markers) so << "//@ENDLOADS\n";
         st.loads += (int64_t)ph.modes.size();
         ++st.phases;
         // Terms of one row with equal |coefficient| that fall into this phase are summed first
@@ -1832,43 +1328,25 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
           << I4 << "    f64* sp = stages + ((ti - step_begin) * S + st) * " << ndim << " * ldr + m;\n";
         for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
         o << I4 << "}\n";
-        const bool table = opt.lds_coeff_table;
-        const bool dpp = table && opt.lds_coeff_dpp && !(opt.lds_debug & 2);
-        if (table) {
-            g_ktab = &tables[w];
-            g_lit_mix = opt.lds_lit_mix;
-            g_lit_count = 0;
-            g_kdpp = dpp;
-            if (dpp) o << I4 << "gf64* ktl = (gf64*)(kf64*)" << kname << "_kt" << w << " + (lane & 15); asm volatile(\"\" : \"+v\"(ktl));\n";
-            else o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
-        } else g_asm_lit = true;
+        g_ktab = &tables[w];
+        o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
         std::ostringstream so;
         std::vector<PTerm> terms;
         for (int i : own) {
             const Row &r = rows[i];
-            if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << (dpp ? hexlit(r.c0) : lit(r.c0)) << ";\n";
+            if (r.has_c0 && r.c0 != 0.0) so << I4 << "f64 k" << i << " = " << lit(r.c0) << ";\n";
             else so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        std::vector<Phase> phases = build_phases(nnode, terms, cap);
-        if (opt.lds_merge_phases) phases = merge_small_phases(phases, cap);
-        // one wait per coefficient segment, LDS reads requested a segment ahead (resolve_ktab_phased)
-        const bool pipe = table && opt.lds_pipeline && !dpp && !(opt.lds_debug & 6);
+        const std::vector<Phase> phases = build_phases(nnode, terms, cap);
         // step-start state of the own rows, consumed at the end of the stage
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
-                        }, stats, pipe);
-        g_ktab_samelines = (opt.lds_debug & 4) != 0;
-        if (pipe) o << resolve_ktab_phased(so.str(), tables[w], opt.lds_coeff_dedupe, opt.lds_segment);
-        else
-        o << (table ? resolve_ktab(so.str(), tables[w], (opt.lds_debug & 2) ? -1 : (dpp ? 64 + opt.lds_dpp_ahead : opt.ktab_group), opt.lds_coeff_dedupe) : so.str());
-        g_ktab_samelines = false;
-        g_lit_mix = 0;
+                        }, stats);
+        o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
         g_ktab = nullptr;
-        g_kdpp = false;
-        g_asm_lit = false;
         if (tend_kernel) {
             o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"
               << I4 << "    if (live) {\n";
@@ -1888,9 +1366,9 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
             o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";
         }
-        if (!(opt.lds_debug & 1)) o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
+        o << I4 << "__syncthreads();          // every wavefront is done reading the stage state\n";
         for (int d : own) o << I4 << "xs[" << (d - 1) << "][lane] = k" << d << ";\n";
-        if (!(opt.lds_debug & 1)) o << I4 << "__syncthreads();\n";
+        o << I4 << "__syncthreads();\n";
         if (!der.empty()) {                                  // derived monomials of the new stage state
             emit_lds_derived(o, I4, ndim, der, dshare[w], dval, dval);
             o << I4 << "__syncthreads();\n";
@@ -1912,8 +1390,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
     // general-tableau flavour: CodeGenPrepare takes 3.3 min on this kernel at ndim 228 and changes nothing in the result
     // (same registers, same scratch); qgs_hip_api.hip reads the line below and passes the flags to hiprtc
     if (dense) out << "// qgs-compile-flags: -mllvm -disable-cgp\n";
-    if (opt.lds_coeff_table)
-        for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
 }
 
@@ -2008,30 +1485,22 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
         o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st] * inverse;\n";
         o << I4 << "i64 yoff = 0; asm volatile(\"\" : \"+s\"(yoff));\n";
         o << I4 << "unsigned long long lastmask = last ? ~0ull : 0ull; asm volatile(\"\" : \"+v\"(lastmask));\n";
-        const bool table = opt.lds_coeff_table;
-        if (table) {
-            g_ktab = &tables[w];
-            o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
-        } else g_asm_lit = true;
+        g_ktab = &tables[w];
+        o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
         std::ostringstream so;
         std::vector<PTerm> terms;
         for (int i : own) {
             so << I4 << "f64 k" << i << " = 0.0;\n";
             terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         }
-        std::vector<Phase> phases = build_phases(ndim + nx, terms, cap);
-        if (opt.lds_merge_phases) phases = merge_small_phases(phases, cap);
-        const bool pipe = table && opt.lds_pipeline;
+        const std::vector<Phase> phases = build_phases(ndim + nx, terms, cap);
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8", "xl8"}, "(const char*)lds_all", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = vw[yoff + " << (d - 1) * 64 << "];\n";
-                        }, stats, pipe);
-        if (pipe) o << resolve_ktab_phased(so.str(), tables[w], opt.lds_coeff_dedupe, opt.lds_segment);
-        else
-        o << (table ? resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe) : so.str());
+                        }, stats);
+        o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
         g_ktab = nullptr;
-        g_asm_lit = false;
         for (int d : own) {
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
             o << I4 << "k" << d << " = qgs_bitsel(lastmask, acc" << d << ", __builtin_fma(ha, k" << d << ", yg" << d << "));\n";
@@ -2064,8 +1533,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
     // as for the general-tableau stepper: half of the 40 s this kernel takes to compile at ndim 228 is CodeGenPrepare, and the
     // kernel runs the same without it (24.4 vs 24.5 ms for 16 384 members x 8 columns x 10 steps)
     out << "// qgs-compile-flags: -mllvm -disable-cgp\n";
-    if (opt.lds_coeff_table)
-        for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
 }
 
@@ -2152,12 +1620,10 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkSplit: return "qgs_spec_rksplit" + std::to_string(opt.row_split) + "_s" + std::to_string(S);
     case Kernel::RkStages: return "qgs_spec_rkstages_s" + std::to_string(S);
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
-    case Kernel::TglSplit: return "qgs_spec_tglsplit" + std::to_string(opt.tgl_split) + "_s" + std::to_string(S);
     case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
     case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
     case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
-    case Kernel::RkPark: return "qgs_spec_rkp_s" + std::to_string(S);
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
     case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
     case Kernel::RkDense: return "qgs_spec_rkd_s" + std::to_string(S);
@@ -2185,8 +1651,7 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t); break;
     case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt, der.t); break;
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
-    case Kernel::RkPark: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
-    case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, false, true); break;
+    case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
     case Kernel::RkDense: emit_rk_dense_kernel(o, ndim, rows, S, opt, der.t); break;
     case Kernel::TglDense:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j, 1, true);
@@ -2197,10 +1662,6 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::TglX:
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j,
                         opt.tgl_share_x);
-        break;
-    case Kernel::TglSplit:
-        emit_tgl_split_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S,
-                              opt.tgl_split, opt);
         break;
     case Kernel::RkLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t); break;
     case Kernel::TendLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, true); break;
@@ -2215,19 +1676,16 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
 {
     CodegenOptions opt = opt_in;
     if (ndim < 2 * opt.row_split) opt.row_split = 1;      // too few rows to split
-    if (ndim < 2 * opt.tgl_split) opt.tgl_split = 1;
     std::vector<std::pair<Kernel, int>> l = {{Kernel::Tend, 0}};
     if (have_jac) l.push_back({Kernel::Jac, 0});
     for (int S : stages) {
         l.push_back({Kernel::Rk, S});
-        if (opt.rk_park_y && S > 1) l.push_back({Kernel::RkPark, S});
         if (opt.rk_spread_rec) l.push_back({Kernel::RkRec, S});
         if (opt.row_split > 1) l.push_back({Kernel::RkSplit, S});
         if (have_jac) {
             l.push_back({Kernel::RkStages, S});
             l.push_back({Kernel::Tgl, S});
             if (opt.tgl_share_x > 1) l.push_back({Kernel::TglX, S});
-            if (opt.tgl_split > 1) l.push_back({Kernel::TglSplit, S});
         }
     }
     return l;

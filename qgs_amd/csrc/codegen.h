@@ -23,45 +23,23 @@ struct Term {          // one COO entry (i, j, k, value); index 0 is the constan
 struct CodegenOptions {
     bool group_coeff = true;   // factor equal-|coefficient| bilinear terms of a row: c*(m1 +- m2 ...)
     int min_waves_per_simd = 1;
-    int interleave_plain = 1;  // same for the plain one-wave stepper
     int interleave = 2;        // rows whose statements are interleaved in the row-split stepper (ILP)
     int ktab_group = 16;       // 16: software-pipelined coefficient fetch in groups of 16; 0: compiler-placed loads
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
-    bool tgl_park_lds = false; // tangent kernel: keep `v` and `acc` in LDS instead of (accumulation) registers (measured 3-8 % slower)
-    int tgl_split = 1;         // wavefronts per 64 lanes in the row-split tangent kernel (1 = not emitted)
-    bool rk_coeff_dedupe = false;  // register-resident stepper: ditto (measured neutral with the system hiprtc build: 4.78 vs 4.78 ms; off)
-    bool tgl_buffer_loads = false; // tangent kernel: stage states through buffer loads (descriptor + SGPR row offset + VGPR lane offset): the
-                               // per-row 64-bit address arithmetic moves from the VALU to the scalar unit
     int tgl_interleave = 2;    // tangent kernel: rows whose statements are emitted round-robin (config 4, 100 calls: 0.949 -> 0.933 ms with park_v)
     bool tgl_park_v = true;    // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
     bool tgl_coeff_dedupe = true;  // tangent kernel: same de-duplication of coefficient fetches as lds_coeff_dedupe (config 4: 1.24 -> 1.20 ms)
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
-    bool nt_record = false;    // plain stepper: non-temporal stores for the records
     bool rk_spread_rec = true; // also emit qgs_spec_rkr_s<S> for write_steps == 1 (every step is a record): the 36 row stores of a step are
                                // spread over its stages, unconditional, scalar row pointer + lane offset (codegen.cpp emit_rk_kernel)
-    bool rk_park_y = false;    // also emit qgs_spec_rkp_s<S>: step-start state parked in LDS, 216 VGPRs, 2 wavefronts per SIMD
-                               // (measured: no gain -- 9.8 vs 9.0 ms at 131 072 members, equal at 1 048 576: the lone wavefront
-                               // already keeps the fp64 pipe 91 % busy)
     int row_split = 4;         // also emit the row-split stepper with this many wavefronts per 64 members
     int lds_waves = 16;        // LDS-resident stepper (large ndim): wavefronts per 64 members
     int lds_tgl_members = 16;  // LDS-resident tangent kernels: members per workgroup tile (16 x 4 columns, or 8 x 8 columns)
     int lds_cap = 20;          // ... and modes cached in registers per phase (24 spills at 128 VGPRs: 63.6 ms vs 55.6 ms)
     bool lds_group = true;     // ... sum equal-|coefficient| terms of a row inside a phase first: 11 % fewer instructions and
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
-    bool lds_coeff_table = true; // ... coefficients from __constant__ tables (s_load) or as s_mov literals in the code
-    bool lds_coeff_dpp = false;  // stepper: coefficients fetched 16 per vector load and broadcast by the FMA's DPP operand (v_fmac_f64_dpp
-                                 // row_newbcast) instead of through the scalar cache.  Correct, not faster: 54.3 vs 52.8 ms at ndim
-                                 // 228 (the inline-asm FMAs cost 8 more VGPRs -> more spills, and run at 90 % of the plain rate)
-    int lds_dpp_ahead = 3;       // ... groups of 16 coefficients requested ahead of the one being consumed (2 VGPRs each)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
-    bool lds_pipeline = false;  // ... coefficient segments aligned with the phases, the next segment's coefficients and the next phase's
-                               //     LDS reads requested one segment ahead: one wait per segment (codegen.cpp resolve_ktab_phased)
-    int lds_segment = 16;      // ... coefficients per segment (two 8-double SGPR vectors, double-buffered)
-    bool lds_merge_phases = false; // ... consecutive small phases whose mode sets fit the factor cache together become one
-    int lds_lit_mix = 0;       // ... > 0: every n-th coefficient is an s_mov literal pair in the instruction stream instead of a table entry
-    int lds_debug = 0;         // timing experiments only (WRONG results): 1 = no barriers in the stage loop, 2 = every coefficient
-                               // is table entry 0 (no coefficient stream)
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
 };
 
@@ -87,8 +65,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_tend            f(x) for an ensemble                       (tendencies.py:111-115)
 //   qgs_spec_jac             Df(x) for an ensemble                      (tendencies.py:117-121)
 //   qgs_spec_rk_s<S>         fused S-stage RK trajectory stepper        (integrate.py:182-223)
-//   qgs_spec_rkp_s<S>        same as qgs_spec_rk_s<S> with the step-start state parked in LDS after stage 0: two wavefronts per
-//                            SIMD, for ensembles that offer them
+//   qgs_spec_rkr_s<S>        the same stepper for write_steps == 1 (every step a record): record stores spread over the step
 //   qgs_spec_rkd_s<S>        S-stage RK with a general lower-triangular tableau (partial stage sums in LDS; optional stage store)
 //   qgs_spec_tgld_s<S>       tangent / adjoint propagation for such a tableau
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
@@ -105,7 +82,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, TglSplit, RkLds, TglLds, AdjLds, TglX, RkPark, RkRec, TendLds, RkDense, TglDense, RkLdsDense };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

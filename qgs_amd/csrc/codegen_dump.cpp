@@ -37,9 +37,7 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "stages=", 7)) stages = {std::atoi(argv[a] + 7)};
         if (!std::strncmp(argv[a], "split=", 6)) opt.row_split = std::atoi(argv[a] + 6);
         if (!std::strcmp(argv[a], "ktab")) opt.const_table = true;
-        if (!std::strcmp(argv[a], "nopark")) opt.tgl_park_lds = false;
         if (!std::strncmp(argv[a], "kgroup=", 7)) opt.ktab_group = std::atoi(argv[a] + 7);
-        if (!std::strncmp(argv[a], "tsplit=", 7)) opt.tgl_split = std::atoi(argv[a] + 7);
         if (!std::strncmp(argv[a], "ilv=", 4)) opt.interleave = std::atoi(argv[a] + 4);
     }
     if (rank == 5) opt.row_split = 1;

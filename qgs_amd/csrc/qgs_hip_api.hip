@@ -699,38 +699,23 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     return 0;
 }
 
-// Developer knobs (the defaults are what ships): QGS_HIP_NO_GROUP=1, QGS_HIP_ROW_SPLIT=<R>
+// Generator knobs (the defaults are what ships)
 void apply_env_options(qgs::CodegenOptions &cg)
 {
     if (const char *e = std::getenv("QGS_HIP_NO_GROUP")) if (*e == '1') cg.group_coeff = false;
     if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_KTAB")) cg.const_table = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) cg.ktab_group = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_TGL_PARK")) cg.tgl_park_lds = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_TGL_SPLIT")) cg.tgl_split = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) cg.ktab_group = (std::atoi(e) == 16) ? 16 : 0;
     if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_X")) cg.tgl_share_x = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_INTERLEAVE_PLAIN")) cg.interleave_plain = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) cg.lds_cap = std::max(2, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_NT_RECORD")) cg.nt_record = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_RK_PARK")) cg.rk_park_y = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) cg.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) cg.lds_yload_ahead = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) cg.lds_debug = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_LDS_PIPE")) cg.lds_pipeline = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_LITMIX")) cg.lds_lit_mix = std::max(0, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_LDS_SEGMENT")) cg.lds_segment = std::max(4, std::min(16, std::atoi(e)));
-    if (const char *e = std::getenv("QGS_HIP_LDS_MERGE")) cg.lds_merge_phases = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_DEDUPE")) cg.lds_coeff_dedupe = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_DPP")) cg.lds_coeff_dpp = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_DPP_AHEAD")) cg.lds_dpp_ahead = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_TGL_DEDUPE")) cg.tgl_coeff_dedupe = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_TGL_BLOAD")) cg.tgl_buffer_loads = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK_V")) cg.tgl_park_v = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_INTERLEAVE")) cg.tgl_interleave = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_RK_DEDUPE")) cg.rk_coeff_dedupe = (*e == '1');
 }
 
 // explicit scheme: a[i][j] == 0 for j >= i
@@ -1201,20 +1186,16 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         const int R = m->cg.row_split;
         const int64_t waves = (n_traj + 63) / 64;
         bool split = R > 1 && m->ndim >= 2 * R && waves * R <= (int64_t)m->n_simd * 5 / 2;
-        // more wavefronts than SIMDs: the variant with the step-start state parked in LDS fits two wavefronts per SIMD
-        bool park = !split && m->cg.rk_park_y && s > 1 && waves > (int64_t)m->n_simd && m->der.t.empty();
         if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
-            if (!std::strcmp(e, "plain")) split = park = false;
-            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) { split = true; park = false; }
-            if (!std::strcmp(e, "park") && s > 1 && m->der.t.empty()) { park = true; split = false; }
+            if (!std::strcmp(e, "plain")) split = false;
+            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) split = true;
         }
         // every step is a record (write_steps == 1, the reference's default): the variant with the record stores spread over the step
-        bool spread = !split && !park && m->cg.rk_spread_rec && write_steps == 1 && ld >= 64 * waves;
+        bool spread = !split && m->cg.rk_spread_rec && write_steps == 1 && ld >= 64 * waves;
         if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) spread = spread && (*e == '1');
         hipFunction_t f;
         std::string name;
-        if (get_function(m, split ? qgs::Kernel::RkSplit : (park ? qgs::Kernel::RkPark : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk)), s,
-                         &f, &name)) return -1;
+        if (get_function(m, split ? qgs::Kernel::RkSplit : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk), s, &f, &name)) return -1;
         double *y_out = nullptr, *stg = nullptr;
         long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
         int bw = backward, wf = 1;
@@ -1372,8 +1353,6 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
                                             stages, d_time, d_tab_spec, st, m->chains(true)));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
         } else if (spec && m->spec_jac_possible) {
-            // row-split tangent kernel (R wavefronts per 64 lanes) only on request; measured slower
-            bool tgl_split = m->cg.tgl_split > 1 && m->ndim >= 2 * m->cg.tgl_split;
             // shared-stage-state kernel: C columns of the same 64 members per workgroup, stage states prefetched through LDS
             const int C = m->cg.tgl_share_x;
             // Measured (tools/tgls_scale.py, MAOOAM-36, 36 columns, 10 steps): while the stage record of a chunk stays in the
@@ -1382,22 +1361,17 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
             size_t share_min = (size_t)256 << 20;
             if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) share_min = (size_t)std::atoll(e) << 20;
-            bool share_x = !tgl_split && C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
+            bool share_x = C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
                            (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
                            stage_bytes_per_step * (size_t)(end - begin) >= share_min;
-            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) {
-                tgl_split = tgl_split && std::strcmp(e, "plain") != 0;
-                share_x = share_x && std::strcmp(e, "plain") != 0;
-            }
+            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) share_x = share_x && std::strcmp(e, "plain") != 0;
             hipFunction_t f2;
             std::string n2;
-            if (get_function(m, tgl_split ? qgs::Kernel::TglSplit : (share_x ? qgs::Kernel::TglX : qgs::Kernel::Tgl), s, &f2, &n2)) return -1;
+            if (get_function(m, share_x ? qgs::Kernel::TglX : qgs::Kernel::Tgl, s, &f2, &n2)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
-            if (tgl_split) {
-                HIPCHK(hipModuleLaunchKernel(f2, (unsigned)((L + 63) / 64), 1, 1, 64 * m->cg.tgl_split, 1, 1, 0, st, a2, nullptr));
-            } else if (share_x) {
+            if (share_x) {
                 HIPCHK(hipModuleLaunchKernel(f2, (unsigned)(ld / 64), (unsigned)((n_tg + C - 1) / C), 1, 64 * C, 1, 1, 0, st, a2, nullptr));
             } else if (launch(f2, L, st, a2)) return -1;
         } else {
@@ -1591,6 +1565,20 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     if (qgs_unpack_records(m, n_traj, ld, (int64_t)m->ndim * n_tg, n_records, m->b_fm_modes.f64(), m->b_fm_rows.f64(), nullptr)) return -1;
     HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(fmatrix, m->b_fm_rows.p, tg_rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_host_register(void *ptr, int64_t bytes)
+{
+    if (!ptr || bytes <= 0) return fail("bad arguments");
+    HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+int qgs_host_unregister(void *ptr)
+{
+    if (!ptr) return fail("bad arguments");
+    HIPCHK(hipHostUnregister(ptr));
     return 0;
 }
 

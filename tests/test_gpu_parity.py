@@ -632,20 +632,3 @@ def test_random_polynomial_systems(seed, ndim, rank, nnz):
         assert rel_err(tr, ref_ad[0]) < 1e-12 and rel_err(fm, ref_ad[1]) < 1e-11, kind
     m.close()
 
-
-def test_lds_stepper_with_lane_broadcast_coefficients(monkeypatch):
-    """Opt-in code-generation variant of the LDS-resident stepper (QGS_HIP_LDS_DPP=1): 16 coefficients per vector load,
-    handed to the FMA by its DPP operand (v_fmac_f64_dpp row_newbcast) instead of the scalar cache."""
-    from qgs_amd import _lib
-    from oracle.oracle import OracleModel
-    monkeypatch.setenv('QGS_HIP_LDS_DPP', '1')
-    coo, val, jcoo, jval = _random_system(5, 70, 3, 900)
-    m = _lib.HipModel(70, coo, val, jcoo, jval)
-    m.set_kernel(2)
-    ora = OracleModel(70, coo, val, jcoo, jval)
-    x = np.random.RandomState(9).rand(130, 70) * 0.3
-    t = np.concatenate((np.arange(0., 0.05, 0.01), [0.05]))
-    out = m.rk_integrate(t, x, 1, 2, RK4['b'], RK4['c'], RK4['a'])
-    assert m.last_kernel_info()['name'] == 'qgs_spec_rklds16'
-    assert rel_err(out, ora.integrate_runge_kutta_jit(t, x, 1, 2, RK4['b'], RK4['c'], RK4['a'])) < 1e-12
-    m.close()

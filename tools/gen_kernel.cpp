@@ -28,13 +28,7 @@ int main(int argc, char **argv)
     if (const char *e = std::getenv("QGS_HIP_KTAB")) opt.const_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) opt.lds_yload_ahead = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) opt.lds_group = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_TABLE")) opt.lds_coeff_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) opt.ktab_group = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_LDS_PIPE")) opt.lds_pipeline = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_LDS_LITMIX")) opt.lds_lit_mix = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_LDS_DEBUG")) opt.lds_debug = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_LDS_SEGMENT")) opt.lds_segment = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_LDS_MERGE")) opt.lds_merge_phases = (*e == '1');
     const int S = argc > 3 ? std::atoi(argv[3]) : 4;
     qgs::Kernel k = qgs::Kernel::Tend;
     if (!std::strcmp(argv[2], "rk")) k = qgs::Kernel::Rk;

@@ -1,4 +1,5 @@
-# developer script: effective shader clock (GRBM_GUI_ACTIVE / duration) and VALU activity of the ndim-228 stepper under variants
+# developer script: effective shader clock (GRBM_GUI_ACTIVE / duration / 8 XCDs) and VALU activity of the ndim-228 stepper;
+# arguments: generator knob settings "NAME=VALUE ..." (one run each), e.g. "QGS_HIP_LDS_CAP=18"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/lds228_clock

@@ -1,5 +1,5 @@
-"""Time only: qgs_spec_rklds16 on the MAOOAM 6x6 tensor, 65 536 members x 100 steps (QGS_HIP_LDS_DEBUG experiments give wrong
-results on purpose)."""
+"""Time only: qgs_spec_rklds16 on the MAOOAM 6x6 tensor, 65 536 members x 100 steps (generator knobs through the environment,
+see INTEGRATION.md)."""
 import json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,4 +17,4 @@ for _ in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-print('QGS_HIP_LDS_DEBUG=%s: %.2f ms %s' % (os.environ.get('QGS_HIP_LDS_DEBUG', '0'), min(ts[1:]) * 1e3, m.last_kernel_info()), flush=True)
+print('%.2f ms %s' % (min(ts[1:]) * 1e3, m.last_kernel_info()), flush=True)
