@@ -12,6 +12,11 @@
  * identical (same loop order, built with -ffp-contract=off); trajectories agree to
  * <= 1e-13 relative (the reference's `@` products go through BLAS, whose summation
  * order/FMA use is not specified, so bitwise equality is not claimed there).
+ * Caveat on the pin: numba is not installable in that container, so the goldens are the
+ * reference's own loops executed by CPython with `numba.njit` replaced by the identity
+ * (oracle/refshim/): same statements and IEEE-754 operation order as the jitted code, but
+ * not numba-compiled code.  The reference has no stepper fixtures of its own; its tensor
+ * fixtures (model_test/*.ref, tests/golden/ref/) cross-pin the tensors.
  *
  * Each function cites the reference file:line (relative to the qgs repository root) whose
  * statements it follows.  Operation order is the reference's: (a*b)*val then +=, no FMA.

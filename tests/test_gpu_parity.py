@@ -7,10 +7,13 @@ Tolerances (fp64; the HIP kernels use FMA and a different summation order than t
   trajectories 1000 steps    1e-10 relative (weakly chaotic amplification of rounding differences)
   tangent / adjoint 10 steps 1e-11 relative
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import RK4, load_golden, rel_err
+from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -632,3 +635,35 @@ def test_random_polynomial_systems(seed, ndim, rank, nnz):
         assert rel_err(tr, ref_ad[0]) < 1e-12 and rel_err(fm, ref_ad[1]) < 1e-11, kind
     m.close()
 
+
+
+def test_cache_miss_compiles_the_same_stepper(tmp_path):
+    """A tensor that misses the kernel cache is compiled at model-creation time by the out-of-process helper (system hiprtc),
+    not by whatever hiprtc this -- torch-importing -- process has mapped: the stepper must come out with the registers of the
+    pre-built one (282; PyTorch's bundled compiler gives 324) and without scratch."""
+    import subprocess
+    import sys
+    code = ("import os, sys, json, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from qgs_amd import _lib\n"
+            "g = np.load(%r)\n"
+            "ndim = int(g['ndim'])\n"
+            "m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval'])\n"
+            "n = 65536\n"
+            "ic = torch.rand((ndim, n), dtype=torch.float64, device='cuda') * 0.01\n"
+            "rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')\n"
+            "t = np.arange(0., 0.55, 0.1)\n"
+            "b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); c = np.array([0., .5, .5, 1.]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.\n"
+            "m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), torch.cuda.current_stream().cuda_stream)\n"
+            "torch.cuda.synchronize()\n"
+            "print('INFO ' + json.dumps(m.last_kernel_info()))\n"
+            "print('FILES %%d' %% len([f for f in os.listdir(os.environ['QGS_HIP_CACHE_DIR']) if f.endswith('.hsaco')]))\n"
+            % (REPO, os.path.join(GOLDEN_DIR, 'm36.npz')))
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(tmp_path)))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = p.stdout.decode()
+    info = json.loads([ln for ln in out.splitlines() if ln.startswith('INFO ')][0][5:])
+    assert info['name'] == 'qgs_spec_rk_s4'
+    assert info['vgprs'] <= 288 and info['scratch_bytes'] == 0, info
+    assert int([ln for ln in out.splitlines() if ln.startswith('FILES ')][0][6:]) >= 1
