@@ -261,10 +261,11 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
     rec = torch.empty((steps + 1, ndim, n), dtype=torch.float64, device=dev)
     ms, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 1, b, c, a, rec.data_ptr(), st), 5)
     rec_bytes = float(rec.numel() * 8)
+    kname_rec = model.last_kernel_info()['name']
     ms0, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 5)
     out['config2_write_steps_1'] = {
         'workload': 'MAOOAM-36, 65 536 members, 100 RK4 steps, write_steps=1: 101 records = %.2f GB (device layout)' % (rec_bytes / 1e9),
-        'kernel': model.last_kernel_info()['name'], 'ms': ms, 'ms_same_run_without_records': ms0,
+        'kernel': kname_rec, 'ms': ms, 'ms_same_run_without_records': ms0,
         'traj_steps_per_s': n * steps / (ms * 1e-3),
         'roofline': {'bound': 'hbm', 'achieved': rec_bytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
