@@ -1260,6 +1260,14 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
     }
     const std::vector<std::vector<int>> owns = lds_partition(ndim, nnode, rt, W, cap, opt.lds_group);
     const NodeFn node = [](int m) { return LdsNode{(int64_t)(m - 1) * 512, 0}; };
+    // private buffers (step-start state, running sum, partial stage sums): a wavefront only ever touches its own rows, so they
+    // are laid out [wavefront's rows, consecutively][64]: all of a wavefront's rows lie within +-4 KB of one or two base
+    // addresses (the immediate offset range of global_load / global_store) instead of needing a 64-bit address per row
+    std::vector<int> slot(ndim + 1, 0);
+    {
+        int q = 0;
+        for (int w = 0; w < W; ++w) for (int d : owns[w]) slot[d] = q++;
+    }
     std::ostringstream o;
     std::vector<KTable> tables(W);
     o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members,\n"
@@ -1294,7 +1302,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
         // acc<r>: running y + dt*sum b_i k_i; equals the state y at every step boundary
         for (int d : own) o << I2 << "f64 acc" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
-        for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << slot[d] * 64 << "] = acc" << d << ";\n";
         o << I2 << "__syncthreads();\n";
         if (!der.empty()) {
             emit_lds_derived(o, I2, ndim, der, dshare[w], dval, dval);
@@ -1308,7 +1316,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
           << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ldr + m;\n"
           << I4 << "++iw; next_rec += write_steps;\n"
           << I4 << "if (live) {\n";
-        for (int d : own) o << I4 << "    p[" << (d - 1) << " * ldr] = acc" << d << ";\n";
+        for (int d : own) o << I4 << "    p[" << (d - 1) << " * ldr] = " << "acc" << d << ";\n";
         o << I4 << "}\n" << I3 << "}\n";
         o << "#pragma nounroll\n";
         o << I3 << "for (int st = 0; st < S; ++st) {\n";
@@ -1321,7 +1329,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         // opaque per-stage values: the compiler must not hoist the re-reads of the step-start state out of the stage
         // loop (they would occupy registers for the whole step), nor turn the last-stage select into a branch that
         // sinks those loads to their use
-        o << I4 << "i64 yoff = 0; asm volatile(\"\" : \"+s\"(yoff));\n";
+        o << I4 << "const f64* ywp = " << (dense ? "basep" : "yw") << "; asm volatile(\"\" : \"+v\"(ywp));\n";
         o << I4 << "unsigned long long lastmask = last ? ~0ull : 0ull; asm volatile(\"\" : \"+v\"(lastmask));\n";
         o << I4 << "if (stages && live) {\n"
           << I4 << "    i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
@@ -1343,7 +1351,8 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8"}, "(const char*)xs", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
-                            for (int d : own) h << I4 << "const f64 yg" << d << " = " << (dense ? "basep" : "yw") << "[yoff + " << (d - 1) * 64 << "];\n";
+                            for (int d : own) h << I4 << "const f64 yg" << d << " = ywp[" << slot[d] * 64 << "];\n";
+
                         }, stats);
         o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
         g_ktab = nullptr;
@@ -1359,7 +1368,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
               << I4 << "    const f64 hq = dt * tab[S + q * S + st];\n"
               << I4 << "    f64* pq = pw + (i64)q * " << ndim * 64 << ";\n";
             for (int d : own)
-                o << I4 << "    pq[" << (d - 1) * 64 << "] = __builtin_fma(hq, k" << d << ", st == 0 ? yg" << d << " : pq[" << (d - 1) * 64 << "]);\n";
+                o << I4 << "    pq[" << slot[d] * 64 << "] = __builtin_fma(hq, k" << d << ", st == 0 ? yg" << d << " : pq[" << slot[d] * 64 << "]);\n";
             o << I4 << "}\n";
         }
         for (int d : own) {
@@ -1374,14 +1383,14 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
             o << I4 << "__syncthreads();\n";
         }
         o << I3 << "}\n";
-        // the new state is the start of the next step (stored after the barriers: a barrier waits for outstanding stores)
-        for (int d : own) o << I3 << "yw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        // the new state is the start of the next step
+        for (int d : own) o << I3 << "yw[" << slot[d] * 64 << "] = acc" << d << ";\n";
         o << I2 << "}\n";
         o << I2 << "if (live) {\n" << I3 << "if (y_out) {\n";
-        for (int d : own) o << I4 << "y_out[" << (d - 1) << " * ld + m] = acc" << d << ";\n";
+        for (int d : own) o << I4 << "y_out[" << (d - 1) << " * ld + m] = " << "acc" << d << ";\n";
         o << I3 << "}\n" << I3 << "if (write_final) {\n"
           << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
-        for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = acc" << d << ";\n";
+        for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = " << "acc" << d << ";\n";
         o << I3 << "}\n" << I2 << "}\n    }\n";
     }
     o << "}\n";
