@@ -50,10 +50,75 @@ class CooTensor(object):
         out.data = summed[keep]
         return out
 
+    @classmethod
+    def from_sorted_keys(cls, keys, data, shape):
+        """From linearised, strictly increasing indices: zeros dropped."""
+        keep = data != 0.
+        out = cls.__new__(cls)
+        out.shape = tuple(shape)
+        out.coords = np.array(np.unravel_index(keys[keep], shape))
+        out.data = np.ascontiguousarray(data[keep])
+        return out
+
     def todense(self):
         out = np.zeros(self.shape)
         out[tuple(self.coords)] = self.data
         return out
+
+
+class _BlockAccumulator(object):
+    """Sparse stand-in for the dense `(ndim+1)^3` array the tensor used to be assembled in (0.1 GB per copy at ndim 228, 8 GB at
+    ndim 1000; the reference assembles sparse dictionaries).  The assembly adds whole blocks, `T[rows, cols, k] += values`;
+    here a block contributes its non-zero entries as (linear index, value) pairs, and `result()` replays the blocks in
+    program order on the union of the touched entries -- every entry sees the same sequence of additions as in the dense
+    array, so the sums are bit-identical to it.  (All plain assignments of the assembly are first touches of their block, i.e.
+    additions to zero.)"""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        self._keys, self._vals = [], []
+
+    def add(self, index, values, sign=1.):
+        idx = np.broadcast_arrays(*[np.asarray(q) for q in index])
+        vals = np.broadcast_to(np.asarray(values, dtype=np.float64), idx[0].shape)
+        nz = vals != 0.
+        if not nz.any():
+            return
+        self._keys.append(np.ravel_multi_index(tuple(q[nz] for q in idx), self.shape))
+        self._vals.append(vals[nz] if sign > 0 else -vals[nz])
+
+    def sub(self, index, values):
+        self.add(index, values, -1.)
+
+    def result(self):
+        """(sorted unique linear indices, summed values)"""
+        if not self._keys:
+            return np.zeros(0, dtype=np.int64), np.zeros(0)
+        uniq = np.unique(np.concatenate(self._keys))
+        acc = np.zeros(len(uniq))
+        for k, v in zip(self._keys, self._vals):
+            pos = np.searchsorted(uniq, k)
+            if len(np.unique(pos)) == len(pos):
+                acc[pos] += v
+            else:                                   # an index twice in one block: sequential accumulation
+                np.add.at(acc, pos, v)
+        return uniq, acc
+
+
+def _swap12(keys, shape):
+    """linear index of (i, k, j) for linear indices of (i, j, k)"""
+    i, j, k = np.unravel_index(keys, shape)
+    return np.ravel_multi_index((i, k, j), shape)
+
+
+def _lookup(keys, vals, query):
+    """values of `query` indices in the sparse (sorted keys, vals), 0 where absent"""
+    pos = np.searchsorted(keys, query)
+    pos_c = np.minimum(pos, max(len(keys) - 1, 0))
+    hit = (pos < len(keys)) & (keys[pos_c] == query) if len(keys) else np.zeros(len(query), dtype=bool)
+    out = np.zeros(len(query))
+    out[hit] = vals[pos_c[hit]]
+    return out
 
 
 class QgsTensor(object):
@@ -95,21 +160,26 @@ class QgsTensor(object):
         par = self.params
         if par is None or self.atmospheric_inner_products is None:
             return
-        full = self._assemble_dense()
-        self.jacobian_tensor = CooTensor(full + np.swapaxes(full, 1, 2))
-        self.tensor = CooTensor(self.simplify_dense(full))
+        shape = (par.ndim + 1,) * 3
+        keys, vals = self._assemble().result()
+        self.jacobian_tensor, self.tensor = self.derive(keys, vals, shape)
 
     @staticmethod
-    def simplify_dense(full):
-        """Fold T_ijk with j > k onto T_ikj (upper-triangular in the last two indices)."""
-        lower = np.tril(np.ones(full.shape[1:], dtype=bool), -1)
-        out = full.copy()
-        out += np.swapaxes(np.where(lower[np.newaxis], full, 0.), 1, 2)
-        out[:, lower] = 0.
-        return out
+    def derive(keys, vals, shape):
+        """(jacobian tensor, simplified tensor) of the un-simplified tensor given as sorted linear indices + values:
+        J = T + T.swapaxes(1, 2) (qgtensor.py:700-722); the tensor itself with T_ijk, j > k folded onto T_ikj
+        (qgtensor.py:724-746).  Entry by entry the same two-operand sums as on dense arrays."""
+        swapped = _swap12(keys, shape)
+        union = np.union1d(keys, swapped)
+        own = _lookup(keys, vals, union)
+        mirror = _lookup(keys, vals, _swap12(union, shape))
+        jac = CooTensor.from_sorted_keys(union, own + mirror, shape)
+        _, j, k = np.unravel_index(union, shape)
+        folded = np.where(j < k, own + mirror, np.where(j == k, own, 0.))
+        return jac, CooTensor.from_sorted_keys(union, folded, shape)
 
-    def _assemble_dense(self):
-        """Rank-3 part of the tensor, dense.  With dynamic reference temperatures (`offset` = 1) the temperature fields
+    def _assemble(self):
+        """Rank-3 part of the tensor as a `_BlockAccumulator` (un-simplified).  With dynamic reference temperatures (`offset` = 1) the temperature fields
         carry a 0-th (constant) mode: their inner products arrays are one larger than the streamfunction ones, and the
         streamfunction equations skip index 0 (qgtensor.py:175-178: `jo = j + offset`)."""
         par = self.params
@@ -123,7 +193,7 @@ class QgsTensor(object):
         ndim = par.ndim
         natm = nvar[0]
         o = 1 if par.dynamic_T else 0
-        T = np.zeros((ndim + 1, ndim + 1, ndim + 1))
+        T = _BlockAccumulator((ndim + 1, ndim + 1, ndim + 1))
 
         psi = np.arange(natm) + 1                                   # tensor index of psi_a,j
         theta_all = np.arange(nvar[1]) + par.variables_range[0] + 1  # theta_a,j (j = 0: T_a,0 with dynamic_T)
@@ -146,62 +216,62 @@ class QgsTensor(object):
         # ---- psi_a equations (qgtensor.py:231-265) -------------------------------------------------
         rows = psi
         v = a_inv @ c[o:, o:]                                       # [i, j]
-        T[rows[:, None], psi[None, :], 0] -= v * beta
-        T[rows[:, None], psi[None, :], 0] -= (kd * eye) / 2
-        T[rows[:, None], theta[None, :], 0] = (kd * eye) / 2
+        T.sub((rows[:, None], psi[None, :], 0), v * beta)
+        T.sub((rows[:, None], psi[None, :], 0), (kd * eye) / 2)
+        T.add((rows[:, None], theta[None, :], 0), (kd * eye) / 2)
         if hk is not None:
             oro = np.einsum('il,ljk->ijk', a_inv, g_oro[o:, o:, o:]) @ hk      # a_inv[i,:] @ g[:, j, :] @ hk
-            T[rows[:, None], psi[None, :], 0] -= oro / 2
-            T[rows[:, None], theta[None, :], 0] += oro / 2
+            T.sub((rows[:, None], psi[None, :], 0), oro / 2)
+            T.add((rows[:, None], theta[None, :], 0), oro / 2)
         vb = np.einsum('il,ljk->ijk', a_inv, b[o:, o:, o:])
-        T[rows[:, None, None], psi[None, :, None], psi[None, None, :]] = - vb
-        T[rows[:, None, None], theta[None, :, None], theta[None, None, :]] = - vb
+        T.add((rows[:, None, None], psi[None, :, None], psi[None, None, :]), - vb)
+        T.add((rows[:, None, None], theta[None, :, None], theta[None, None, :]), - vb)
         if ocean:
             noc = nvar[2]
             psio = np.arange(noc) + par.variables_range[1] + 1
             v = a_inv @ np.asarray(aips._d)[o:, o:]
-            T[rows[:, None], psio[None, :], 0] += v * kd / 2
+            T.add((rows[:, None], psio[None, :], 0), v * kd / 2)
 
         # ---- theta_a equations (qgtensor.py:268-338) -------------------------------------------------
         rows = theta_all
         if par.Cpa is not None:
-            T[rows, 0, 0] -= a_theta @ u @ np.asarray(par.Cpa, dtype=float)
+            T.sub((rows, 0, 0), a_theta @ u @ np.asarray(par.Cpa, dtype=float))
         if atp.hd is not None and atp.thetas is not None:
             val = - a_theta @ u @ np.asarray(atp.thetas, dtype=float)
-            T[rows, 0, 0] += val * float(atp.hd)
+            T.add((rows, 0, 0), val * float(atp.hd))
         v = a_theta @ a[:, o:]
-        T[rows[:, None], psi[None, :], 0] += v * kd * sig0 / 2
-        T[rows[:, None], theta[None, :], 0] -= v * (kd / 2 + 2 * kdp) * sig0
+        T.add((rows[:, None], psi[None, :], 0), v * kd * sig0 / 2)
+        T.sub((rows[:, None], theta[None, :], 0), v * (kd / 2 + 2 * kdp) * sig0)
         v = - a_theta @ c[:, o:]
-        T[rows[:, None], theta[None, :], 0] += v * beta * sig0
+        T.add((rows[:, None], theta[None, :], 0), v * beta * sig0)
         if hk is not None:
             oro = np.einsum('il,ljk->ijk', a_theta, g_oro[:, o:, o:]) @ hk
-            T[rows[:, None], theta[None, :], 0] -= sig0 * oro / 2
-            T[rows[:, None], psi[None, :], 0] += sig0 * oro / 2
+            T.sub((rows[:, None], theta[None, :], 0), sig0 * oro / 2)
+            T.add((rows[:, None], psi[None, :], 0), sig0 * oro / 2)
         vb = np.einsum('il,ljk->ijk', a_theta, b[:, o:, o:])
         vg = np.einsum('il,ljk->ijk', a_theta, g[:, o:, o:])
-        T[rows[:, None, None], psi[None, :, None], theta[None, None, :]] = - vb * sig0
-        T[rows[:, None, None], theta[None, :, None], psi[None, None, :]] = - vb * sig0
-        T[rows[:, None, None], psi[None, :, None], theta[None, None, :]] += vg
+        T.add((rows[:, None, None], psi[None, :, None], theta[None, None, :]), - vb * sig0)
+        T.add((rows[:, None, None], theta[None, :, None], psi[None, None, :]), - vb * sig0)
+        T.add((rows[:, None, None], psi[None, :, None], theta[None, None, :]), vg)
         v = a_theta @ u
         if par.Lpa is not None:
-            T[rows[:, None], theta_all[None, :], 0] += v * float(atp.sc) * par.Lpa
+            T.add((rows[:, None], theta_all[None, :], 0), v * float(atp.sc) * par.Lpa)
         if par.LSBpa is not None:
-            T[rows[:, None], theta_all[None, :], 0] += v * par.LSBpa
+            T.add((rows[:, None], theta_all[None, :], 0), v * par.LSBpa)
         if atp.hd is not None:
-            T[rows[:, None], theta_all[None, :], 0] += v * float(atp.hd)
+            T.add((rows[:, None], theta_all[None, :], 0), v * float(atp.hd))
         if ocean:
             v = - a_theta @ np.asarray(aips._d)[:, o:]
-            T[rows[:, None], psio[None, :], 0] += v * sig0 * kd / 2
+            T.add((rows[:, None], psio[None, :], 0), v * sig0 * kd / 2)
         if ocean or ground_temp:
             nsurf = nvar[3] if ocean else nvar[2]
             dT_all = np.arange(nsurf) + (par.variables_range[2] if ocean else par.variables_range[1]) + 1
             dT = dT_all[o:]
         if (ocean or ground_temp) and par.Lpa is not None:
             v = - a_theta @ np.asarray(aips._s)
-            T[rows[:, None], dT_all[None, :], 0] += v * par.Lpa / 2
+            T.add((rows[:, None], dT_all[None, :], 0), v * par.Lpa / 2)
             if par.LSBpgo is not None:
-                T[rows[:, None], dT_all[None, :], 0] += v * par.LSBpgo
+                T.add((rows[:, None], dT_all[None, :], 0), v * par.LSBpgo)
 
         if ocean:
             # ---- psi_o equations (qgtensor.py:342-364) ---------------------------------------------------
@@ -210,26 +280,26 @@ class QgsTensor(object):
             M_psio = np.linalg.inv(bM[o:, o:] + par.G * bU[o:, o:])
             rows = psio
             v = M_psio @ bK[o:, o:] * float(op.d)
-            T[rows[:, None], psi[None, :], 0] += v
-            T[rows[:, None], theta[None, :], 0] -= v
+            T.add((rows[:, None], psi[None, :], 0), v)
+            T.sub((rows[:, None], theta[None, :], 0), v)
             v = - M_psio @ bN[o:, o:]
-            T[rows[:, None], psio[None, :], 0] += v * beta
+            T.add((rows[:, None], psio[None, :], 0), v * beta)
             v = - M_psio @ bM[o:, o:]
-            T[rows[:, None], psio[None, :], 0] += v * (float(op.r) + float(op.d))
-            T[rows[:, None, None], psio[None, :, None], psio[None, None, :]] -= np.einsum('il,ljk->ijk', M_psio, bC[o:, o:, o:])
+            T.add((rows[:, None], psio[None, :], 0), v * (float(op.r) + float(op.d)))
+            T.sub((rows[:, None, None], psio[None, :, None], psio[None, None, :]), np.einsum('il,ljk->ijk', M_psio, bC[o:, o:, o:]))
 
             # ---- delta T_o equations (qgtensor.py:367-389) -----------------------------------------------
             rows = dT_all
-            T[rows, 0, 0] += U_inv @ bW @ np.asarray(par.Cpgo, dtype=float)
+            T.add((rows, 0, 0), U_inv @ bW @ np.asarray(par.Cpgo, dtype=float))
             v = U_inv @ bW
-            T[rows[:, None], theta_all[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
+            T.add((rows[:, None], theta_all[None, :], 0), v * 2 * float(atp.sc) * par.Lpgo)
             if par.sbpa is not None:
-                T[rows[:, None], theta_all[None, :], 0] += v * par.sbpa
+                T.add((rows[:, None], theta_all[None, :], 0), v * par.sbpa)
             eye_o = np.eye(nvar[3], dtype=int)
-            T[rows[:, None], dT_all[None, :], 0] = - par.Lpgo * eye_o
+            T.add((rows[:, None], dT_all[None, :], 0), - par.Lpgo * eye_o)
             if par.sbpgo is not None:
-                T[rows[:, None], dT_all[None, :], 0] += - par.sbpgo * eye_o
-            T[rows[:, None, None], psio[None, :, None], dT[None, None, :]] -= np.einsum('il,ljk->ijk', U_inv, bO[:, o:, o:])
+                T.add((rows[:, None], dT_all[None, :], 0), - par.sbpgo * eye_o)
+            T.sub((rows[:, None, None], psio[None, :, None], dT[None, None, :]), np.einsum('il,ljk->ijk', U_inv, bO[:, o:, o:]))
 
         if ground_temp:
             # ---- delta T_g equations (qgtensor.py:392-409) -----------------------------------------------
@@ -237,15 +307,15 @@ class QgsTensor(object):
             bU, bW = np.asarray(bips._U), np.asarray(bips._W)
             U_inv = np.linalg.inv(bU)
             rows = dT_all
-            T[rows, 0, 0] += U_inv @ bW @ np.asarray(par.Cpgo, dtype=float)
+            T.add((rows, 0, 0), U_inv @ bW @ np.asarray(par.Cpgo, dtype=float))
             v = U_inv @ bW
-            T[rows[:, None], theta_all[None, :], 0] += v * 2 * float(atp.sc) * par.Lpgo
+            T.add((rows[:, None], theta_all[None, :], 0), v * 2 * float(atp.sc) * par.Lpgo)
             if par.sbpa is not None:
-                T[rows[:, None], theta_all[None, :], 0] += v * par.sbpa
+                T.add((rows[:, None], theta_all[None, :], 0), v * par.sbpa)
             eye_g = np.eye(ngr, dtype=int)
-            T[rows[:, None], dT_all[None, :], 0] = - par.Lpgo * eye_g
+            T.add((rows[:, None], dT_all[None, :], 0), - par.Lpgo * eye_g)
             if par.sbpgo is not None:
-                T[rows[:, None], dT_all[None, :], 0] += - par.sbpgo * eye_g
+                T.add((rows[:, None], dT_all[None, :], 0), - par.sbpgo * eye_g)
         return T
 
     # ---- I/O ------------------------------------------------------------------------------------------
@@ -332,10 +402,11 @@ class QgsTensorDynamicT(QgsTensor):
             return
         n1 = par.ndim + 1
         shape = (n1,) * 5
-        full3 = self._assemble_dense()
-        nz = np.nonzero(full3)
+        keys3, vals3 = self._assemble().result()
+        keep = vals3 != 0.
+        nz = np.unravel_index(keys3[keep], (n1,) * 3)
         coords = [np.vstack((np.array(nz), np.zeros((2, len(nz[0])), dtype=np.int64)))]    # (i, j, k, 0, 0)
-        data = [full3[nz]]
+        data = [vals3[keep]]
         for c, d in self._quartic_entries():
             coords.append(c)
             data.append(d)
