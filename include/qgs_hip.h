@@ -73,7 +73,8 @@ int64_t qgs_model_info(const qgs_model *m, int which);
  * stepper serves the trajectory integrations and f, and (ndim <= 243) LDS-resident tangent / adjoint kernels the
  * tangent pass; Df stays generic.  Rank-5 models have the register-resident kernels only.  In automatic mode
  * these are used when their code objects are already cached or the run is long enough to pay for the 20-40 s
- * compilation. */
+ * compilation.  The call also re-reads the kernel-selection knobs of INTEGRATION.md from the environment (they are read
+ * when a model is created and here, never inside a launch). */
 int qgs_model_set_kernel(qgs_model *m, int kind);
 
 /* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) -------------- */

@@ -381,6 +381,32 @@ struct KernelInfo {
     int vgprs = 0, sgprs = 0, lds = 0, scratch = 0;
 };
 
+// Kernel-selection overrides (developer knobs), read from the environment ONCE when a model is created -- the
+// launch paths only look at these fields.
+struct LaunchTuning {
+    int64_t wave_max_traj = -1;        // QGS_HIP_WAVE_MAX_TRAJ: largest ensemble on the wavefront-per-trajectory kernels (-1: measured crossovers)
+    int64_t lds_tgl_min_pairs = 0;     // QGS_HIP_LDS_TGL_MIN_PAIRS
+    int lds_force = -1;                // QGS_HIP_LDS=0|1: never / always the LDS-resident JIT kernels (-1: when cached or worth compiling)
+    bool generic_simple = false;       // QGS_HIP_GENERIC=simple: never the tiled generic stepper
+    int rk_variant = 0;                // QGS_HIP_RK_VARIANT=plain|split -> 1 | 2 (0: by ensemble size)
+    bool rk_spread_rec = true;         // QGS_HIP_RK_SPREAD_REC=0: burst record stores also for write_steps == 1
+    int64_t tgls_chunk = 0;            // QGS_HIP_TGLS_CHUNK: steps per trajectory / tangent pass pair (0: by the stage-record size)
+    size_t tgl_share_min_bytes = (size_t)256 << 20;   // QGS_HIP_TGL_SHARE_MIN_MB
+    bool tgl_plain = false;            // QGS_HIP_TGL_VARIANT=plain: never the shared-stage-state tangent kernel
+    void read_env()
+    {
+        if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) wave_max_traj = std::atoll(e);
+        if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MIN_PAIRS")) lds_tgl_min_pairs = std::atoll(e);
+        if (const char *e = std::getenv("QGS_HIP_LDS")) lds_force = (*e == '1') ? 1 : 0;
+        if (const char *e = std::getenv("QGS_HIP_GENERIC")) generic_simple = !std::strcmp(e, "simple");
+        if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) rk_variant = !std::strcmp(e, "plain") ? 1 : (!std::strcmp(e, "split") ? 2 : 0);
+        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) rk_spread_rec = (*e == '1');
+        if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) tgls_chunk = std::max<int64_t>(1, std::atoll(e));
+        if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) tgl_share_min_bytes = (size_t)std::atoll(e) << 20;
+        if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_plain = !std::strcmp(e, "plain");
+    }
+};
+
 }  // namespace
 
 struct qgs_model {
@@ -436,6 +462,7 @@ struct qgs_model {
     bool prefer_lds = false;          // register-resident kernels exist but would spill (rank 5 with many derived monomials)
     mutable std::map<std::string, bool> lds_on_disk;   // kernel name -> code object found in the kernel cache (checked once)
     qgs::CodegenOptions cg;
+    LaunchTuning tune;
     // compiled specialised kernels, one module per kernel (keyed by the kernel name)
     std::map<std::string, hipModule_t> modules;
     std::map<std::string, hipFunction_t> functions;
@@ -745,18 +772,14 @@ bool use_wave(const qgs_model *m, int64_t n_traj, int s, const double *a)
     // members (MAOOAM 6x6: 29 vs 102 us per RK4 step for one trajectory, 8.0 vs 20.4 ms per 200 steps at 256 members,
     // 30 vs 20 ms at 1024; T4 MAOOAM: 12 vs 27 us per step)
     int64_t limit = (m->max_row_terms <= 16) ? 2048 : (m->max_row_terms <= 32 ? 1024 : 512);
-    if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
+    if (m->tune.wave_max_traj >= 0) limit = m->tune.wave_max_traj;
     return n_traj <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.t.size()) && m->wave_der_ok_t &&
            qgs::tableau_is_subdiagonal(s, a);
 }
 
 // below this many (member, column) pairs the wavefront-per-pair kernel would be preferred to the LDS-resident tangent
 // kernel; measured (tools/tgls228.py): the LDS-resident one wins at every size (1 x 228 pairs: 3.8 vs 5.5 ms per 10 steps)
-int64_t lds_tgl_min_pairs()
-{
-    if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MIN_PAIRS")) return std::atoll(e);
-    return 0;
-}
+int64_t lds_tgl_min_pairs(const qgs_model *m) { return m->tune.lds_tgl_min_pairs; }
 
 // wavefront-per-(member, column) tangent kernel: against the specialised lane kernel it wins below 4096 pairs,
 // against the simple generic kernel (large ndim, latency-bound at ~350 ms per 10 steps) up to ~16k pairs
@@ -764,7 +787,7 @@ bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
 {
     if (m->kernel_kind != 0) return false;
     int64_t limit = m->spec_possible ? 4096 : 16384;
-    if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) limit = std::atoll(e);
+    if (m->tune.wave_max_traj >= 0) limit = m->tune.wave_max_traj;
     return pairs <= limit && s >= 1 && s <= 8 && qgs::wave_supported(m->ndim + (int)m->der.j.size()) && m->wave_der_ok_j &&
            qgs::tableau_is_subdiagonal(s, a);
 }
@@ -774,7 +797,7 @@ bool use_tgl_wave(const qgs_model *m, int64_t pairs, int s, const double *a)
 // is already there, for runs long enough to pay for the compilation, or when requested with qgs_model_set_kernel(m, 2).
 bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work)
 {
-    if (const char *e = std::getenv("QGS_HIP_LDS")) return *e == '1';
+    if (m->tune.lds_force >= 0) return m->tune.lds_force == 1;
     if (m->kernel_kind == 2) return true;
     if (m->prefer_lds) return true;         // the alternative is a register-resident kernel that spills and takes minutes to compile
     const std::string name = qgs::kernel_name(k, 0, m->cg);
@@ -807,7 +830,7 @@ bool use_lds_tgl(const qgs_model *m, int64_t pairs, int64_t n_steps, int s, cons
 // tiled generic stepper: sub-diagonal tableau, stage state fits one workgroup's LDS
 bool use_tiled(const qgs_model *m, int s, const double *a)
 {
-    if (const char *e = std::getenv("QGS_HIP_GENERIC")) if (!std::strcmp(e, "simple")) return false;
+    if (m->tune.generic_simple) return false;
     if (m->rank != 3) return false;                                   // the tiled stream holds two factors per term
     return s >= 1 && s <= 8 && qgs::tiled_supported(m->ndim) && qgs::tableau_is_subdiagonal(s, a);
 }
@@ -985,6 +1008,7 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     if (r5 && upload_reduced(m)) { qgs_model_destroy(m); return -1; }
     classify_model(m);
     apply_env_options(m->cg);
+    m->tune.read_env();
     if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
     *out = m;
     return 0;
@@ -1036,6 +1060,8 @@ int qgs_model_set_kernel(qgs_model *m, int kind)
     if (kind < 0 || kind > 2) return fail("kind must be 0, 1 or 2");
     if (kind == 2 && !m->spec_possible && !m->lds_spec_possible) return fail("specialised kernels are not available for this ndim");
     m->kernel_kind = kind;
+    m->tune = LaunchTuning();             // the selection knobs are read here and at model creation, never in a launch path
+    m->tune.read_env();
     return 0;
 }
 
@@ -1186,13 +1212,10 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         const int R = m->cg.row_split;
         const int64_t waves = (n_traj + 63) / 64;
         bool split = R > 1 && m->ndim >= 2 * R && waves * R <= (int64_t)m->n_simd * 5 / 2;
-        if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) {
-            if (!std::strcmp(e, "plain")) split = false;
-            if (!std::strcmp(e, "split") && R > 1 && m->ndim >= 2 * R) split = true;
-        }
+        if (m->tune.rk_variant == 1) split = false;
+        if (m->tune.rk_variant == 2 && R > 1 && m->ndim >= 2 * R) split = true;
         // every step is a record (write_steps == 1, the reference's default): the variant with the record stores spread over the step
-        bool spread = !split && m->cg.rk_spread_rec && write_steps == 1 && ld >= 64 * waves;
-        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) spread = spread && (*e == '1');
+        const bool spread = !split && m->cg.rk_spread_rec && m->tune.rk_spread_rec && write_steps == 1 && ld >= 64 * waves;
         hipFunction_t f;
         std::string name;
         if (get_function(m, split ? qgs::Kernel::RkSplit : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk), s, &f, &name)) return -1;
@@ -1285,7 +1308,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
     // Steps are processed in chunks: trajectory kernel (stores every stage state) -> tangent kernel.
     const size_t stage_bytes_per_step = sizeof(double) * (size_t)s * A;
     int64_t chunk = std::max<int64_t>(1, (int64_t)((size_t)768 << 20) / (int64_t)stage_bytes_per_step);
-    if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) chunk = std::max<int64_t>(1, std::atoll(e));
+    if (m->tune.tgls_chunk > 0) chunk = m->tune.tgls_chunk;
     chunk = std::min<int64_t>(chunk, std::max<int64_t>(1, n_steps));
     if (m->stages.ensure(stage_bytes_per_step * (size_t)chunk)) return -1;
     if (m->b_state2.ensure(sizeof(double) * (size_t)A)) return -1;
@@ -1337,7 +1360,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         }
         // --- tangent / adjoint pass ---
         const bool lds_tgl = (!spec || !m->spec_jac_possible) && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
-        if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs())) {
+        if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs(m))) {
             if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
                                n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
         } else if (dense && m->spec_jac_possible) {
@@ -1359,12 +1382,11 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             // 256 MB Infinity Cache every column can afford to read it (one-wavefront kernel 3-8 % ahead: 1.11 vs 1.21 ms at
             // 16 384 members, 189 MB); beyond that the re-reads go to HBM and sharing wins 1.5x (65 536 members, 755 MB:
             // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
-            size_t share_min = (size_t)256 << 20;
-            if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) share_min = (size_t)std::atoll(e) << 20;
+            const size_t share_min = m->tune.tgl_share_min_bytes;
             bool share_x = C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
                            (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
                            stage_bytes_per_step * (size_t)(end - begin) >= share_min;
-            if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) share_x = share_x && std::strcmp(e, "plain") != 0;
+            share_x = share_x && !m->tune.tgl_plain;
             hipFunction_t f2;
             std::string n2;
             if (get_function(m, share_x ? qgs::Kernel::TglX : qgs::Kernel::Tgl, s, &f2, &n2)) return -1;

@@ -263,10 +263,14 @@ def test_tgls_chunked_equals_unchunked(models, monkeypatch):
     for kind in _kinds(m):
         m.set_kernel(KINDS[kind])
         monkeypatch.delenv('QGS_HIP_TGLS_CHUNK', raising=False)
+        m.set_kernel(KINDS[kind])                            # (the selection knobs are read at set_kernel / model creation)
         a_tr, a_fm = m.rk_tgls_integrate(t, ic, tg, 1, 4, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         monkeypatch.setenv('QGS_HIP_TGLS_CHUNK', '5')
+        m.set_kernel(KINDS[kind])
         b_tr, b_fm = m.rk_tgls_integrate(t, ic, tg, 1, 4, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert np.array_equal(a_tr, b_tr) and np.array_equal(a_fm, b_fm), kind
+    monkeypatch.delenv('QGS_HIP_TGLS_CHUNK', raising=False)
+    m.set_kernel(0)
 
 
 def test_specialised_equals_generic_long_run(models):
@@ -432,6 +436,7 @@ def test_shared_stage_state_tangent_kernel(models, n_traj, n_tg):
     import os
     os.environ['QGS_HIP_TGL_SHARE_MIN_MB'] = '0'          # in production only stage records beyond the Infinity Cache take it
     g, m = load_golden('m36'), models('m36')
+    m.set_kernel(2)                                           # re-reads the selection knobs
     ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
     rng = np.random.RandomState(1000 * n_traj + n_tg)
     ic = rng.rand(n_traj, g.ndim) * 0.01
@@ -448,13 +453,15 @@ def test_shared_stage_state_tangent_kernel(models, n_traj, n_tg):
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (d, ws, adj)
         os.environ['QGS_HIP_TGL_VARIANT'] = 'plain'
         try:
+            m.set_kernel(2)                                   # re-reads the selection knobs
             _, fm1 = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
             assert m.last_kernel_info()['name'] == 'qgs_spec_tgl_s%d' % len(b)
         finally:
             del os.environ['QGS_HIP_TGL_VARIANT']
+            m.set_kernel(2)
         assert np.array_equal(fm, fm1)                       # same arithmetic, only the way the stage states arrive differs
     del os.environ['QGS_HIP_TGL_SHARE_MIN_MB']
-    m.set_kernel(0)
+    m.set_kernel(0)                                           # back to the defaults
 
 
 def test_lds_resident_kernels_on_a_second_tensor_ndim72():

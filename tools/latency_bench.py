@@ -26,6 +26,7 @@ for n in [int(x) for x in os.environ.get("LB_SIZES", "1,16,64,256,1024,2048,4096
     out = []
     for label, env in (('wave', '1000000'), ('lane', '0')):
         os.environ['QGS_HIP_WAVE_MAX_TRAJ'] = env
+        m.set_kernel(0)                    # the selection knobs are read at set_kernel / model creation
         m.rk_integrate_device(n, ld, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); m.rk_integrate_device(n, ld, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st); e1.record(); torch.cuda.synchronize()

@@ -32,6 +32,7 @@ for n in (1024, 4096, 16384, 65536, 131072):
             os.environ['QGS_HIP_TGL_VARIANT'] = 'plain'
         else:
             os.environ.pop('QGS_HIP_TGL_VARIANT', None)
+        m.set_kernel(2)                        # the selection knobs are read at set_kernel / model creation
         ts = []
         for _ in range(4):
             torch.cuda.synchronize(); t0 = time.perf_counter()
