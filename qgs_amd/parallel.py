@@ -142,6 +142,8 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device())
         device = torch.device(device)
+        if device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         b, c, a = resolve_tableau(b, c, a)
         nrec = _lib.n_records(grid, write_steps)
         if ens.n_local > 0:
