@@ -40,3 +40,18 @@ def test_cache_key_separates_compilers(tmp_path):
                        env=dict(os.environ, QGS_HIP_CACHE_DIR=str(tmp_path), QGS_HIP_INPROC_RTC=inproc))
         counts.append(len([f for f in os.listdir(str(tmp_path)) if f.endswith('.hsaco')]))
     assert counts[0] > 0 and counts[1] == 2 * counts[0]
+
+
+def test_launcher_starts_one_child_per_rank_and_reports_their_failure():
+    """`launch_ranks` with the GPU count faked to 2 (none here): both children start as ranks (RANK / WORLD_SIZE set, so they do
+    not try to launch again), find no GPU, exit 1 -- and the parent says which ranks failed instead of hanging or exiting 2."""
+    code = ("import sys\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "bench.visible_gpus = lambda: 2\n"
+            "sys.exit(bench.launch_ranks(2, ['--gpus', '2', '--steps', '1', '--warmup', '0']))\n" % REPO)
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    err = p.stderr.decode()
+    assert p.returncode == 1, err[-2000:]
+    assert 'no GPU visible' in err and 'ranks failed (rank, exit code): [(0, 1), (1, 1)]' in err
+    assert p.stdout.decode().strip() == ''
