@@ -79,43 +79,43 @@ class ScaleParams(Params):
 
     def __init__(self, dic=None):
         Params.__init__(self, dic)
-        self.scale = ScalingParameter(5.e6, units='[m]', description="characteristic space scale (L*pi)", dimensional=True)
-        self.f0 = ScalingParameter(1.032e-4, units='[s^-1]', description="Coriolis parameter at the middle of the domain",
+        self.scale = ScalingParameter(5.e6, units='[m]', description="space scale of the model, pi times the length L", dimensional=True)
+        self.f0 = ScalingParameter(1.032e-4, units='[s^-1]', description="Coriolis parameter at the central latitude of the domain",
                                    dimensional=True)
-        self.n = ScalingParameter(1.3e0, description="aspect ratio (n = 2 L_y / L_x)")
-        self.rra = ScalingParameter(6370.e3, units='[m]', description="earth radius", dimensional=True)
-        self.phi0_npi = ScalingParameter(0.25e0, description="latitude expressed in fraction of pi")
-        self.deltap = ScalingParameter(5.e4, units='[Pa]', description='pressure difference between the two atmospheric layers',
+        self.n = ScalingParameter(1.3e0, description="domain aspect ratio n = 2 Ly / Lx")
+        self.rra = ScalingParameter(6370.e3, units='[m]', description="radius of the Earth", dimensional=True)
+        self.phi0_npi = ScalingParameter(0.25e0, description="central latitude as a fraction of pi")
+        self.deltap = ScalingParameter(5.e4, units='[Pa]', description='pressure difference separating the two layers of the atmosphere',
                                        dimensional=True)
-        self.Ha = ScalingParameter(8500., units='[m]', description="Average height of the 500 hPa pressure level at midlatitude",
+        self.Ha = ScalingParameter(8500., units='[m]', description="mean mid-latitude height of the 500 hPa surface",
                                    dimensional=True)
         self.set_params(dic)
 
     @property
     def L(self):
-        return ScalingParameter(float(self.scale) / np.pi, units='[m]', description='Typical length scale L', dimensional=True)
+        return ScalingParameter(float(self.scale) / np.pi, units='[m]', description='length scale L of the non-dimensionalisation', dimensional=True)
 
     @property
     def L_y(self):
-        return ScalingParameter(float(self.scale), units='[m]', description='The meridional extent of the model domain',
+        return ScalingParameter(float(self.scale), units='[m]', description='north-south extent of the domain',
                                 dimensional=True)
 
     @property
     def L_x(self):
         return ScalingParameter(2 * float(self.scale) / float(self.n), units='[m]',
-                                description='The zonal extent of the model domain', dimensional=True)
+                                description='east-west extent of the domain', dimensional=True)
 
     @property
     def phi0(self):
         return ScalingParameter(float(self.phi0_npi) * np.pi, units='[rad]',
-                                description="The reference latitude of the center of the domain", dimensional=True)
+                                description="latitude of the centre of the domain", dimensional=True)
 
     @property
     def beta(self):
         phi0 = float(self.phi0)
         return Parameter(float(self.L) / float(self.rra) * np.cos(phi0) / np.sin(phi0), input_dimensional=False,
                          units='[m^-1][s^-1]', scale_object=self,
-                         description="Meridional gradient of the Coriolis parameter at phi_0")
+                         description="beta: meridional derivative of the Coriolis parameter at phi_0")
 
 
 class AtmosphericParams(Params):
@@ -126,17 +126,17 @@ class AtmosphericParams(Params):
         Params.__init__(self, dic)
         self._scale_params = scale_params
         self.kd = Parameter(0.1, input_dimensional=False, scale_object=scale_params, units='[s^-1]',
-                            description="atmosphere bottom friction coefficient")
+                            description="friction coefficient between the lower atmospheric layer and the surface")
         self.kdp = Parameter(0.01, input_dimensional=False, scale_object=scale_params, units='[s^-1]',
-                             description="atmosphere internal friction coefficient")
+                             description="friction coefficient between the two atmospheric layers")
         self.sigma = Parameter(0.2e0, input_dimensional=False, scale_object=scale_params, units='[m^2][s^-2][Pa^-2]',
-                               description="static stability of the atmosphere")
+                               description="atmospheric static stability")
         self.set_params(dic)
 
     @property
     def sig0(self):
         return Parameter(float(self.sigma) / 2, input_dimensional=False, scale_object=self._scale_params,
-                         units='[m^2][s^-2][Pa^-2]', description="0.5 * static stability of the atmosphere")
+                         units='[m^2][s^-2][Pa^-2]', description="half the atmospheric static stability")
 
 
 class _SpectralField(object):
@@ -164,7 +164,7 @@ class AtmosphericTemperatureParams(Params, _SpectralField):
         Params.__init__(self, dic)
         self._scale_params = scale_params
         self.hd = Parameter(0.045, input_dimensional=False, units='[s]', scale_object=scale_params,
-                            description="Newtonian cooling coefficient")
+                            description="coefficient of the Newtonian cooling")
         self.thetas = None
         self.gamma = None
         self.C = None
@@ -207,13 +207,13 @@ class OceanicParams(Params):
         Params.__init__(self, dic)
         self._scale_params = scale_params
         self.gp = Parameter(3.1e-2, units='[m][s^-2]', return_dimensional=True, scale_object=scale_params,
-                            description='reduced gravity')
+                            description='reduced gravity of the ocean layer')
         self.r = Parameter(1.e-8, units='[s^-1]', scale_object=scale_params,
-                           description="frictional coefficient at the bottom of the ocean")
+                           description="friction coefficient at the ocean bottom")
         self.h = Parameter(5.e2, units='[m]', return_dimensional=True, scale_object=scale_params,
-                           description="depth of the water layer of the ocean")
+                           description="depth of the active ocean layer")
         self.d = Parameter(1.e-8, units='[s^-1]', scale_object=scale_params,
-                           description="strength of the ocean-atmosphere mechanical coupling")
+                           description="mechanical coupling strength between ocean and atmosphere")
         self.set_params(dic)
 
 
@@ -224,7 +224,7 @@ class _SurfaceTemperatureParams(Params, _SpectralField):
         Params.__init__(self, dic)
         self._scale_params = scale_params
         self.gamma = Parameter(2.e8, units='[J][m^-2][K^-1]', scale_object=scale_params, return_dimensional=True,
-                               description='specific heat capacity of the ' + self._what)
+                               description='heat capacity (specific) of the ' + self._what)
         self.C = None
         self.T0 = None
         self.dynamic_T = None
@@ -327,9 +327,9 @@ class QgParams(Params):
         self.time_unit = 'days'
 
         self.rr = Parameter(287.058e0, return_dimensional=True, units='[J][kg^-1][K^-1]', scale_object=sp,
-                            description="gas constant of dry air")
+                            description="dry-air gas constant")
         self.sb = Parameter(5.67e-8, return_dimensional=True, units='[J][m^-2][s^-1][K^-4]', scale_object=sp,
-                            description="Stefan-Boltzmann constant")
+                            description="constant of Stefan and Boltzmann")
         self.set_params(dic)
 
     # ---- derived nondimensional quantities (params.py:946-1076) ----------------------------------
@@ -596,7 +596,7 @@ class QgParams(Params):
             gotp.set_insolation(self.nmod[0] * [0.e0])
             gotp.set_insolation(350.0, 0)
             gotp.T0 = Parameter(285.0, units='[K]', scale_object=self.scale_params, return_dimensional=True,
-                                description="stationary solution for the 0-th order oceanic temperature")
+                                description="zeroth-order stationary ocean temperature")
 
     def set_atmospheric_modes(self, basis, auto=False):
         """Configure the atmosphere from a basis object (params.py:1529-1568)."""
@@ -725,7 +725,7 @@ class QgParams(Params):
         atp.thetas = None
         atp.hd = None
         atp.gamma = Parameter(1.e7, units='[J][m^-2][K^-1]', scale_object=sp, return_dimensional=True,
-                              description='specific heat capacity of the atmosphere')
+                              description='heat capacity (specific) of the atmosphere')
         if self.dynamic_T:
             atp.set_insolation((self.nmod[0] + 1) * [0.e0], None, True)
             atp.set_insolation(100.0, 0, True)
@@ -734,11 +734,11 @@ class QgParams(Params):
             atp.set_insolation(self.nmod[0] * [0.e0])
             atp.set_insolation(100.0, 0)
             atp.T0 = Parameter(270.0, units='[K]', scale_object=sp, return_dimensional=True,
-                               description="stationary solution for the 0-th order atmospheric temperature")
-        atp.eps = Parameter(0.76e0, input_dimensional=False, description="emissivity coefficient for the grey-body atmosphere")
-        atp.sc = Parameter(1., input_dimensional=False, description="ratio of surface to atmosphere temperature")
+                               description="zeroth-order stationary atmospheric temperature")
+        atp.eps = Parameter(0.76e0, input_dimensional=False, description="grey-body emissivity of the atmosphere")
+        atp.sc = Parameter(1., input_dimensional=False, description="surface-to-atmosphere temperature ratio")
         atp.hlambda = Parameter(20.00, units='[W][m^-2][K^-1]', scale_object=sp, return_dimensional=True,
-                                description="sensible+turbulent heat exchange between ocean/ground and atmosphere")
+                                description="sensible and turbulent heat exchange coefficient between the surface (ocean or ground) and the atmosphere")
 
     @property
     def ablocks(self):
@@ -780,7 +780,7 @@ class QgParams(Params):
             self.gotemperature_params.set_insolation(350.0, 0)
             self.gotemperature_params.T0 = Parameter(285.0, units='[K]', scale_object=self.scale_params,
                                                      return_dimensional=True,
-                                                     description="stationary solution for the 0-th order oceanic temperature")
+                                                     description="zeroth-order stationary ocean temperature")
             if self.ground_params is not None:
                 self.ground_params.hk = None
 
@@ -808,4 +808,4 @@ class QgParams(Params):
             self.gotemperature_params.set_insolation(350.0, 0)
             self.gotemperature_params.T0 = Parameter(285.0, units='[K]', scale_object=self.scale_params,
                                                      return_dimensional=True,
-                                                     description="stationary solution for the 0-th order oceanic temperature")
+                                                     description="zeroth-order stationary ocean temperature")
