@@ -1432,6 +1432,12 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
     const NodeFn node = [ndim, xs_bytes, MT](int n) {
         return n <= ndim ? LdsNode{xs_bytes + (int64_t)(n - 1) * 512, 0} : LdsNode{(int64_t)(n - ndim - 1) * (MT * 8), 1};
     };
+    // private step-start buffer laid out per wavefront behind an opaque base pointer, as in emit_rk_lds_kernel
+    std::vector<int> slot(ndim + 1, 0);
+    {
+        int q = 0;
+        for (int w = 0; w < W; ++w) for (int d : owns[w]) slot[d] = q++;
+    }
     std::ostringstream o;
     std::vector<KTable> tables(W);
     o << "\n// " << (adjoint ? "adjoint" : "tangent") << " model, run-time stage count, " << MT << " members x " << NC << " columns per workgroup of " << W
@@ -1470,7 +1476,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
         o << "\n";
         const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
         for (int d : own) o << I2 << "f64 acc" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
-        for (int d : own) o << I2 << "ws[" << (d - 1) << "][lane] = acc" << d << "; vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        for (int d : own) o << I2 << "ws[" << (d - 1) << "][lane] = acc" << d << "; vw[" << slot[d] * 64 << "] = acc" << d << ";\n";
         o << I2 << "if (step_begin < step_end) QGS_LOAD_XS(stages);\n";
         o << I2 << "__syncthreads();\n";
         if (!der.empty()) {
@@ -1492,7 +1498,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
         o << I4 << "const bool last = (st == S - 1);\n";
         o << I4 << "const f64 hb = dt * tab[st] * inverse;\n";                      // inverse = +-1: exact
         o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st] * inverse;\n";
-        o << I4 << "i64 yoff = 0; asm volatile(\"\" : \"+s\"(yoff));\n";
+        o << I4 << "const f64* vwp = vw; asm volatile(\"\" : \"+v\"(vwp));\n";
         o << I4 << "unsigned long long lastmask = last ? ~0ull : 0ull; asm volatile(\"\" : \"+v\"(lastmask));\n";
         g_ktab = &tables[w];
         o << I4 << "kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
@@ -1506,7 +1512,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
         const int hook_phase = std::max(0, (int)phases.size() - std::max(0, opt.lds_yload_ahead));
         emit_lds_phases(so, I4, phases, node, {"lane8", "xl8"}, "(const char*)lds_all", opt.lds_group, hook_phase,
                         [&](std::ostringstream &h) {
-                            for (int d : own) h << I4 << "const f64 yg" << d << " = vw[yoff + " << (d - 1) * 64 << "];\n";
+                            for (int d : own) h << I4 << "const f64 yg" << d << " = vwp[" << slot[d] * 64 << "];\n";
                         }, stats);
         o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
         g_ktab = nullptr;
@@ -1527,7 +1533,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
             o << I4 << "__syncthreads();\n";
         }
         o << I3 << "}\n";
-        for (int d : own) o << I3 << "vw[" << (d - 1) * 64 << "] = acc" << d << ";\n";
+        for (int d : own) o << I3 << "vw[" << slot[d] * 64 << "] = acc" << d << ";\n";
         o << I2 << "}\n";
         o << I2 << "if (live) {\n" << I3 << "if (w_out_p) {\n";
         for (int d : own) o << I4 << "w_out_p[" << (d - 1) << " * L + l] = acc" << d << ";\n";
