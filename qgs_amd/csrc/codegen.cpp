@@ -205,7 +205,8 @@ struct Acc {
     bool init = false;
     const char *indent;
     Acc(std::ostringstream &os, const std::string &n, const char *ind) : o(os), name(n), indent(ind) {}
-    void set_const(double c) { o << indent << "f64 " << name << " = " << lit(c) << ";\n"; init = true; }
+    // (one v_mov_b64 from the SGPR pair; the compiler's own copy is two v_mov_b32)
+    void set_const(double c) { o << indent << "f64 " << name << " = qgs_mov64(" << lit(c) << ");\n"; init = true; }
     // r += c * expr
     void add(const std::string &c, const std::string &expr)
     {
@@ -383,6 +384,26 @@ __device__ __forceinline__ i64 qgs_rec_index(i64 iw, i64 n_records, int backward
 // step in a counter instead of dividing every step
 #define QGS_REC_INIT i64 iw = 0, next_rec = -1; \
     if (write_steps > 0) { iw = (step_begin + write_steps - 1) / write_steps; next_rec = iw * write_steps; }
+// a*b + c as the three-address v_fma_f64 (see emit_rk_kernel)
+__device__ __forceinline__ f64 qgs_fma3(f64 a, f64 b, f64 c)
+{
+    f64 d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a uniform double (SGPR pair) into a vector register with one v_mov_b64
+__device__ __forceinline__ f64 qgs_mov64(f64 c)
+{
+    f64 d;
+    asm("v_mov_b64 %0, %1" : "=v"(d) : "s"(c));
+    return d;
+}
+// the double whose low / high word sit in lanes `lane` / `lane + 1` of v
+__device__ __forceinline__ f64 qgs_lane_f64(unsigned v, int lane)
+{
+    const unsigned long long lo = __builtin_amdgcn_readlane(v, lane), hi = __builtin_amdgcn_readlane(v, lane + 1);
+    return __builtin_bit_cast(f64, (hi << 32) | lo);
+}
 // mask ? a : b on the bit patterns (mask is all ones or all zeros), branch-free
 __device__ __forceinline__ f64 qgs_bitsel(unsigned long long mask, f64 a, f64 b)
 {
@@ -467,12 +488,22 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const i64 m = live ? m0 : (n_traj - 1);   // tail lanes shadow the last member and never store\n";
     o << "    " << decl_list("y", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
-    for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
-    for (int st = 0; st + 1 < S; ++st) o << "    const f64 ta" << st << " = tab[" << (S + st) << "];\n";
+    // The 2S - 1 tableau entries sit in the lanes of ONE vector register (lane 2n / 2n + 1 = low / high word of tab[n]) and are
+    // read back with two v_readlane where a stage needs them.  As 14 loop-invariant SGPRs next to the coefficient
+    // pipeline's 64 they were spilled to lanes by the compiler anyway, and then reloaded as a block at every stage
+    // boundary and at the end of every step (86 v_readlane per RK4 step instead of 14).
+    o << "    unsigned tabw = 0;\n"
+      << "    if (threadIdx.x < " << 2 * (2 * S - 1) << ") tabw = ((const unsigned*)tab)[threadIdx.x];\n";
     emit_settle_loads(o, "    ", "y", all_rows(ndim));
     o << "    QGS_REC_INIT\n";
-    o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
-    o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    // The steps between two records are an inner loop of their own: what only the (cold) record block needs -- record
+    // pointer, leading dimension, counters -- is then not part of the hot loop's scalar state.
+    const bool nest = !spread_rec;
+    if (nest) o << "    i64 ti = step_begin;\n    while (ti < step_end) {\n";
+    else {
+        o << "    for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    }
     if (spread_rec) {
         // write_steps == 1: step ti is record ti; uniform (scalar) pointer to this workgroup's 64 columns of row 0
         o << "        f64* const prow = rec + qgs_rec_index(ti, n_records, backward) * " << ndim << " * ld + (i64)blockIdx.x * QGS_WAVE;\n";
@@ -484,6 +515,12 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         for (int d = 1; d <= ndim; ++d) o << "                p[" << (d - 1) << " * ld] = y" << d << ";\n";
         o << "            }\n        }\n";
     }
+    if (nest) {
+        o << "        i64 seg_end = step_end;\n"
+          << "        if (write_steps > 0 && next_rec < seg_end) seg_end = next_rec;    // next_rec > ti here\n"
+          << "        for (; ti < seg_end; ++ti) {\n"
+          << "        const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+    }
     o << "        " << decl_list("acc", ndim) << "\n";
     if (S > 1) o << "        " << decl_list("xa", ndim) << "\n";
     if (S > 2) o << "        " << decl_list("xb", ndim) << "\n";
@@ -492,8 +529,9 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         const std::string outn = (st % 2 == 0) ? "xa" : "xb";
         const bool last = (st == S - 1);
         o << "        {   // stage " << st << "\n";
-        o << "            const f64 hb = dt * tb" << st << ";\n";
-        if (!last) o << "            const f64 ha = dt * ta" << st << ";\n";
+        o << "            unsigned tw = tabw; asm volatile(\"\" : \"+v\"(tw));   // keeps the v_readlane inside the stage\n";
+        o << "            const f64 hb = dt * qgs_lane_f64(tw, " << 2 * st << ");\n";
+        if (!last) o << "            const f64 ha = dt * qgs_lane_f64(tw, " << 2 * (S + st) << ");\n";
         if (store_stages) {
             o << "            if (live) {\n                f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
             for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
@@ -508,15 +546,22 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         for (int i = 1; i <= ndim; ++i) {
             const std::string rn = "r" + std::to_string(i);
             emit_tend_row(so, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
-            so << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
-            if (!last) so << "            " << outn << i << " = __builtin_fma(ha, " << rn << ", y" << i << ");\n";
             if (spread_rec && (i - 1) % S == st) so << "            *(f64*)((char*)(prow + " << (i - 1) << " * ld) + lane8) = y" << i << ";\n";
+            // Whenever the addend stays live (y_i in every stage but the last) the sum is formed by an explicit three-address
+            // v_fma_f64 (qgs_fma3): the compiler otherwise picks the two-address v_fmac_f64 plus a v_mov_b64 copy of the
+            // addend (63 copies per RK4 step at ndim 36).  In the last stage y_i is dead (the stage input is xa / xb), so the new
+            // state is written straight into it and no end-of-step copy y = acc is left.
+            if (!last) so << "            " << outn << i << " = qgs_fma3(ha, " << rn << ", y" << i << ");\n";
+            if (st == 0 && !last) so << "            acc" << i << " = qgs_fma3(hb, " << rn << ", y" << i << ");\n";
+            else if (last && S > 1) so << "            y" << i << " = qgs_fma3(hb, " << rn << ", acc" << i << ");\n";
+            else so << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
         }
         o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
         g_ktab = nullptr;
         o << "        }\n";
     }
-    for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = acc" << d << ";\n";
+    if (S == 1) for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = acc" << d << ";\n";
+    if (nest) o << "        }\n";
     o << "    }\n";
     o << "    if (live) {\n";
     o << "        if (y_out) {\n";
