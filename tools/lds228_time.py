@@ -5,6 +5,8 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qgs_amd import _lib
+if os.environ.get('RK_AB_LIB'):                    # another build of the library (A/B across generator versions)
+    _lib.LIB_PATH = os.path.abspath(os.environ['RK_AB_LIB'])
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 't228.npz')); ndim = int(g['ndim'])
 m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval']); m.set_kernel(2)
