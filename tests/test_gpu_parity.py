@@ -243,6 +243,43 @@ def test_general_tableaus_on_the_specialised_stepper(models, name):
     m.set_kernel(0)
 
 
+@pytest.mark.parametrize('variant', ['plain', 'split'])
+@pytest.mark.parametrize('name', ['m36', 'rp20'])
+def test_subdiagonal_tableaus_of_one_to_three_stages(models, monkeypatch, name, variant):
+    """Euler, midpoint, Heun and Heun's third-order scheme on the fused stepper (`qgs_spec_rk_s<S>`, `qgs_spec_rkr_s<S>` when
+    every step is a record): the last stage writes the new state in place (not for S = 1, where the stage input is the
+    state itself), and the steps between two records are an inner loop -- record cadences that divide the run, that do not,
+    that exceed it; forward and backward; against the oracle (integrate.py:182-223)."""
+    from oracle.oracle import OracleModel
+    g, m = load_golden(name), models(name)
+    monkeypatch.setenv('QGS_HIP_RK_VARIANT', variant)               # one wavefront per 64 members / rows split over four
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    z = np.zeros
+    euler = (np.array([1.]), z(1), z((1, 1)))
+    a = z((2, 2)); a[1, 0] = .5
+    midpoint = (np.array([0., 1.]), np.array([0., .5]), a)
+    a = z((2, 2)); a[1, 0] = 1.
+    heun = (np.array([.5, .5]), np.array([0., 1.]), a)
+    a = z((3, 3)); a[1, 0] = 1. / 3; a[2, 1] = 2. / 3
+    heun3 = (np.array([.25, 0., .75]), np.array([0., 1. / 3, 2. / 3]), a)
+    ic = np.random.RandomState(7).rand(130, g.ndim) * 0.01
+    t = np.concatenate((np.arange(0., 1.3, 0.1), [1.3]))            # 13 steps
+    for b, c, a in (euler, midpoint, heun, heun3):
+        for d in (1, -1):
+            for ws in (0, 1, 4, 13, 50):
+                ref = ora.integrate_runge_kutta_jit(t, ic, d, ws, b, c, a, threads=4)
+                m.set_kernel(2)                                     # (re-reads the selection knobs)
+                out = m.rk_integrate(t, ic, d, ws, b, c, a)
+                kname = m.last_kernel_info()['name']
+                if variant == 'plain':
+                    assert kname == ('qgs_spec_rkr_s%d' if ws == 1 else 'qgs_spec_rk_s%d') % len(b), kname
+                else:
+                    assert kname.startswith('qgs_spec_rk'), kname
+                assert out.shape == ref.shape and rel_err(out, ref) < 1e-13, (len(b), d, ws, kname)
+    monkeypatch.delenv('QGS_HIP_RK_VARIANT')
+    m.set_kernel(0)
+
+
 def test_zero_steps_and_single_step(models):
     """n_time == 1 (no step): the only record is the initial condition (integrate.py:221)."""
     g, m = load_golden('a36'), models('a36')
