@@ -391,6 +391,14 @@ __device__ __forceinline__ f64 qgs_fma3(f64 a, f64 b, f64 c)
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// v -> row[lane] with `row` a uniform pointer, as the scalar-base form of the store (SGPR pair + 32-bit lane offset).  The
+// compiler forms a 64-bit vector address with one v_lshl_add_u64 per store instead (a VALU slot for a lone wavefront), also
+// when base and offset are handed to it separately; an opaque offset per store costs a v_mov_b32 each.  The store is not
+// tracked by the compiler's vmcnt bookkeeping, which only makes its own waits more conservative.
+__device__ __forceinline__ void qgs_store_row(f64* row, unsigned lane8, f64 v)
+{
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lane8), "v"(v), "s"(row) : "memory");
+}
 // a uniform double (SGPR pair) into a vector register with one v_mov_b64
 __device__ __forceinline__ f64 qgs_mov64(f64 c)
 {
@@ -482,7 +490,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const f64* __restrict__ dtime,  // directed time grid\n"
       << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
-    if (spread_rec) o << "    const unsigned lane8 = threadIdx.x * 8u;\n";
+    if (spread_rec || store_stages) o << "    const unsigned lane8 = threadIdx.x * 8u;\n";
     o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);   // tail lanes shadow the last member and never store\n";
@@ -533,9 +541,14 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         o << "            const f64 hb = dt * qgs_lane_f64(tw, " << 2 * st << ");\n";
         if (!last) o << "            const f64 ha = dt * qgs_lane_f64(tw, " << 2 * (S + st) << ");\n";
         if (store_stages) {
-            o << "            if (live) {\n                f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-            for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
-            o << "            }\n";
+            // scalar row pointer + lane offset, the leading dimension opaque per stage: with `sp[d * ld]` the compiler kept the
+            // 36 row offsets as loop-invariant SGPR pairs, spilled them to lanes and reloaded them in every stage
+            // (982 v_readlane + 933 v_writelane in the kernel)
+            o << "            {\n                i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
+              << "                f64* const srow = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ldr + (i64)blockIdx.x * QGS_WAVE;\n"
+              << "                if (live) {\n";
+            for (int d = 1; d <= ndim; ++d) o << "                    qgs_store_row(srow + " << (d - 1) << " * ldr, lane8, " << in << d << ");\n";
+            o << "                }\n            }\n";
         }
         emit_derived(o, "            ", ndim, der, names(in));
         if (opt.const_table) {
@@ -546,7 +559,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         for (int i = 1; i <= ndim; ++i) {
             const std::string rn = "r" + std::to_string(i);
             emit_tend_row(so, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
-            if (spread_rec && (i - 1) % S == st) so << "            *(f64*)((char*)(prow + " << (i - 1) << " * ld) + lane8) = y" << i << ";\n";
+            if (spread_rec && (i - 1) % S == st) so << "            qgs_store_row(prow + " << (i - 1) << " * ld, lane8, y" << i << ");\n";
             // Whenever the addend stays live (y_i in every stage but the last) the sum is formed by an explicit three-address
             // v_fma_f64 (qgs_fma3): the compiler otherwise picks the two-address v_fmac_f64 plus a v_mov_b64 copy of the
             // addend (63 copies per RK4 step at ndim 36).  In the last stage y_i is dead (the stage input is xa / xb), so the new

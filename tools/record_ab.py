@@ -3,6 +3,8 @@ import numpy as np, torch
 ROOT='/root/repo'
 sys.path.insert(0, ROOT)
 from qgs_amd import _lib
+if os.environ.get('RK_AB_LIB'):                    # another build of the library (tools/build_prev_lib.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ['RK_AB_LIB'])
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'm36.npz')); ndim = int(g['ndim'])
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 n, steps = 65536, 100
