@@ -100,9 +100,26 @@ def launch_ranks(n, argv):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
+    # a rank that dies would leave the others waiting in a collective: watch all of them, stop the rest (exactly the
+    # processes started above) as soon as one fails
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):
+            failed = True
+            break
+        time.sleep(0.2)
+    if failed:
+        time.sleep(2.0)                                   # let the failing rank's peers report on their own first
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
     codes = [p.wait() for p in procs]
-    sys.stdout.write(out.decode())
+    reader.join(timeout=5.0)
+    sys.stdout.write(b''.join(chunks).decode())
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c]
     if bad:
