@@ -1618,8 +1618,20 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 // norm / beta / tau itself.  Same conventions as the LDS kernel of generic_kernels.hip (LAPACK dgeqr2 + dorg2r).
 std::string generate_qr_kernel(int n_rows, int n_cols)
 {
+    // Householder QR (dgeqr2 + dorg2r, the algorithm behind np.linalg.qr), one wavefront per matrix, lane = column, the column
+    // in registers.  The pivot column of step j is broadcast from lane j with two v_readlane per entry and stays in SGPRs:
+    // every sum that needs it takes it as the scalar operand of a v_fma_f64.  The scaled reflector u = v * scale is never
+    // formed outside lane j:  w = t (q_j + u.q) = t (q_j + scale (v.q)),  q -= w u = q - (w scale) v;  lanes <= j run the
+    // same statements with w = 0, so the only conditional code is lane j storing its reflector (q_i *= scale).  Against the
+    // first version (u in 2 x (R - j) registers per lane, conditional moves): 95 instead of 155 registers at 36 x 36, 155
+    // instead of 312 + scratch at 64 x 64.
     const int R = n_rows, C = n_cols, K = std::min(R, C);
     std::ostringstream o;
+    // sum_{i = lo .. R-1} a_i * b_i into `name` (one chain; four independent partial sums measured no faster)
+    auto dot = [&](const std::string &name, const std::string &a, const std::string &b, int lo) {
+        o << "        f64 " << name << " = 0.0;\n";
+        for (int i = lo; i < R; ++i) o << "        " << name << " = __builtin_fma(" << a << i << ", " << b << i << ", " << name << ");\n";
+    };
     o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
     o << "__device__ __forceinline__ f64 qgs_bcast(f64 x, int lane)\n{\n"
       << "    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);\n"
@@ -1629,15 +1641,20 @@ std::string generate_qr_kernel(int n_rows, int n_cols)
     o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << " per wavefront, lane = column\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_qr_" << R << "x" << C
       << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld)\n{\n";
-    o << "    const i64 m = blockIdx.x;\n    const int c = threadIdx.x;\n    const bool col = c < " << C << ";\n";
+    // Workgroups go round-robin to the 8 XCDs, each with its own L2, and 16 consecutive members share every 128-byte line of
+    // A[row][col][member]: XCD x takes the x-th eighth of the ensemble, so that the wavefronts sharing a line run on one XCD
+    // at about the same time (grid = 8 * ceil(n_traj / 8) workgroups).
+    o << "    const i64 per = (n_traj + 7) / 8;\n"
+      << "    const i64 m = (i64)(blockIdx.x & 7) * per + (i64)(blockIdx.x >> 3);\n"
+      << "    if (m >= n_traj) return;\n"
+      << "    const int c = threadIdx.x;\n    const bool col = c < " << C << ";\n";
     o << "    f64* const ap = a + (col ? c : 0) * ld + m;\n";
     for (int i = 0; i < R; ++i) o << "    f64 q" << i << " = col ? ap[(i64)" << i * C << " * ld] : 0.0;\n";
     o << "    f64 tau = 0.0;                       // lane j keeps tau_j\n";
     for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
         o << "    {   // column " << j << "\n";
         for (int i = j; i < R; ++i) o << "        const f64 v" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
-        o << "        f64 xn2 = 0.0;\n";
-        for (int i = j + 1; i < R; ++i) o << "        xn2 = __builtin_fma(v" << i << ", v" << i << ", xn2);\n";
+        dot("xn2", "v", "v", j + 1);
         o << "        const f64 alpha = v" << j << ";\n"
           << "        f64 t = 0.0, beta = alpha, scale = 0.0;\n"
           << "        if (xn2 != 0.0) {\n"
@@ -1645,29 +1662,28 @@ std::string generate_qr_kernel(int n_rows, int n_cols)
           << "            t = (beta - alpha) / beta;\n"
           << "            scale = 1.0 / (alpha - beta);\n"
           << "        }\n";
-        for (int i = j + 1; i < R; ++i) o << "        const f64 u" << i << " = v" << i << " * scale;\n";
-        o << "        if (c > " << j << ") {\n            f64 w = q" << j << ";\n";
-        for (int i = j + 1; i < R; ++i) o << "            w = __builtin_fma(u" << i << ", q" << i << ", w);\n";
-        o << "            w *= t;\n            q" << j << " -= w;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
-        o << "        }\n";
-        o << "        if (c == " << j << ") {\n            tau = t;\n            rdiag[(i64)" << j << " * ld + m] = beta;\n            q" << j << " = beta;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = u" << i << ";\n";
+        dot("s", "v", "q", j + 1);
+        o << "        const f64 w = (c > " << j << ") ? t * __builtin_fma(scale, s, q" << j << ") : 0.0;\n"
+          << "        q" << j << " -= w;\n"
+          << "        const f64 ws = w * scale;\n";
+        for (int i = j + 1; i < R; ++i) o << "        q" << i << " = __builtin_fma(-ws, v" << i << ", q" << i << ");\n";
+        o << "        if (c == " << j << ") {              // this lane's column is v itself: keep the reflector u = v * scale\n"
+          << "            tau = t;\n            rdiag[(i64)" << j << " * ld + m] = beta;\n            q" << j << " = beta;\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " *= scale;\n";
         o << "        }\n    }\n";
     }
     for (int j = K - 1; j >= 0; --j) {              // ---- dorg2r
         o << "    {   // Q: reflector " << j << "\n";
         o << "        const f64 t = qgs_bcast(tau, " << j << ");\n";
         for (int i = j + 1; i < R; ++i) o << "        const f64 u" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
-        o << "        if (c > " << j << ") {\n            f64 w = q" << j << ";\n";
-        for (int i = j + 1; i < R; ++i) o << "            w = __builtin_fma(u" << i << ", q" << i << ", w);\n";
-        o << "            w *= t;\n            q" << j << " -= w;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
-        o << "        }\n";
-        o << "        if (c == " << j << ") {\n";
+        dot("s", "u", "q", j + 1);
+        o << "        const f64 w = (c > " << j << ") ? t * (q" << j << " + s) : 0.0;\n"
+          << "        q" << j << " -= w;\n";
+        for (int i = j + 1; i < R; ++i) o << "        q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
+        o << "        if (c == " << j << ") {              // column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u)\n";
         for (int i = 0; i < j; ++i) o << "            q" << i << " = 0.0;\n";
         o << "            q" << j << " = 1.0 - t;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " = -t * u" << i << ";\n";
+        for (int i = j + 1; i < R; ++i) o << "            q" << i << " *= -t;\n";
         o << "        }\n    }\n";
     }
     o << "    if (col) {\n";

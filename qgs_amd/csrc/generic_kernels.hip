@@ -693,12 +693,23 @@ __device__ __forceinline__ double qr_col_dot(const double *A, int j, int c, int 
     return (w0 + w1) + (w2 + w3);
 }
 
+// Member of workgroup b in the batched QR kernels (grid = 8 * ceil(n_traj / 8)).  Workgroups go round-robin to the 8 XCDs,
+// each with its own L2, and 16 consecutive members share every 128-byte line of A[row][col][member]: XCD x takes the x-th
+// eighth of the ensemble, so the workgroups that share a line run on one XCD at about the same time (36 x 36, 16 384
+// members: 0.37 instead of 0.53 ms).  Returns n_traj or more for the padding workgroups.
+__device__ __forceinline__ int64_t qr_member(unsigned b, int64_t n_traj)
+{
+    const int64_t per = (n_traj + 7) / 8;
+    return (int64_t)(b & 7) * per + (int64_t)(b >> 3);
+}
+
 __global__ void __launch_bounds__(WAVE) batched_qr_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
                                                           double *__restrict__ a, double *__restrict__ rdiag)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *A = (double *)smem;                            // [n_rows][QR_STRIDE]
-    const int64_t m = blockIdx.x;
+    const int64_t m = qr_member(blockIdx.x, n_traj);
+    if (m >= n_traj) return;                               // (the whole workgroup)
     const int c = threadIdx.x;                             // own column
     const bool col = c < n_cols;
     for (int i = 0; i < n_rows; ++i) A[i * QR_STRIDE + c] = col ? a[((int64_t)i * n_cols + c) * ld + m] : 0.0;
@@ -1009,7 +1020,8 @@ __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_ro
     __shared__ double red[QRG_THREADS / WAVE];
     __shared__ double part[QRG_THREADS];
     __shared__ double s_t, s_beta, s_scale;
-    const int64_t m = blockIdx.x;
+    const int64_t m = qr_member(blockIdx.x, n_traj);
+    if (m >= n_traj) return;                               // (the whole workgroup)
     const int tid = threadIdx.x;
     double *B = scratch + (int64_t)m * n_rows * n_cols;
     double *tau = taus + (int64_t)m * n_cols;
@@ -1057,7 +1069,7 @@ void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld
                               hipStream_t st)
 {
     double *taus = scratch + (size_t)n_traj * n_rows * n_cols;
-    hipLaunchKernelGGL(batched_qr_global_kernel, dim3((unsigned)n_traj), dim3(QRG_THREADS), sizeof(double) * (size_t)n_rows, st,
+    hipLaunchKernelGGL(batched_qr_global_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(QRG_THREADS), sizeof(double) * (size_t)n_rows, st,
                        n_rows, n_cols, n_traj, ld, a, rdiag, scratch, taus);
 }
 
@@ -1069,7 +1081,7 @@ void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, doubl
         if (hipFuncSetAttribute((const void *)batched_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
             configured = lds;
     }
-    hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)n_traj), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag);
+    hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag);
 }
 
 bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }

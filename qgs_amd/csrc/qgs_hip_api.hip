@@ -1443,7 +1443,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         long long nt = n_traj, l = ld;
         void *args[] = {(void *)&d_a, (void *)&d_rdiag, &nt, &l};
         note_kernel(m, fname, f);
-        HIPCHK(hipModuleLaunchKernel(f, (unsigned)n_traj, 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+        HIPCHK(hipModuleLaunchKernel(f, (unsigned)(8 * ((n_traj + 7) / 8)), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
         return 0;
     }
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
