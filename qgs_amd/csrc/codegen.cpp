@@ -857,9 +857,19 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
           << "    const i64 m = m0 < n_traj ? m0 : n_traj - 1;\n"
           << "    const i64 g_total = (step_end - step_begin) * " << S << ";\n";
     } else {
+        // Which (64-member group, column) a workgroup takes.  The n_tg column wavefronts of a member group read the same stage
+        // states; workgroups go round-robin to the 8 XCDs (8 separate L2s), so when ld is a multiple of 64 XCD x takes the x-th
+        // eighth of the member groups and runs the columns of a group back to back: the stage states then come from that
+        // XCD's L2 instead of the Infinity Cache (grid = 8 * ceil(groups / 8) * n_tg, qgs_hip_api.hip launch_tgl()).
         o << "    const int lane = threadIdx.x;\n";
         o << "    const i64 L = n_tg * ld;\n"
-          << "    const i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+          << "    i64 l0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
+          << "    if ((ld & 63) == 0) {\n"
+          << "        const unsigned ng = (unsigned)(ld >> 6), per = (ng + 7u) >> 3, q = blockIdx.x >> 3;\n"
+          << "        const unsigned grp = (blockIdx.x & 7u) * per + q / (unsigned)n_tg, colr = q % (unsigned)n_tg;\n"
+          << "        if (grp >= ng) return;\n"
+          << "        l0 = (i64)colr * ld + (i64)grp * QGS_WAVE + threadIdx.x;\n"
+          << "    }\n"
           << "    const bool live = (l0 < L) && ((l0 % ld) < n_traj);\n"
           << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
           << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";

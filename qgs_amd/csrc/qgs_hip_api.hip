@@ -688,6 +688,15 @@ void note_kernel(qgs_model *m, const std::string &name, hipFunction_t f)
     }
 }
 
+// grid of the one-wavefront-per-(64 members, column) tangent kernels (codegen emit_tgl_kernel: XCD-aware order when ld % 64 == 0)
+int launch_tgl(hipFunction_t f, int64_t ld, int64_t n_tg, hipStream_t st, void **args)
+{
+    unsigned blocks = (unsigned)((n_tg * ld + 63) / 64);
+    if ((ld & 63) == 0) blocks = (unsigned)(8 * (((ld >> 6) + 7) / 8) * n_tg);
+    HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, 64, 1, 1, 0, st, args, nullptr));
+    return 0;
+}
+
 int launch(hipFunction_t f, int64_t lanes, hipStream_t st, void **args)
 {
     const unsigned blocks = (unsigned)((lanes + 63) / 64);
@@ -1370,7 +1379,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_full,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
-            if (launch(f2, L, st, a2)) return -1;
+            if (launch_tgl(f2, ld, n_tg, st, a2)) return -1;
         } else if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
             HIPCHK(qgs::launch_gen_tgl_wave(m->wave_J(adjoint != 0), m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm,
                                             stages, d_time, d_tab_spec, st, m->chains(true)));
@@ -1395,7 +1404,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             note_kernel(m, n2, f2);
             if (share_x) {
                 HIPCHK(hipModuleLaunchKernel(f2, (unsigned)(ld / 64), (unsigned)((n_tg + C - 1) / C), 1, 64 * C, 1, 1, 0, st, a2, nullptr));
-            } else if (launch(f2, L, st, a2)) return -1;
+            } else if (launch_tgl(f2, ld, n_tg, st, a2)) return -1;
         } else {
             qgs::launch_gen_tgl(Jrow, pa, n_tg, inverse, w_src, w_state, d_rec_fm, stages, m->work.f64(), d_time, d_tab_full, st);
             note_kernel(m, "gen_tgl_kernel", nullptr);
