@@ -399,6 +399,13 @@ __device__ __forceinline__ void qgs_store_row(f64* row, unsigned lane8, f64 v)
 {
     asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lane8), "v"(v), "s"(row) : "memory");
 }
+typedef double qgs_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void qgs_store_row2(f64* row, unsigned lane16, f64 a, f64 b)
+{
+    qgs_d2 pr;
+    pr.x = a; pr.y = b;
+    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(lane16), "v"(pr), "s"(row) : "memory");
+}
 // a uniform double (SGPR pair) into a vector register with one v_mov_b64
 __device__ __forceinline__ f64 qgs_mov64(f64 c)
 {
@@ -473,13 +480,20 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
 // here its store goes out somewhere in the step: row r right after its evaluation in stage (r - 1) mod S, one 512-byte
 // store every ~58 FMAs, addressed as scalar row pointer + lane offset (no 64-bit VALU address arithmetic).  Lanes past the
 // last member write their own padding column of the record (the buffer has ld >= 64 * gridDim.x columns per row).
+// pair_stages (qgs_spec_rkstagesp_s<S>, feeds qgs_spec_tglp_s<S>): the stage record holds the modes in pairs,
+// S[..][mode / 2][member][2] (an odd last mode as before), written with one 128-bit store per pair.  The tangent kernel then
+// needs half as many vector-memory instructions for the stage states, and each costs a lone wavefront ~3.4 issue slots
+// (config 4: 0.932 instead of 0.965 ms per call).  Every other producer / consumer of stage records keeps S[..][mode][member].
 void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, int S, bool store_stages,
-                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool spread_rec = false)
+                    const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der, bool spread_rec = false,
+                    bool pair_stages = false)
 {
     std::ostringstream o;
     KTable table;
     spread_rec = spread_rec && !store_stages;
-    const std::string kname = std::string(store_stages ? "qgs_spec_rkstages_s" : (spread_rec ? "qgs_spec_rkr_s" : "qgs_spec_rk_s")) + std::to_string(S);
+    pair_stages = pair_stages && store_stages;
+    const std::string kname = std::string(store_stages ? (pair_stages ? "qgs_spec_rkstagesp_s" : "qgs_spec_rkstages_s")
+                                                       : (spread_rec ? "qgs_spec_rkr_s" : "qgs_spec_rk_s")) + std::to_string(S);
     o << "\n// " << S << "-stage RK, " << (store_stages ? "also storing every stage input state" : "trajectory only")
       << (spread_rec ? ", every step a record (write_steps == 1)" : "") << "\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64, " << opt.min_waves_per_simd << ") " << kname << "(\n"
@@ -547,6 +561,11 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             o << "            {\n                i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
               << "                f64* const srow = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ldr + (i64)blockIdx.x * QGS_WAVE;\n"
               << "                if (live) {\n";
+            if (pair_stages) {             // pair (d, d + 1) at srow' = stage base + (d - 1) * ld + 128 * workgroup, 16 bytes per lane
+                for (int d = 1; d + 1 <= ndim; d += 2)
+                    o << "                    qgs_store_row2(srow + " << (d - 1) << " * ldr + (i64)blockIdx.x * QGS_WAVE, lane8 * 2u, " << in << d << ", " << in << (d + 1) << ");\n";
+                if (ndim & 1) o << "                    qgs_store_row(srow + " << (ndim - 1) << " * ldr, lane8, " << in << ndim << ");\n";
+            } else
             for (int d = 1; d <= ndim; ++d) o << "                    qgs_store_row(srow + " << (d - 1) << " * ldr, lane8, " << in << d << ");\n";
             o << "                }\n            }\n";
         }
@@ -817,16 +836,19 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
 // the cycles in s_waitcnt), and reads every stage state once per column.
 void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
                      const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt,
-                     const std::vector<std::pair<int, int>> &der, int share_x = 1, bool dense = false)
+                     const std::vector<std::pair<int, int>> &der, int share_x = 1, bool dense = false, bool pair_x = false)
 {
     // dense: general lower-triangular tableau (tab = b[S], a[S*S]); the partial sums of the later stages' inputs are kept in
     // LDS exactly as in emit_rk_dense_kernel
+    // pair_x (qgs_spec_tglp_s<S>): stage record in mode pairs as written by qgs_spec_rkstagesp_s<S> (see emit_rk_kernel)
     std::ostringstream o;
     KTable tables[2];
     const int C = dense ? 1 : std::max(1, share_x);
     const bool shx = C > 1;
+    pair_x = pair_x && !shx && !dense;
     const std::string kname = dense ? "qgs_spec_tgld_s" + std::to_string(S)
-                                    : (shx ? "qgs_spec_tglx" + std::to_string(C) + "_s" + std::to_string(S) : "qgs_spec_tgl_s" + std::to_string(S));
+                                    : (shx ? "qgs_spec_tglx" + std::to_string(C) + "_s" + std::to_string(S)
+                                           : (pair_x ? "qgs_spec_tglp_s" : "qgs_spec_tgl_s") + std::to_string(S));
     o << "\n// tangent (adjoint=0) / adjoint (adjoint=1) model, " << S << "-stage RK, one lane per (member, column)";
     if (shx) o << ", " << C << " columns per workgroup sharing the stage states through LDS";
     o << "\n";
@@ -928,8 +950,16 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
             }
             for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = xsh[pb][" << (d - 1) << "][lane];\n";
         } else {
-            o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
-            for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+            if (pair_x) {
+                o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld;\n";
+                for (int d = 1; d + 1 <= ndim; d += 2)
+                    o << "            const qgs_d2 xp" << d << " = *(const qgs_d2*)(sp + " << (d - 1) << " * ld + 2 * m); const f64 x" << d
+                      << " = xp" << d << ".x, x" << (d + 1) << " = xp" << d << ".y;\n";
+                if (ndim & 1) o << "            const f64 x" << ndim << " = sp[" << (ndim - 1) << " * ld + m];\n";
+            } else {
+                o << "            const f64* sp = stages + ((ti - step_begin) * " << S << " + " << st << ") * " << ndim << " * ld + m;\n";
+                for (int d = 1; d <= ndim; ++d) o << "            const f64 x" << d << " = sp[" << (d - 1) << " * ld];\n";
+            }
         }
         emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
@@ -1718,6 +1748,8 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::Rk: return "qgs_spec_rk_s" + std::to_string(S);
     case Kernel::RkSplit: return "qgs_spec_rksplit" + std::to_string(opt.row_split) + "_s" + std::to_string(S);
     case Kernel::RkStages: return "qgs_spec_rkstages_s" + std::to_string(S);
+    case Kernel::RkStagesPair: return "qgs_spec_rkstagesp_s" + std::to_string(S);
+    case Kernel::TglPair: return "qgs_spec_tglp_s" + std::to_string(S);
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::RkLds: return "qgs_spec_rklds" + std::to_string(opt.lds_waves);
     case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
@@ -1750,6 +1782,10 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::Rk: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t); break;
     case Kernel::RkSplit: emit_rk_split_kernel(o, ndim, rows, S, opt.row_split, opt, der.t); break;
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
+    case Kernel::RkStagesPair: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t, false, true); break;
+    case Kernel::TglPair:
+        emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j, 1, false, true);
+        break;
     case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;
     case Kernel::RkDense: emit_rk_dense_kernel(o, ndim, rows, S, opt, der.t); break;
     case Kernel::TglDense:
@@ -1784,6 +1820,7 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
         if (have_jac) {
             l.push_back({Kernel::RkStages, S});
             l.push_back({Kernel::Tgl, S});
+            if (opt.tgl_pair) { l.push_back({Kernel::RkStagesPair, S}); l.push_back({Kernel::TglPair, S}); }
             if (opt.tgl_share_x > 1) l.push_back({Kernel::TglX, S});
         }
     }

@@ -28,6 +28,7 @@ struct CodegenOptions {
     bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     int tgl_interleave = 2;    // tangent kernel: rows whose statements are emitted round-robin (config 4, 100 calls: 0.949 -> 0.933 ms with park_v)
     bool tgl_park_v = true;    // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
+    bool tgl_pair = true;      // stage record in mode pairs between qgs_spec_rkstagesp_s<S> and qgs_spec_tglp_s<S> (128-bit accesses)
     bool tgl_coeff_dedupe = true;  // tangent kernel: same de-duplication of coefficient fetches as lds_coeff_dedupe (config 4: 1.24 -> 1.20 ms)
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
@@ -69,6 +70,7 @@ bool tableau_is_subdiagonal(int s, const double *a);
 //   qgs_spec_rkd_s<S>        S-stage RK with a general lower-triangular tableau (partial stage sums in LDS; optional stage store)
 //   qgs_spec_tgld_s<S>       tangent / adjoint propagation for such a tableau
 //   qgs_spec_rkstages_s<S>   same, also storing every stage state       (feeds the tangent kernel)
+//   qgs_spec_rkstagesp_s<S> / qgs_spec_tglp_s<S>   the pair that exchanges the stage record in mode pairs (128-bit accesses)
 //   qgs_spec_rklds<W>        large systems: stage state in LDS, W wavefronts per 64 members, factors cached in
 //                            registers phase by phase; run-time stage count, optional stage store
 //   qgs_spec_rkldsd<W>       the LDS-resident stepper for a general lower-triangular tableau
@@ -82,7 +84,8 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
-enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense };
+enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense,
+                    RkStagesPair, TglPair };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                             const CodegenOptions &opt, const Derived &der = Derived());

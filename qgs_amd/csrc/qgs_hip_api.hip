@@ -751,6 +751,7 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_DEDUPE")) cg.lds_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_DEDUPE")) cg.tgl_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK_V")) cg.tgl_park_v = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_TGL_PAIR")) cg.tgl_pair = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_INTERLEAVE")) cg.tgl_interleave = std::max(1, std::atoi(e));
 }
 
@@ -1337,14 +1338,35 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         const int final_chunk = (end == n_steps);
         const double *y_src = first ? d_ic : y_state;
         const double *w_src = first ? d_tg_ic : w_state;
+        // which tangent kernel this chunk takes (decided first: the stepper has to know the layout of the stage record it feeds)
+        const bool lds_tgl = (!spec || !m->spec_jac_possible) && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
+        const bool tg_lds = lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs(m));
+        const bool tg_dense = !tg_lds && dense && m->spec_jac_possible;
+        const bool tg_wave = !tg_lds && !tg_dense && use_tgl_wave(m, n_traj * n_tg, s, a);
+        const bool tg_spec = !tg_lds && !tg_dense && !tg_wave && spec && m->spec_jac_possible;
+        // shared-stage-state kernel: C columns of the same 64 members per workgroup, stage states prefetched through LDS
+        // Measured (tools/tgls_scale.py, MAOOAM-36, 36 columns, 10 steps): while the stage record of a chunk stays in the
+        // 256 MB Infinity Cache every column can afford to read it (one-wavefront kernel 3-8 % ahead: 1.11 vs 1.21 ms at
+        // 16 384 members, 189 MB); beyond that the re-reads go to HBM and sharing wins 1.5x (65 536 members, 755 MB:
+        // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
+        const int C = m->cg.tgl_share_x;
+        const bool share_x = tg_spec && C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
+                             (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
+                             stage_bytes_per_step * (size_t)(end - begin) >= m->tune.tgl_share_min_bytes && !m->tune.tgl_plain;
+        const bool st_wave = use_wave(m, n_traj, s, a);
+        const bool st_lds_first = !st_wave && m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a);
+        const bool st_spec = !st_wave && !st_lds_first && !dense && spec;
+        // the fused stepper and the one-wavefront-per-column tangent kernel exchange the stage record in mode pairs
+        // (128-bit accesses: codegen emit_rk_kernel pair_stages); every other combination uses S[..][mode][member]
+        const bool pair = st_spec && tg_spec && !share_x && m->cg.tgl_pair && (ld & 1) == 0;
         // --- trajectory pass (stores every stage input state) ---
         qgs::RkArgs pa{m->ndim, s, n_traj, ld, begin, end, write_steps, n_records, backward, final_chunk};
         long long nt = n_traj, l = ld, sb = begin, se = end, ws = write_steps, nr = n_records, ntg = n_tg;
         int bw = backward, wf = final_chunk, adj = adjoint ? 1 : 0;
         double inv = inverse;
-        if (use_wave(m, n_traj, s, a)) {                  // few members: latency-optimised, lane = tensor row
+        if (st_wave) {                                    // few members: latency-optimised, lane = tensor row
             HIPCHK(qgs::launch_gen_rk_wave(m->wave_T(), m->max_row_terms, pa, y_src, y_state, d_rec, stages, d_time, d_tab_spec, st, m->chains(false)));
-        } else if (m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a)) {
+        } else if (st_lds_first) {
             if (launch_rk_lds(m, n_traj, ld, y_src, y_state, d_rec, stages, d_time, d_tab_spec, begin, end, write_steps, n_records,
                               backward, final_chunk, s, st)) return -1;
         } else if (dense) {
@@ -1355,7 +1377,7 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             if (launch(f1, n_traj, st, a1)) return -1;
         } else if (spec) {
             hipFunction_t f1;
-            if (get_function(m, qgs::Kernel::RkStages, s, &f1)) return -1;
+            if (get_function(m, pair ? qgs::Kernel::RkStagesPair : qgs::Kernel::RkStages, s, &f1)) return -1;
             void *a1[] = {(void *)&y_src, &y_state, &d_rec, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
             if (launch(f1, n_traj, st, a1)) return -1;
@@ -1368,11 +1390,10 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
             qgs::launch_gen_rk(m->dT.view(), pa, y_src, y_state, d_rec, stages, m->work.f64(), d_time, d_tab_full, st);
         }
         // --- tangent / adjoint pass ---
-        const bool lds_tgl = (!spec || !m->spec_jac_possible) && use_lds_tgl(m, n_traj * n_tg, n_steps, s, a, adjoint);
-        if (lds_tgl && (m->kernel_kind == 2 || n_traj * n_tg > lds_tgl_min_pairs(m))) {
+        if (tg_lds) {
             if (launch_tgl_lds(m, n_traj, ld, n_tg, w_src, w_state, d_rec_fm, stages, d_time, d_tab_spec, begin, end, write_steps,
                                n_records, backward, final_chunk, adjoint ? 1 : 0, inverse, s, st)) return -1;
-        } else if (dense && m->spec_jac_possible) {
+        } else if (tg_dense) {
             hipFunction_t f2;
             std::string n2;
             if (get_function(m, qgs::Kernel::TglDense, s, &f2, &n2)) return -1;
@@ -1380,25 +1401,14 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);
             if (launch_tgl(f2, ld, n_tg, st, a2)) return -1;
-        } else if (use_tgl_wave(m, n_traj * n_tg, s, a)) {       // few (member, column) pairs: lane = row of J / J^T
+        } else if (tg_wave) {                                    // few (member, column) pairs: lane = row of J / J^T
             HIPCHK(qgs::launch_gen_tgl_wave(m->wave_J(adjoint != 0), m->max_jrow_terms, pa, n_tg, inverse, w_src, w_state, d_rec_fm,
                                             stages, d_time, d_tab_spec, st, m->chains(true)));
             note_kernel(m, "gen_tgl_wave_kernel", nullptr);
-        } else if (spec && m->spec_jac_possible) {
-            // shared-stage-state kernel: C columns of the same 64 members per workgroup, stage states prefetched through LDS
-            const int C = m->cg.tgl_share_x;
-            // Measured (tools/tgls_scale.py, MAOOAM-36, 36 columns, 10 steps): while the stage record of a chunk stays in the
-            // 256 MB Infinity Cache every column can afford to read it (one-wavefront kernel 3-8 % ahead: 1.11 vs 1.21 ms at
-            // 16 384 members, 189 MB); beyond that the re-reads go to HBM and sharing wins 1.5x (65 536 members, 755 MB:
-            // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
-            const size_t share_min = m->tune.tgl_share_min_bytes;
-            bool share_x = C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
-                           (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
-                           stage_bytes_per_step * (size_t)(end - begin) >= share_min;
-            share_x = share_x && !m->tune.tgl_plain;
+        } else if (tg_spec) {
             hipFunction_t f2;
             std::string n2;
-            if (get_function(m, share_x ? qgs::Kernel::TglX : qgs::Kernel::Tgl, s, &f2, &n2)) return -1;
+            if (get_function(m, share_x ? qgs::Kernel::TglX : (pair ? qgs::Kernel::TglPair : qgs::Kernel::Tgl), s, &f2, &n2)) return -1;
             void *a2[] = {(void *)&w_src, &w_state, &d_rec_fm, &stages, (void *)&d_time, (void *)&d_tab_spec,
                           &nt, &l, &ntg, &sb, &se, &ws, &nr, &bw, &wf, &adj, &inv};
             note_kernel(m, n2, f2);

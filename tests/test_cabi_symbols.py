@@ -66,7 +66,9 @@ def test_prebuild_generates_code_objects(tmp_path, monkeypatch):
     jval = np.array([-0.5, 2.0, 2.0, -2.0])
     _lib.prebuild(2, coo, val, jcoo, jval, stage_counts=(2,))
     objs = [f for f in os.listdir(tmp_path) if f.endswith('.hsaco')]
-    assert len(objs) == 7          # one code object per kernel: f, Df, rk_s2, rkr_s2 (write_steps = 1), rkstages_s2, tgl_s2, tglx4_s2 (2 rows: no split)
+    # one code object per kernel: f, Df, rk_s2, rkr_s2 (write_steps = 1), rkstages_s2, tgl_s2, rkstagesp_s2 + tglp_s2 (stage record in
+    # mode pairs), tglx4_s2 (2 rows: no split)
+    assert len(objs) == 9
     assert all(os.path.getsize(os.path.join(tmp_path, f)) > 1000 for f in objs)
 
 
@@ -90,7 +92,7 @@ def test_prebuild_shards_cover_every_code_object(tmp_path):
         env = dict(os.environ, QGS_HIP_CACHE_DIR=str(d), QGS_HIP_PREBUILD_SHARD='%d/2' % i, QGS_HIP_NO_TORCH_PRELOAD='1')
         subprocess.check_call([sys.executable, '-c', code], env=env)
         seen.append(sorted(f for f in os.listdir(d) if f.endswith('.hsaco')))
-    assert len(seen[0]) + len(seen[1]) == 7 and abs(len(seen[0]) - len(seen[1])) == 1
+    assert len(seen[0]) + len(seen[1]) == 9 and abs(len(seen[0]) - len(seen[1])) == 1
     assert not set(seen[0]) & set(seen[1])
 
 

@@ -194,11 +194,11 @@ def test_rank5_models_vs_oracle(models, name, n_traj):
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'qgs_spec_tgllds16')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else 'qgs_spec_tgllds16')
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, -1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.)
         assert rel_err(tr, atr) < 1e-12 and rel_err(fm, afm) < 1e-11, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tgl_s4' if name == 'd38' else 'qgs_spec_adjlds16')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else 'qgs_spec_adjlds16')
     m.set_kernel(0)
 
 
@@ -492,7 +492,7 @@ def test_shared_stage_state_tangent_kernel(models, n_traj, n_tg):
         try:
             m.set_kernel(2)                                   # re-reads the selection knobs
             _, fm1 = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
-            assert m.last_kernel_info()['name'] == 'qgs_spec_tgl_s%d' % len(b)
+            assert m.last_kernel_info()['name'] == 'qgs_spec_tglp_s%d' % len(b)      # (stage record in mode pairs)
         finally:
             del os.environ['QGS_HIP_TGL_VARIANT']
             m.set_kernel(2)
@@ -605,7 +605,8 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     assert stepper_name(m36, 36, 65536) == 'qgs_spec_rk_s4'
     assert stepper_name(m36, 36, 16384) == 'qgs_spec_rksplit4_s4'
     assert stepper_name(m36, 36, 64) == 'gen_rk_wave_kernel'
-    assert tangent_name(m36, 36, 16384, 36) == 'qgs_spec_tgl_s4'
+    assert tangent_name(m36, 36, 16384, 36) == 'qgs_spec_tglp_s4'          # fed by qgs_spec_rkstagesp_s4: stage record in mode pairs
+    assert tangent_name(m36, 36, 1024, 36) == 'qgs_spec_tgl_s4'            # fed by the wave-per-trajectory stepper: plain record
     assert tangent_name(m36, 36, 65536, 36) == 'qgs_spec_tglx4_s4'
     r38 = (np.array([1., 3., 3., 1.]) / 8., np.array([0., 1. / 3, 2. / 3, 1.]),
            np.array([[0., 0, 0, 0], [1. / 3, 0, 0, 0], [-1. / 3, 1., 0, 0], [1., -1., 1., 0]]))
@@ -679,6 +680,31 @@ def test_random_polynomial_systems(seed, ndim, rank, nnz):
         assert rel_err(tr, ref_ad[0]) < 1e-12 and rel_err(fm, ref_ad[1]) < 1e-11, kind
     m.close()
 
+
+@pytest.mark.parametrize('seed,ndim', [(21, 7), (22, 12), (23, 1)])
+def test_paired_stage_record_equals_plain(monkeypatch, seed, ndim):
+    """`qgs_spec_rkstagesp_s<S>` -> `qgs_spec_tglp_s<S>` exchange the stage record in mode pairs (128-bit accesses, an odd last
+    mode on its own); the arithmetic is the same as with the plain record, so the results must be bitwise equal -- odd and even
+    ndim, ensembles that do not fill their last wavefront."""
+    from qgs_amd import _lib
+    coo, val, jcoo, jval = _random_system(seed, ndim, 3, 12 * ndim)
+    rng = np.random.RandomState(seed)
+    x = rng.rand(150, ndim) * 0.3
+    tg = rng.randn(150, ndim, 3)
+    t = np.concatenate((np.arange(0., 0.05, 0.01), [0.05]))
+    out = {}
+    for pair in ('1', '0'):
+        monkeypatch.setenv('QGS_HIP_TGL_PAIR', pair)
+        m = _lib.HipModel(ndim, coo, val, jcoo, jval)
+        m.set_kernel(2)
+        res = []
+        for d, ws, adj, inv in ((1, 1, False, 1.), (-1, 2, True, -1.)):
+            res.append(m.rk_tgls_integrate(t, x, tg, d, ws, RK4['b'], RK4['c'], RK4['a'], adj, inv))
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if pair == '1' else 'qgs_spec_tgl_s4')
+        out[pair] = res
+        m.close()
+    for (tr1, fm1), (tr0, fm0) in zip(out['1'], out['0']):
+        assert np.array_equal(tr1, tr0) and np.array_equal(fm1, fm0)
 
 
 def test_cache_miss_compiles_the_same_stepper(tmp_path):
