@@ -16,7 +16,7 @@
  * reference's own loops executed by CPython with `numba.njit` replaced by the identity
  * (oracle/refshim/): same statements and IEEE-754 operation order as the jitted code, but
  * not numba-compiled code.  The reference has no stepper fixtures of its own; its tensor
- * fixtures (model_test/*.ref, tests/golden/ref/) cross-pin the tensors.
+ * fixtures (model_test/<name>.ref, tests/golden/ref/) cross-pin the tensors.
  *
  * Each function cites the reference file:line (relative to the qgs repository root) whose
  * statements it follows.  Operation order is the reference's: (a*b)*val then +=, no FMA.
