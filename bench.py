@@ -79,10 +79,35 @@ def load_model_tensors():
 # launcher: `python bench.py --gpus N` typed directly
 # ---------------------------------------------------------------------------------------------------------------
 def visible_gpus():
-    """Number of GPUs this process could use, WITHOUT initialising the HIP runtime (the parent must stay GPU-free:
-    it only starts child processes)."""
-    import torch
-    return int(torch.cuda.device_count())
+    """Number of GPUs the child ranks will see, counted WITHOUT loading the HIP runtime (the launcher parent must stay
+    GPU-free: it only starts child processes): the KFD topology nodes that have SIMDs (CPUs are nodes with simd_count 0),
+    cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set."""
+    import glob
+    n, seen = 0, 0
+    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+        try:
+            with open(path) as f:
+                for line in f:
+                    k, _, v = line.partition(' ')
+                    if k == 'simd_count':
+                        seen += 1
+                        n += 1 if int(v) > 0 else 0
+                        break
+        except (OSError, ValueError):
+            pass
+    if seen == 0:
+        # no readable KFD topology (unusual container): ask a short-lived child, so that this process still never loads HIP
+        try:
+            out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
+                                 stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout
+            return int(out.decode().strip().splitlines()[-1])
+        except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
+            return 0
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([q for q in v.split(',') if q.strip() != '']))
+    return n
 
 
 def launch_ranks(n, argv):
@@ -377,7 +402,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--members', type=int, default=65536, help='ensemble members per GPU')
+    ap.add_argument('--members', type=int, default=None,
+                    help='ensemble members per GPU (default: 131 072 with --gpus 8 = BASELINE configs[4], 1 048 576 members over 8 GPUs; '
+                         '65 536 = configs[1] otherwise)')
     ap.add_argument('--rk-steps', type=int, default=1000, help='RK4 steps per pass')
     ap.add_argument('--kernel', choices=['auto', 'generic', 'spec'], default='auto')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -386,6 +413,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
+    members_default = args.members is None
+    if members_default:
+        args.members = 131072 if args.gpus == 8 else 65536
 
     under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     if not under_launcher and args.gpus > 1:
@@ -534,7 +564,11 @@ def main():
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'MAOOAM 2x2 atm / 2x4 ocean (36 modes) fp64, %d-member ensemble per GPU, %d RK4 steps '
-                                   'per pass, write_steps=0 (BASELINE configs[1])' % (n_traj, rk_steps),
+                                   'per pass, write_steps=0 (%s)'
+                                   % (n_traj, rk_steps,
+                                      'BASELINE configs[4]: %d members sharded across %d GPUs, RCCL gather only' % (n_traj * world, world)
+                                      if (world == 8 and n_traj == 131072) else
+                                      ('BASELINE configs[1]' if n_traj == 65536 else 'configs[1] model at a non-default ensemble size')),
                        'members_per_gpu': n_traj, 'rk_steps_per_pass': rk_steps, 'ndim': ndim, 'tensor_nnz': int(len(val)),
                        'dt': dt, 'tensor_source': tensor_src,
                        'parallelism': 'members sharded x%d, RCCL gather of final states onto rank 0 (async, overlapped)' % world,

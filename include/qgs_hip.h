@@ -34,6 +34,7 @@ extern "C" {
 #endif
 
 typedef struct qgs_model qgs_model;   /* opaque: tensors staged on one device + compiled kernels */
+typedef struct qgs_group qgs_group;   /* opaque: one qgs_model per GPU of a device list; members are sharded over them */
 
 /* Error text of the last failing call on this thread ("" if none). */
 const char *qgs_last_error(void);
@@ -63,7 +64,8 @@ int qgs_model_create_rank(int device, int ndim, int rank,
 int qgs_model_destroy(qgs_model *m);
 
 /* Model properties: which=0 ndim, 1 nnz, 2 jnnz, 3 device, 4 specialised-kernel available (0/1), 5 tensor rank,
- * 6 / 7 number of derived monomials of the tendencies / Jacobian code (rank 5). */
+ * 6 / 7 number of derived monomials of the tendencies / Jacobian code (rank 5), 8 number of record windows the last
+ * host-layout integration of this model was cut into. */
 int64_t qgs_model_info(const qgs_model *m, int which);
 
 /* Select the kernel family: 0 = automatic (specialised when available, else generic),
@@ -77,7 +79,10 @@ int64_t qgs_model_info(const qgs_model *m, int which);
  * when a model is created and here, never inside a launch). */
 int qgs_model_set_kernel(qgs_model *m, int kind);
 
-/* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) -------------- */
+/* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) --------------
+ * Results may be larger than the device memory: the integrations keep only a window of records on the device
+ * (QGS_HIP_RECORD_WINDOW_MB, default 8192) and hand window k to the host while window k + 1 is computed.  The result
+ * block may be pageable memory (staged copy) or page-locked (qgs_host_register: the device stores into it directly). */
 
 /* f(t, x) for n_traj states at once.   qgs/functions/tendencies.py:111-115 + sparse_mul.py:48-81 */
 int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx);
@@ -116,6 +121,31 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
                              int time_direction, int64_t write_steps, int s, const double *b, const double *c,
                              const double *a, double *mean, double *var, double *final_states);
 
+/* All GPUs of the node (or any list of them) behind one handle: what the reference's integrators do with the cores of the
+ * machine (one task per trajectory over `num_threads` processes, qgs/integrators/integrator.py:79-82, 133-142, 386-395).
+ * `devices` may name a device more than once (two models and two pipelines on it).  Members are split into contiguous
+ * shards, shard i = members [start, start + count) with the remainder going to the first shards (qgs_group_shard); every
+ * shard is integrated by its own model from a host thread of its own and delivers its slice of the result block itself
+ * (G parallel device-to-host streams; no collective).  Arguments and results exactly as for the qgs_model entry points of
+ * the same name; results are bitwise those of a single model.  SURVEY 8(b)'s `device_mask`. */
+int qgs_group_create(int n_devices, const int *devices, int ndim, int rank,
+                     int64_t nnz, const int32_t *coo, const double *val,
+                     int64_t jnnz, const int32_t *jcoo, const double *jval, qgs_group **out);
+int qgs_group_destroy(qgs_group *g);
+int qgs_group_size(const qgs_group *g);
+qgs_model *qgs_group_model(qgs_group *g, int i);              /* borrowed: shard i's model (its device: qgs_model_info(m, 3)) */
+int qgs_group_shard(const qgs_group *g, int64_t n_traj, int i, int64_t *start, int64_t *count);
+int qgs_group_set_kernel(qgs_group *g, int kind);
+int qgs_group_tendencies(qgs_group *g, int64_t n_traj, const double *x, double *dx);
+int qgs_group_jacobian(qgs_group *g, int64_t n_traj, const double *x, double *jac);
+int qgs_group_rk_integrate(qgs_group *g, int64_t n_traj, const double *ic,
+                           const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                           int s, const double *b, const double *c, const double *a, double *traj);
+int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                                const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                                int s, const double *b, const double *c, const double *a,
+                                int adjoint, double inverse, double *traj, double *fmatrix);
+
 /* Page-lock (and later release) a caller-owned host block that receives large results, so that the device-to-host copies
  * of the host-layout entry points run at the pinned PCIe rate (measured 57 instead of 50 GB/s for a 1.9 GB record, and
  * without first-touch page faults inside the copy).  Optional: every entry point also accepts pageable memory.  The Python
@@ -126,6 +156,14 @@ int qgs_host_unregister(void *ptr);
 
 /* ---- device-layout entry points (pointers are device pointers on the model's device; the work
  *      is enqueued on `stream` (a hipStream_t, NULL = default stream) and NOT synchronised) ------ */
+
+/* qgs_rk_integrate with both blocks in DEVICE memory, in the reference's layouts: d_ic_rows (n_traj, ndim), d_traj_rows
+ * (n_traj, ndim, n_records).  Pack, windowed stepper and record unpack run on the model's own streams with only a window
+ * of mode-major records as scratch; blocking.  (The shard of a multi-process run whose result is gathered with RCCL,
+ * qgs_amd/parallel.py.) */
+int qgs_rk_integrate_rows_device(qgs_model *m, int64_t n_traj, const double *d_ic_rows,
+                                 const double *time, int64_t n_time, int time_direction, int64_t write_steps,
+                                 int s, const double *b, const double *c, const double *a, double *d_traj_rows);
 
 /* (n_traj, ndim) host-layout device buffer  <->  mode-major X[ndim][ld] */
 int qgs_pack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_rows, double *d_x_modes, void *stream);

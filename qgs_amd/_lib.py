@@ -35,6 +35,18 @@ SIGNATURES = {
     'qgs_rk_integrate': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p]),
     'qgs_rk_tgls_integrate': (_int, [_vp, _i64, _i64, _f64p, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p,
                                      _int, _dbl, _f64p, _f64p]),
+    'qgs_group_create': (_int, [_int, ctypes.POINTER(_int), _int, _int, _i64, _vp, _vp, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
+    'qgs_group_destroy': (_int, [_vp]),
+    'qgs_group_size': (_int, [_vp]),
+    'qgs_group_model': (_vp, [_vp, _int]),
+    'qgs_group_shard': (_int, [_vp, _i64, _int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)]),
+    'qgs_group_set_kernel': (_int, [_vp, _int]),
+    'qgs_group_tendencies': (_int, [_vp, _i64, _f64p, _f64p]),
+    'qgs_group_jacobian': (_int, [_vp, _i64, _f64p, _f64p]),
+    'qgs_group_rk_integrate': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p]),
+    'qgs_group_rk_tgls_integrate': (_int, [_vp, _i64, _i64, _f64p, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p,
+                                           _int, _dbl, _f64p, _f64p]),
+    'qgs_rk_integrate_rows_device': (_int, [_vp, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp]),
     'qgs_host_register': (_int, [_vp, _i64]),
     'qgs_host_unregister': (_int, [_vp]),
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
@@ -271,6 +283,11 @@ class HipModel(object):
         return bool(lib().qgs_model_info(self._h, 4))
 
     @property
+    def last_windows(self):
+        """Record windows the last host-layout integration was cut into (1: the record fitted the device budget)."""
+        return int(lib().qgs_model_info(self._h, 8))
+
+    @property
     def n_derived(self):
         """Derived monomials of the generated tendencies / Jacobian code (rank-5 tensors; (0, 0) for rank 3)."""
         return int(lib().qgs_model_info(self._h, 6)), int(lib().qgs_model_info(self._h, 7))
@@ -367,6 +384,13 @@ class HipModel(object):
         _check(lib().qgs_rk_integrate_device(self._h, n_traj, ld, d_ic, time, len(time), int(time_direction),
                                              int(write_steps), len(b), b, c, a, d_rec, stream or None))
 
+    def rk_integrate_rows_device(self, n_traj, d_ic_rows, time, time_direction, write_steps, b, c, a, d_traj_rows):
+        """`rk_integrate` with both blocks in device memory in the reference's layouts ((n_traj, ndim) in, (n_traj, ndim,
+        n_records) out); only a window of mode-major records is held as scratch.  Blocking."""
+        time, b, c, a = _c(time), _c(b), _c(c), _c(a)
+        _check(lib().qgs_rk_integrate_rows_device(self._h, n_traj, d_ic_rows, time, len(time), int(time_direction),
+                                                  int(write_steps), len(b), b, c, a, d_traj_rows))
+
     def batched_qr_device(self, n_traj, ld, n_rows, n_cols, d_a, d_rdiag, stream=0):
         _check(lib().qgs_batched_qr_device(self._h, n_traj, ld, int(n_rows), int(n_cols), d_a, d_rdiag, stream or None))
 
@@ -376,3 +400,160 @@ class HipModel(object):
         _check(lib().qgs_rk_tgls_integrate_device(self._h, n_traj, ld, n_tg, d_ic, d_tg_ic, time, len(time),
                                                   int(time_direction), int(write_steps), len(b), b, c, a,
                                                   int(bool(adjoint)), float(inverse), d_rec, d_rec_fm, stream or None))
+
+
+def visible_devices():
+    """Indices of the GPUs this process can use (HIP's numbering, after ROCR_/HIP_VISIBLE_DEVICES)."""
+    return list(range(backend_info()[0]))
+
+
+class _ShardModel(HipModel):
+    """A group's model of one shard: borrowed handle, destroyed with the group."""
+
+    def __init__(self, handle, owner):                       # noqa: super().__init__ creates a handle; this one is borrowed
+        self._h = handle
+        self._owner = owner
+        self.ndim = int(lib().qgs_model_info(handle, 0))
+        self.device = int(lib().qgs_model_info(handle, 3))
+        self.rank = int(lib().qgs_model_info(handle, 5))
+
+    def close(self):
+        self._h = None
+
+
+class HipModelGroup(object):
+    """A model's tensors staged on several GPUs (qgs_group handle): the host-layout calls of `HipModel`, with the members
+    split into contiguous shards, one per listed device, each integrated and delivered by its own GPU.
+
+    What the reference does with the cores of the machine (one task per trajectory over `num_threads` worker processes,
+    qgs/integrators/integrator.py:79-82, 133-142, 386-395).  `devices` may list a device more than once.
+    """
+
+    KERNEL_AUTO, KERNEL_GENERIC, KERNEL_SPECIALISED = 0, 1, 2
+
+    def __init__(self, ndim, coo, val, jcoo=None, jval=None, devices=None):
+        self.ndim = int(ndim)
+        self.devices = [int(d) for d in (visible_devices() if devices is None else devices)]
+        if not self.devices:
+            raise ValueError('a device group needs at least one device')
+        self.coo, self.val = _c(coo, np.int32), _c(val)
+        self.jcoo = _c(jcoo, np.int32) if jcoo is not None else None
+        self.jval = _c(jval) if jval is not None else None
+        self.rank = _tensor_rank(self.coo, self.jcoo)
+        h = _vp()
+        devs = (_int * len(self.devices))(*self.devices)
+        _check(lib().qgs_group_create(len(self.devices), devs, self.ndim, self.rank, len(self.val), _ptr(self.coo), _ptr(self.val),
+                                      0 if self.jval is None else len(self.jval), _ptr(self.jcoo), _ptr(self.jval),
+                                      ctypes.byref(h)))
+        self._h = h
+        self.models = [_ShardModel(lib().qgs_group_model(h, i), self) for i in range(len(self.devices))]
+
+    def close(self):
+        if getattr(self, '_h', None):
+            for m in self.models:
+                m.close()
+            lib().qgs_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self.devices)
+
+    def shard(self, n_traj, i):
+        """(start, count) of shard i of an ensemble of n_traj members."""
+        a, n = _i64(0), _i64(0)
+        _check(lib().qgs_group_shard(self._h, int(n_traj), int(i), ctypes.byref(a), ctypes.byref(n)))
+        return a.value, n.value
+
+    def set_kernel(self, kind):
+        _check(lib().qgs_group_set_kernel(self._h, int(kind)))
+
+    @property
+    def specialised_available(self):
+        return self.models[0].specialised_available
+
+    def last_kernel_info(self):
+        return self.models[0].last_kernel_info()
+
+    _check_ic = HipModel._check_ic
+
+    def tendencies(self, x):
+        x = _c(x)
+        xb = x.reshape(-1, self.ndim)
+        out = np.empty_like(xb)
+        _check(lib().qgs_group_tendencies(self._h, xb.shape[0], xb, out))
+        return out.reshape(x.shape)
+
+    def jacobian(self, x):
+        x = _c(x)
+        xb = x.reshape(-1, self.ndim)
+        out = _RESULTS.empty((xb.shape[0], self.ndim, self.ndim))
+        _check(lib().qgs_group_jacobian(self._h, xb.shape[0], xb, out))
+        return out[0] if x.ndim == 1 else out
+
+    def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a):
+        time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
+        self._check_ic(ic)
+        nrec = n_records(time, write_steps)
+        traj = _RESULTS.empty((ic.shape[0], self.ndim, nrec))
+        _check(lib().qgs_group_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
+                                            len(b), b, c, a, traj))
+        return traj
+
+    def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse):
+        time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)
+        self._check_ic(ic, tg_ic)
+        nrec = n_records(time, write_steps)
+        n_traj, n_tg = ic.shape[0], tg_ic.shape[2]
+        traj = _RESULTS.empty((n_traj, self.ndim, nrec))
+        fm = _RESULTS.empty((n_traj, self.ndim, n_tg, nrec))
+        _check(lib().qgs_group_rk_tgls_integrate(self._h, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
+                                                 int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
+                                                 traj, fm))
+        return traj, fm
+
+    def rk_integrate_moments(self, time, ic, time_direction, write_steps, b, c, a, variance=True, final_states=False):
+        """Ensemble mean / variance of every variable at every record: each shard reduces on its own GPU, the per-shard
+        moments are pooled on the host (Chan et al.'s pairwise update)."""
+        ic = _c(ic)
+        self._check_ic(ic)
+        n_total = ic.shape[0]
+        import threading
+        parts = [None] * len(self.models)
+
+        errors = []
+
+        def run(i):
+            try:
+                a0, n = self.shard(n_total, i)
+                if n > 0:
+                    parts[i] = (n,) + self.models[i].rk_integrate_moments(time, ic[a0:a0 + n], time_direction, write_steps, b, c, a,
+                                                                           variance=variance, final_states=final_states)
+            except Exception as e:                               # re-raised on the calling thread below
+                errors.append(e)
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(self.models))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        parts = [q for q in parts if q is not None]
+        n_acc, mean, m2 = 0, None, None
+        for n, mu, var, _ in parts:
+            if mean is None:
+                n_acc, mean, m2 = n, mu.copy(), (var * n if variance else None)
+                continue
+            delta = mu - mean
+            tot = n_acc + n
+            if variance:
+                m2 = m2 + var * n + delta * delta * (n_acc * n / tot)
+            mean = mean + delta * (n / tot)
+            n_acc = tot
+        fin = np.concatenate([q[3] for q in parts], axis=0) if final_states else None
+        return mean, (m2 / n_acc if variance else None), fin

@@ -7,7 +7,7 @@
 #include <cstring>
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s ndim tensor.txt [nogroup] [waves=N] [stages=4]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ndim tensor.txt [nogroup] [waves=N] [stages=4] [all]\n", argv[0]); return 2; }
     int ndim = std::atoi(argv[1]);
     std::vector<qgs::Term> T, J;
     FILE *f = std::fopen(argv[2], "r");
@@ -31,7 +31,9 @@ int main(int argc, char **argv)
     qgs::reduce_polynomial(ndim, rank, (int64_t)val[1].size(), coo[1].data(), val[1].data(), true, J, der.j);
     qgs::CodegenOptions opt;
     std::vector<int> stages = {4};
+    bool all = false;
     for (int a = 3; a < argc; ++a) {
+        if (!std::strcmp(argv[a], "all")) all = true;
         if (!std::strcmp(argv[a], "nogroup")) opt.group_coeff = false;
         if (!std::strncmp(argv[a], "waves=", 6)) opt.min_waves_per_simd = std::atoi(argv[a] + 6);
         if (!std::strncmp(argv[a], "stages=", 7)) stages = {std::atoi(argv[a] + 7)};
@@ -43,6 +45,14 @@ int main(int argc, char **argv)
     if (rank == 5) opt.row_split = 1;
     std::fprintf(stderr, "ndim %d rank %d terms %zu jac terms %zu derived %zu / %zu tendency fp64 instr %lld\n", ndim, rank, T.size(),
                  J.size(), der.t.size(), der.j.size(), (long long)qgs::count_tendency_flops_instr(ndim, T, opt) + (long long)der.t.size());
-    std::fputs(qgs::generate_source(ndim, T, J, stages, opt, der).c_str(), stdout);
+    if (ndim <= 64) std::fputs(qgs::generate_source(ndim, T, J, stages, opt, der).c_str(), stdout);
+    if (all) {
+        // every other emitter too (the sanitizer job of tests/test_codegen_sanitizers.py): general-tableau, LDS-resident and QR kernels
+        using K = qgs::Kernel;
+        if (ndim <= 64)
+            for (K k : {K::RkDense, K::TglDense}) std::fputs(qgs::generate_kernel(ndim, T, J, k, stages[0], opt, der).c_str(), stdout);
+        for (K k : {K::RkLds, K::TendLds, K::RkLdsDense, K::TglLds, K::AdjLds}) std::fputs(qgs::generate_kernel(ndim, T, J, k, 0, opt, der).c_str(), stdout);
+        std::fputs(qgs::generate_qr_kernel(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5).c_str(), stdout);
+    }
     return 0;
 }

@@ -50,6 +50,11 @@ void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, c
 // Df(x) -> jm[(i-1)*ndim + (j-1)][member]   (output must be zero-filled by the caller)
 void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, const double *x, double *jm, hipStream_t st);
 
+// One state (n_traj == 1, the f / Df handed to an ODE solver): x, dx are plain (ndim,) vectors, possibly in page-locked host
+// memory; jm is (ndim, ndim) row-major in device memory, zero-filled by the caller.  ndim <= 8190 (LDS copy of x).
+void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, hipStream_t st);
+void launch_gen_jac_one(const DevTensor &Jt, int ndim, const double *x, double *jm, hipStream_t st);
+
 // Explicit s-stage RK with the full `a` matrix (integrate.py:204-221).
 //   work: (s + 2) * ndim * ld doubles of scratch;  stages: optional S[(step-step_begin)*s+stage][mode][member]
 //   tab_full: device array  b[s], a[s*s]
@@ -127,6 +132,10 @@ void launch_unpack_states(int ndim, int64_t n_traj, int64_t ld, const double *mo
 // in: R[n_records][n_inner][ld]  ->  out: (n_traj, n_inner, n_records)
 void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t n_records, const double *in, double *out,
                            hipStream_t st);
+// a window of W records R[W][n_inner][ld] -> out[(m * n_inner + q) * out_stride + r], r in [0, W): `out` points at the
+// window's first record column of a (n_traj, n_inner, out_stride) array (device memory or device-accessible host memory)
+void launch_unpack_window(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W, int64_t out_stride, const double *in,
+                          double *out, hipStream_t st);
 // tangent IC: host (n_traj, ndim, n_tg) -> F[ndim][n_tg][ld]
 void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);
 // tangent records: F[n_records][ndim][n_tg][ld] -> (n_traj, ndim, n_tg, n_records): same as unpack_records with

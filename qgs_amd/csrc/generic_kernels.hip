@@ -68,6 +68,46 @@ __global__ void __launch_bounds__(WAVE) gen_jac_kernel(DevTensor Jt, int ndim, i
     }
 }
 
+// ---- one state: f(x) and Df(x) for a single (ndim,) vector (the callables handed to SciPy / DiffEq solvers) -----------
+// One workgroup, thread = tensor row; x may live in page-locked host memory (read once, into LDS), so may dx.
+__global__ void __launch_bounds__(256) gen_tend_one_kernel(DevTensor T, int ndim, const double *__restrict__ x, double *__restrict__ dx)
+{
+    extern __shared__ double xs[];                         // slot 0 = 1 (the constant), slot d = x_d
+    for (int d = threadIdx.x; d <= ndim; d += blockDim.x) xs[d] = d ? x[d - 1] : 1.0;
+    __syncthreads();
+    for (int i = threadIdx.x + 1; i <= ndim; i += blockDim.x) {
+        double r = 0.0;
+        const int e1 = T.rowptr[i + 1];
+        for (int e = T.rowptr[i]; e < e1; ++e) {
+            const uint32_t jk = T.idx[e];
+            double t = xs[jk >> 16] * xs[jk & 0xffffu];
+            if (T.idx2) { const uint32_t cd = T.idx2[e]; t *= xs[cd >> 16] * xs[cd & 0xffffu]; }
+            r = __builtin_fma(t, T.val[e], r);
+        }
+        dx[i - 1] = r;
+    }
+}
+
+// jm is (ndim, ndim) row-major in DEVICE memory, zero-filled by the caller; thread i owns row i
+__global__ void __launch_bounds__(256) gen_jac_one_kernel(DevTensor Jt, int ndim, const double *__restrict__ x, double *__restrict__ jm)
+{
+    extern __shared__ double xs[];
+    for (int d = threadIdx.x; d <= ndim; d += blockDim.x) xs[d] = d ? x[d - 1] : 1.0;
+    __syncthreads();
+    for (int i = threadIdx.x + 1; i <= ndim; i += blockDim.x) {
+        const int e1 = Jt.rowptr[i + 1];
+        for (int e = Jt.rowptr[i]; e < e1; ++e) {
+            const uint32_t jk = Jt.idx[e];
+            const uint32_t j = jk >> 16;
+            if (j == 0) continue;
+            double xk = xs[jk & 0xffffu];
+            if (Jt.idx2) { const uint32_t cd = Jt.idx2[e]; xk *= xs[cd >> 16] * xs[cd & 0xffffu]; }
+            double *q = jm + (int64_t)(i - 1) * ndim + (j - 1);
+            *q = __builtin_fma(xk, Jt.val[e], *q);
+        }
+    }
+}
+
 __device__ __forceinline__ int64_t rec_index(int64_t iw, int64_t n_records, int backward)
 {
     return backward ? (n_records - 1 - iw) : iw;
@@ -812,6 +852,41 @@ __global__ void __launch_bounds__(256) unpack_records_kernel(int64_t n_inner, in
     }
 }
 
+
+// A window of W records R[W][n_inner][ld] -> columns [0, W) of out, where element (m, q, r) of the output sits at
+// out[(m * n_inner + q) * out_stride + r] (out already points at the window's first record column; out_stride = the
+// record count of the whole run).  64 members x 64 consecutive (q, r) pairs per block through an LDS tile: reads are
+// coalesced along the members, writes along r (runs of W doubles, one run of n_inner * W when W == out_stride), which
+// is what a destination in host memory (PCIe writes) needs.
+__global__ void __launch_bounds__(256) unpack_window_kernel(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W,
+                                                            int64_t out_stride, const double *__restrict__ in,
+                                                            double *__restrict__ out)
+{
+    __shared__ double tile[TILE][TILE + 1];
+    const int64_t m0 = (int64_t)blockIdx.x * TILE, total = n_inner * W;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int64_t c0 = (int64_t)blockIdx.y * TILE; c0 < total; c0 += (int64_t)gridDim.y * TILE) {
+        for (int i = ty; i < TILE; i += 4) {
+            const int64_t c = c0 + i, m = m0 + tx;
+            if (c < total && m < n_traj) {
+                const int64_t q = c / W, r = c - q * W;                 // uniform per wavefront
+                tile[i][tx] = in[(r * n_inner + q) * ld + m];
+            }
+        }
+        __syncthreads();
+        const int64_t c = c0 + tx;
+        if (c < total) {
+            const int64_t q = c / W, r = c - q * W;
+            double *o = out + q * out_stride + r;
+            for (int i = ty; i < TILE; i += 4) {
+                const int64_t m = m0 + i;
+                if (m < n_traj) o[m * n_inner * out_stride] = tile[tx][i];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, const double *x, double *dx, hipStream_t st)
@@ -822,6 +897,16 @@ void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, c
 void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, const double *x, double *jm, hipStream_t st)
 {
     hipLaunchKernelGGL(gen_jac_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, Jt, ndim, n_traj, ld, x, jm);
+}
+
+void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_tend_one_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, T, ndim, x, dx);
+}
+
+void launch_gen_jac_one(const DevTensor &Jt, int ndim, const double *x, double *jm, hipStream_t st)
+{
+    hipLaunchKernelGGL(gen_jac_one_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, Jt, ndim, x, jm);
 }
 
 void launch_gen_rk(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
@@ -1123,6 +1208,14 @@ void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t 
     }
     hipLaunchKernelGGL(unpack_records_kernel, dim3(blocks_for(n_traj, 256), (unsigned)std::min<int64_t>(n_inner, 65535)), dim3(256), 0, st,
                        n_inner, n_traj, ld, n_records, in, out);
+}
+
+void launch_unpack_window(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W, int64_t out_stride, const double *in,
+                          double *out, hipStream_t st)
+{
+    const int64_t cb = (n_inner * W + TILE - 1) / TILE;
+    hipLaunchKernelGGL(unpack_window_kernel, dim3(blocks_for(n_traj, TILE), (unsigned)std::min<int64_t>(cb, 65535)), dim3(256), 0, st,
+                       n_inner, n_traj, ld, W, out_stride, in, out);
 }
 
 void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)

@@ -10,8 +10,10 @@
 #include <hip/hiprtc.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <limits.h>
 #include <spawn.h>
+#include <sys/file.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
@@ -24,8 +26,10 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "codegen.h"
@@ -141,7 +145,11 @@ std::vector<std::string> flags_for(const std::string &src)
 // generates worse code for the fused stepper (324 instead of 282 VGPRs); going through the helper gives the same code
 // object everywhere.  QGS_HIP_INPROC_RTC=1 (or a missing helper) compiles with whatever hiprtc this process has mapped.
 // The identity of the compiler is part of the cache key, so objects of one never pass for the other's.
-std::string helper_path() { return lib_dir() + "/qgs_kcompile"; }
+std::string helper_path()
+{
+    if (const char *e = std::getenv("QGS_HIP_HELPER")) if (*e) return e;      // (tests: a helper that fails)
+    return lib_dir() + "/qgs_kcompile";
+}
 
 // environment of the helper: no preloaded tool libraries (profilers), it must stay a plain compiler process
 std::vector<std::string> helper_env()
@@ -156,17 +164,19 @@ std::vector<std::string> helper_env()
     return env;
 }
 
-// run the helper; stdout + stderr of the child end up in *output
+// run the helper; stdout + stderr of the child end up in *output.
+// Returns 0: exit code 0; 1: the helper ran and reported a failure (exit code 1: a compile error, its log is in *output);
+// -1: the helper could not be run or did not end normally (spawn failure, signal, any other exit code, waitpid failure).
+std::mutex g_helper_mutex;
 int run_helper(const std::vector<std::string> &args, std::string *output)
 {
+    std::lock_guard<std::mutex> lock(g_helper_mutex);        // one spawn + read at a time: no other spawn of ours inherits the pipe
     int fds[2];
-    if (pipe(fds) != 0) return -1;
+    if (pipe2(fds, O_CLOEXEC) != 0) return -1;                // (the dup2 targets 1 and 2 lose CLOEXEC in the child)
     posix_spawn_file_actions_t fa;
     posix_spawn_file_actions_init(&fa);
     posix_spawn_file_actions_adddup2(&fa, fds[1], 1);
     posix_spawn_file_actions_adddup2(&fa, fds[1], 2);
-    posix_spawn_file_actions_addclose(&fa, fds[0]);
-    posix_spawn_file_actions_addclose(&fa, fds[1]);
     std::vector<char *> argv;
     for (const auto &a : args) argv.push_back(const_cast<char *>(a.c_str()));
     argv.push_back(nullptr);
@@ -181,66 +191,104 @@ int run_helper(const std::vector<std::string> &args, std::string *output)
     if (rc != 0) { close(fds[0]); return -1; }
     char buf[4096];
     ssize_t n;
-    while ((n = read(fds[0], buf, sizeof buf)) > 0) if (output) output->append(buf, (size_t)n);
+    while ((n = read(fds[0], buf, sizeof buf)) > 0 || (n < 0 && errno == EINTR)) if (n > 0 && output) output->append(buf, (size_t)n);
     close(fds[0]);
     int status = 0;
-    while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
-    return (WIFEXITED(status) && WEXITSTATUS(status) == 0) ? 0 : 1;
+    pid_t w;
+    while ((w = waitpid(pid, &status, 0)) < 0 && errno == EINTR) {}
+    if (w != pid) return -1;                                   // e.g. ECHILD when the application ignores SIGCHLD: the exit status is lost
+    if (!WIFEXITED(status)) return -1;
+    return WEXITSTATUS(status) == 0 ? 0 : (WEXITSTATUS(status) == 1 ? 1 : -1);
 }
 
-bool use_helper()
+// e.g. "inproc-hiprtc7.0-libhiprtc.so.7.0.51831": the hiprtc this process has mapped
+std::string inproc_compiler_id()
 {
-    static const bool yes = [] {
-        if (const char *e = std::getenv("QGS_HIP_INPROC_RTC")) if (*e == '1') return false;
-        if (access(helper_path().c_str(), X_OK) != 0) {
-            std::fprintf(stderr, "libqgs_hip: %s is missing (make -C qgs_amd/csrc); kernels that miss the cache are compiled by the "
-                                 "hiprtc this process has mapped\n", helper_path().c_str());
-            return false;
-        }
-        return true;
-    }();
-    return yes;
+    int major = 0, minor = 0;
+    (void)hiprtcVersion(&major, &minor);
+    std::string file = "?";
+    Dl_info info;
+    if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
+        char real[PATH_MAX];
+        file = realpath(info.dli_fname, real) ? real : info.dli_fname;
+        const size_t k = file.find_last_of('/');
+        if (k != std::string::npos) file = file.substr(k + 1);
+    }
+    return "inproc-hiprtc" + std::to_string(major) + "." + std::to_string(minor) + "-" + file;
 }
 
-// e.g. "hiprtc9.0-libhiprtc.so.7.2.70200": API level + the library file the compiler resolved to
-std::string compiler_id()
+// Which compiler this process uses, decided once: the helper only when it exists AND answers `--version` (its answer, e.g.
+// "hiprtc9.0-libhiprtc.so.7.2.70200", is the compiler identity in the cache key); otherwise the in-process hiprtc under its
+// own identity.  A helper that stops working later (see compile_source) switches the process to the in-process compiler for
+// good -- `helper` and `id` always change together.
+struct CompilerChoice {
+    bool helper = false;
+    std::string id;
+};
+std::mutex g_compiler_mutex;
+CompilerChoice &compiler_choice_locked()
 {
-    static const std::string id = [] {
-        if (use_helper()) {
-            std::string out;
-            if (run_helper({helper_path(), "--version"}, &out) == 0 && !out.empty()) {
-                while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
-                return out;
+    static CompilerChoice c;
+    static bool decided = false;
+    if (!decided) {
+        decided = true;
+        c.id = inproc_compiler_id();
+        const char *e = std::getenv("QGS_HIP_INPROC_RTC");
+        if (!(e && *e == '1')) {
+            if (access(helper_path().c_str(), X_OK) != 0) {
+                std::fprintf(stderr, "libqgs_hip: %s is missing (make -C qgs_amd/csrc); kernels that miss the cache are compiled by the "
+                                     "hiprtc this process has mapped\n", helper_path().c_str());
+            } else {
+                std::string out;
+                if (run_helper({helper_path(), "--version"}, &out) == 0 && !out.empty()) {
+                    while (!out.empty() && (out.back() == '\n' || out.back() == '\r')) out.pop_back();
+                    c.helper = true;
+                    c.id = out;
+                } else {
+                    std::fprintf(stderr, "libqgs_hip: %s --version failed (%s); compiling in-process\n", helper_path().c_str(), out.c_str());
+                }
             }
-            std::fprintf(stderr, "libqgs_hip: %s --version failed: %s\n", helper_path().c_str(), out.c_str());
         }
-        int major = 0, minor = 0;
-        (void)hiprtcVersion(&major, &minor);
-        std::string file = "?";
-        Dl_info info;
-        if (dladdr((void *)&hiprtcVersion, &info) && info.dli_fname) {
-            char real[PATH_MAX];
-            file = realpath(info.dli_fname, real) ? real : info.dli_fname;
-            const size_t k = file.find_last_of('/');
-            if (k != std::string::npos) file = file.substr(k + 1);
-        }
-        return "inproc-hiprtc" + std::to_string(major) + "." + std::to_string(minor) + "-" + file;
-    }();
-    return id;
+    }
+    return c;
 }
-
-std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra)
+CompilerChoice compiler_choice()
 {
-    std::string opts_key = arch + "|O3|c++17|v2|" + compiler_id();
+    std::lock_guard<std::mutex> lock(g_compiler_mutex);
+    return compiler_choice_locked();
+}
+void disable_helper(const std::string &why)
+{
+    std::lock_guard<std::mutex> lock(g_compiler_mutex);
+    CompilerChoice &c = compiler_choice_locked();
+    if (c.helper) {
+        std::fprintf(stderr, "libqgs_hip: %s no longer usable (%s); compiling in-process from now on\n", helper_path().c_str(), why.c_str());
+        c.helper = false;
+        c.id = inproc_compiler_id();
+    }
+}
+std::string compiler_id() { return compiler_choice().id; }
+
+std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra, const std::string &id)
+{
+    std::string opts_key = arch + "|O3|c++17|v2|" + id;
     for (const auto &x : extra) opts_key += "|" + x;
     char name[64];
     std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
     return cache_dir() + "/" + name + ".hsaco";
 }
 
+bool read_file(const std::string &path, std::vector<char> &out)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return !out.empty();
+}
+
 bool source_is_cached(const std::string &src, const std::string &arch)
 {
-    std::ifstream f(cache_path(src, arch, flags_for(src)), std::ios::binary);
+    std::ifstream f(cache_path(src, arch, flags_for(src), compiler_id()), std::ios::binary);
     return (bool)f;
 }
 
@@ -269,51 +317,107 @@ int compile_in_process(const std::string &src, const std::string &arch, const st
     return 0;
 }
 
+std::string scratch_dir()
+{
+    for (const char *v : {"QGS_HIP_TMPDIR", "TMPDIR"})
+        if (const char *e = std::getenv(v)) if (*e && access(e, W_OK) == 0) return e;
+    return "/tmp";
+}
+
+// a fresh private file under the scratch directory (mkstemp); "" on failure
+std::string make_temp(const std::string &suffix_hint)
+{
+    std::string templ = scratch_dir() + "/qgs_hip_" + suffix_hint + "_XXXXXX";
+    std::vector<char> buf(templ.begin(), templ.end());
+    buf.push_back('\0');
+    const int fd = mkstemp(buf.data());
+    if (fd < 0) return "";
+    close(fd);
+    return std::string(buf.data());
+}
+
+// Best effort: put the code object into the kernel cache (write next to the final name, then rename = atomic publish).  A
+// cache directory that is read-only (shared install) just means the next process compiles again.
+void publish_to_cache(const std::string &path, const std::vector<char> &code)
+{
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return;
+        f.write(code.data(), (std::streamsize)code.size());
+        f.close();
+        if (!f) { std::remove(tmp.c_str()); return; }
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+}
+
+// Several processes that miss the same cache entry at the same time (8 ranks creating the same model on a cold cache)
+// compile it once: the first takes an advisory lock on <entry>.lock, the others wait on it and then find the entry.  No lock
+// (read-only cache directory): everybody compiles, nothing is shared, nothing breaks.
+struct CacheLock {
+    int fd = -1;
+    std::string path;
+    explicit CacheLock(const std::string &entry) : path(entry + ".lock")
+    {
+        fd = open(path.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (fd >= 0) while (flock(fd, LOCK_EX) != 0 && errno == EINTR) {}
+    }
+    ~CacheLock()
+    {
+        if (fd >= 0) {
+            std::remove(path.c_str());
+            flock(fd, LOCK_UN);
+            close(fd);
+        }
+    }
+};
+
 int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
 {
     const std::vector<std::string> extra = flags_for(src);
-    const std::string path = cache_path(src, arch, extra);
-    {
-        std::ifstream f(path, std::ios::binary);
-        if (f) {
-            code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-            if (!code.empty()) { if (from_cache) *from_cache = true; return 0; }
-        }
-    }
+    CompilerChoice cc = compiler_choice();
+    std::string path = cache_path(src, arch, extra, cc.id);
+    if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }
+    CacheLock lock(path);
+    if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }      // somebody else compiled it meanwhile
     if (from_cache) *from_cache = false;
     if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // developer knob: keep the generated source
         std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
         f << src;
     }
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    if (use_helper()) {
-        const std::string srcfile = tmp + ".hip";
-        {
+    if (cc.helper) {
+        // source and object travel through private temp files under $TMPDIR, not through the cache directory
+        std::string why;
+        const std::string srcfile = make_temp("src"), objfile = make_temp("obj");
+        if (srcfile.empty() || objfile.empty()) why = "cannot create temp files under " + scratch_dir();
+        if (why.empty()) {
             std::ofstream f(srcfile, std::ios::binary);
             f << src;
-            if (!f) return fail("cannot write " + srcfile + " (kernel cache directory not writable?)");
+            f.close();
+            if (!f) why = "cannot write " + srcfile;
         }
-        std::vector<std::string> args = {helper_path(), arch, srcfile, tmp};
-        args.insert(args.end(), extra.begin(), extra.end());
+        int rc = -1;
         std::string out;
-        const int rc = run_helper(args, &out);
-        std::remove(srcfile.c_str());
-        if (rc != 0) { std::remove(tmp.c_str()); return fail("kernel compilation failed (" + helper_path() + "):\n" + out.substr(0, 4000)); }
-        std::ifstream f(tmp, std::ios::binary);
-        code.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-        if (code.empty()) { std::remove(tmp.c_str()); return fail("kernel compilation produced no code object"); }
-        std::rename(tmp.c_str(), path.c_str());                   // atomic publish into the cache
-        return 0;
+        if (why.empty()) {
+            std::vector<std::string> args = {helper_path(), arch, srcfile, objfile};
+            args.insert(args.end(), extra.begin(), extra.end());
+            rc = run_helper(args, &out);
+            if (rc < 0) why = "helper did not run to completion: " + out.substr(0, 400);
+        }
+        const bool got = (rc == 0) && read_file(objfile, code);
+        if (rc == 0 && !got) why = "helper produced no code object";
+        if (!srcfile.empty()) std::remove(srcfile.c_str());
+        if (!objfile.empty()) std::remove(objfile.c_str());
+        if (rc == 1) return fail("kernel compilation failed (" + helper_path() + "):\n" + out.substr(0, 4000));    // a real compile error
+        if (got) { publish_to_cache(path, code); return 0; }
+        // the helper is not usable (any more): this process compiles in-process from here on, under that compiler's identity
+        disable_helper(why);
+        cc = compiler_choice();
+        path = cache_path(src, arch, extra, cc.id);
+        if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }
     }
     if (compile_in_process(src, arch, extra, code)) return -1;
-    {   // atomic publish into the cache
-        std::ofstream f(tmp, std::ios::binary);
-        if (f) {
-            f.write(code.data(), (std::streamsize)code.size());
-            f.close();
-            std::rename(tmp.c_str(), path.c_str());
-        }
-    }
+    publish_to_cache(path, code);
     return 0;
 }
 
@@ -393,6 +497,8 @@ struct LaunchTuning {
     int64_t tgls_chunk = 0;            // QGS_HIP_TGLS_CHUNK: steps per trajectory / tangent pass pair (0: by the stage-record size)
     size_t tgl_share_min_bytes = (size_t)256 << 20;   // QGS_HIP_TGL_SHARE_MIN_MB
     bool tgl_plain = false;            // QGS_HIP_TGL_VARIANT=plain: never the shared-stage-state tangent kernel
+    size_t window_bytes = (size_t)8 << 30;   // QGS_HIP_RECORD_WINDOW_MB: device memory the host-layout entry points spend on record windows
+    int d2h_mode = 0;                  // QGS_HIP_D2H=kernel|copy -> 1 | 2: records reach a page-locked host block by stores of the unpack kernel, or by a copy (0: by measurement)
     void read_env()
     {
         if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) wave_max_traj = std::atoll(e);
@@ -404,6 +510,8 @@ struct LaunchTuning {
         if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) tgls_chunk = std::max<int64_t>(1, std::atoll(e));
         if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) tgl_share_min_bytes = (size_t)std::atoll(e) << 20;
         if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_plain = !std::strcmp(e, "plain");
+        if (const char *e = std::getenv("QGS_HIP_RECORD_WINDOW_MB")) window_bytes = (size_t)std::max(1.0, std::atof(e) * 1048576.0);   // fractions allowed
+        if (const char *e = std::getenv("QGS_HIP_D2H")) d2h_mode = !std::strcmp(e, "kernel") ? 1 : (!std::strcmp(e, "copy") ? 2 : 0);
     }
 };
 
@@ -471,7 +579,14 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit;
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit, b_carry, b_win[2], b_fwin[2];
+    // host-layout pipeline: compute stream, copy stream, "window k computed" / "window k drained" events (created on first use)
+    hipStream_t st_comp = nullptr, st_copy = nullptr;
+    hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
+    // single-state fast path of f / Df: page-locked staging block the kernels read and write directly
+    double *h_pin = nullptr, *d_pin = nullptr;
+    size_t pin_cap = 0;
+    int64_t last_windows = 0;      // windows of the last host-layout integration (qgs_model_info 8)
     KernelInfo last;
 };
 
@@ -1042,8 +1157,16 @@ int qgs_model_destroy(qgs_model *m)
     for (void *q : {(void *)m->t_row_term, (void *)m->t_term_joff, (void *)m->t_term_koff, (void *)m->t_term_c, (void *)m->t_row_map})
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
-                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out, &m->b_unit})
+                      &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out, &m->b_unit,
+                      &m->b_carry, &m->b_win[0], &m->b_win[1], &m->b_fwin[0], &m->b_fwin[1]})
         b->release();
+    for (int i = 0; i < 2; ++i) {
+        if (m->ev_comp[i]) (void)hipEventDestroy(m->ev_comp[i]);
+        if (m->ev_copy[i]) (void)hipEventDestroy(m->ev_copy[i]);
+    }
+    if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
+    if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
+    if (m->h_pin) (void)hipHostFree(m->h_pin);
     delete m;
     return 0;
 }
@@ -1060,6 +1183,7 @@ int64_t qgs_model_info(const qgs_model *m, int which)
     case 5: return m->rank;
     case 6: return (int64_t)m->der.t.size();
     case 7: return (int64_t)m->der.j.size();
+    case 8: return m->last_windows;
     default: return -1;
     }
 }
@@ -1187,31 +1311,26 @@ static int jacobian_device(qgs_model *m, int64_t n_traj, int64_t ld, const doubl
     return 0;
 }
 
-int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_ic, const double *time,
-                            int64_t n_time, int time_direction, int64_t write_steps, int s, const double *b,
-                            const double *c, const double *a, double *d_rec, void *stream)
+// One launch of the trajectory stepper over the steps [step_begin, step_end) of a run of n_steps steps: state in from y_in,
+// state out to y_out (may be null), records of the steps in the range to d_rec (indexed by the record number of the WHOLE run:
+// a caller that keeps only a window of records passes the window's base minus the offset of its first record), the final
+// record when write_final.  Which kernel runs depends on the run (ensemble size, tableau, write_steps), never on the range, so
+// a run cut into ranges is bitwise the run in one piece.
+static int rk_launch(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_ic, double *y_out, double *d_rec,
+                     const double *d_time, const double *d_tab_spec, const double *d_tab_full, int64_t step_begin,
+                     int64_t step_end, int64_t n_steps, int64_t write_steps, int64_t n_records, int backward, int write_final,
+                     int s, const double *a, hipStream_t st)
 {
-    (void)c;   // autonomous system: f ignores t (tendencies.py:112)
-    if (check_common(m, n_traj, ld)) return -1;
-    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
-    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
-    if (write_steps < 0) return fail("write_steps must be >= 0");
-    HIPCHK(hipSetDevice(m->device));
-    hipStream_t st = (hipStream_t)stream;
-    const double *d_time, *d_tab_spec, *d_tab_full;
-    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
-    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
-    const int backward = time_direction == -1;
     if (use_wave(m, n_traj, s, a)) {
         // small ensemble: one workgroup per trajectory, lane = tensor row (latency-optimised)
-        qgs::RkArgs pw{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
-        HIPCHK(qgs::launch_gen_rk_wave(m->wave_T(), m->max_row_terms, pw, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st, m->chains(false)));
+        qgs::RkArgs pw{m->ndim, s, n_traj, ld, step_begin, step_end, write_steps, n_records, backward, write_final};
+        HIPCHK(qgs::launch_gen_rk_wave(m->wave_T(), m->max_row_terms, pw, d_ic, y_out, d_rec, nullptr, d_time, d_tab_spec, st, m->chains(false)));
         note_kernel(m, "gen_rk_wave_kernel", nullptr);
         return 0;
     }
-    if (m->prefer_lds && use_lds_spec(m, n_traj, n_time - 1, s, a))
-        return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
-                             n_records, backward, 1, s, st);
+    if (m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a))
+        return launch_rk_lds(m, n_traj, ld, d_ic, y_out, d_rec, nullptr, d_time, d_tab_spec, step_begin, step_end, write_steps,
+                             n_records, backward, write_final, s, st);
     if (use_spec(m, s, a)) {
         // Kernel choice by ensemble size (measured, tools/kbench.py / tools/latency_bench.py, MAOOAM-36, ms per 1000 steps):
         //   n <= 2048      wave-per-trajectory kernel (handled above)        0.8-1.5
@@ -1229,9 +1348,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         hipFunction_t f;
         std::string name;
         if (get_function(m, split ? qgs::Kernel::RkSplit : (spread ? qgs::Kernel::RkRec : qgs::Kernel::Rk), s, &f, &name)) return -1;
-        double *y_out = nullptr, *stg = nullptr;
-        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
-        int bw = backward, wf = 1;
+        double *stg = nullptr;
+        long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
+        int bw = backward, wf = write_final;
         void *args[] = {(void *)&d_ic, &y_out, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_spec,
                         &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
         note_kernel(m, name, f);
@@ -1239,12 +1358,12 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         HIPCHK(hipModuleLaunchKernel(f, blocks, 1, 1, split ? 64 * R : 64, 1, 1, 0, st, args, nullptr));
         return 0;
     }
-    if (use_lds_spec(m, n_traj, n_time - 1, s, a))
-        return launch_rk_lds(m, n_traj, ld, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, 0, n_time - 1, write_steps,
-                             n_records, backward, 1, s, st);
+    if (use_lds_spec(m, n_traj, n_steps, s, a))
+        return launch_rk_lds(m, n_traj, ld, d_ic, y_out, d_rec, nullptr, d_time, d_tab_spec, step_begin, step_end, write_steps,
+                             n_records, backward, write_final, s, st);
     if (m->kernel_kind != 1 && m->lds_spec_possible && s >= 2 && s <= 64 && !qgs::tableau_is_subdiagonal(s, a) &&
         tableau_is_lower_triangular(s, a) &&
-        lds_kernel_wanted(m, qgs::Kernel::RkLdsDense, (double)n_traj * (double)(n_time - 1) * (double)s * (double)m->T.size())) {
+        lds_kernel_wanted(m, qgs::Kernel::RkLdsDense, (double)n_traj * (double)n_steps * (double)s * (double)m->T.size())) {
         // general tableau at LDS-resident sizes: same kernel text, partial stage sums in a private global buffer
         hipFunction_t f;
         std::string name;
@@ -1252,9 +1371,9 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         const int64_t blocks = (n_traj + 63) / 64;
         if (m->b_ywork.ensure(sizeof(double) * (size_t)m->ndim * 64 * (size_t)blocks)) return -1;
         if (m->b_vwork.ensure(sizeof(double) * (size_t)s * m->ndim * 64 * (size_t)blocks)) return -1;
-        double *yw = m->b_ywork.f64(), *pw = m->b_vwork.f64(), *y_out = nullptr, *stg = nullptr;
-        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
-        int bw = backward, wf = 1, S = s;
+        double *yw = m->b_ywork.f64(), *pw = m->b_vwork.f64(), *stg = nullptr;
+        long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
+        int bw = backward, wf = write_final, S = s;
         void *args[] = {(void *)&d_ic, &y_out, &yw, &pw, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_full,
                         &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S};
         note_kernel(m, name, f);
@@ -1267,45 +1386,53 @@ int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const doub
         hipFunction_t f;
         std::string name;
         if (get_function(m, qgs::Kernel::RkDense, s, &f, &name)) return -1;
-        double *y_out = nullptr, *stg = nullptr;
-        long long nt = n_traj, l = ld, sb = 0, se = n_time - 1, ws = write_steps, nr = n_records;
-        int bw = backward, wf = 1;
+        double *stg = nullptr;
+        long long nt = n_traj, l = ld, sb = step_begin, se = step_end, ws = write_steps, nr = n_records;
+        int bw = backward, wf = write_final;
         void *args[] = {(void *)&d_ic, &y_out, &d_rec, &stg, (void *)&d_time, (void *)&d_tab_full, &nt, &l, &sb, &se, &ws, &nr, &bw, &wf};
         note_kernel(m, name, f);
         return launch(f, n_traj, st, args);
     }
-    qgs::RkArgs p{m->ndim, s, n_traj, ld, 0, n_time - 1, write_steps, n_records, backward, 1};
+    qgs::RkArgs p{m->ndim, s, n_traj, ld, step_begin, step_end, write_steps, n_records, backward, write_final};
     if (use_tiled(m, s, a)) {
-        HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, d_ic, nullptr, d_rec, nullptr, d_time, d_tab_spec, st));
+        HIPCHK(qgs::launch_gen_rk_tiled(m->tiled(), p, d_ic, y_out, d_rec, nullptr, d_time, d_tab_spec, st));
         note_kernel(m, "gen_rk_tiled_kernel", nullptr);
         return 0;
     }
     if (m->work.ensure(sizeof(double) * (size_t)(s + 2) * m->ndim * ld)) return -1;
-    qgs::launch_gen_rk(m->dT.view(), p, d_ic, nullptr, d_rec, nullptr, m->work.f64(), d_time, d_tab_full, st);
+    qgs::launch_gen_rk(m->dT.view(), p, d_ic, y_out, d_rec, nullptr, m->work.f64(), d_time, d_tab_full, st);
     note_kernel(m, "gen_rk_kernel", nullptr);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_ic,
-                                 const double *d_tg_ic, const double *time, int64_t n_time, int time_direction,
-                                 int64_t write_steps, int s, const double *b, const double *c, const double *a,
-                                 int adjoint, double inverse, double *d_rec, double *d_rec_fm, void *stream)
+int qgs_rk_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_ic, const double *time,
+                            int64_t n_time, int time_direction, int64_t write_steps, int s, const double *b,
+                            const double *c, const double *a, double *d_rec, void *stream)
 {
-    (void)c;
+    (void)c;   // autonomous system: f ignores t (tendencies.py:112)
     if (check_common(m, n_traj, ld)) return -1;
-    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
-    if (n_tg < 1) return fail("n_tg must be >= 1");
     if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
     if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
     if (write_steps < 0) return fail("write_steps must be >= 0");
+    if (!d_ic || !d_rec) return fail("null device pointer");
     HIPCHK(hipSetDevice(m->device));
     hipStream_t st = (hipStream_t)stream;
     const double *d_time, *d_tab_spec, *d_tab_full;
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
-    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
-    const int backward = time_direction == -1;
-    const int64_t n_steps = n_time - 1;
+    return rk_launch(m, n_traj, ld, d_ic, nullptr, d_rec, d_time, d_tab_spec, d_tab_full, 0, n_time - 1, n_time - 1, write_steps,
+                     qgs_n_records(time, n_time, write_steps), time_direction == -1, 1, s, a, st);
+}
+
+// Trajectory + tangent / adjoint passes over the steps [step_lo, step_hi) of a run of n_steps steps.  `first`: the states come
+// from d_ic / d_tg_ic, otherwise from the model's carry buffers (b_state2 / b_tg2), where every call leaves the states it
+// ended with.  Records are indexed by the record number of the whole run (see rk_launch); the final record is written when
+// write_final.  Kernel choices depend on the run, not on the range.
+static int tgls_launch(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_ic, const double *d_tg_ic,
+                       const double *d_time, const double *d_tab_spec, const double *d_tab_full, int64_t step_lo, int64_t step_hi,
+                       int64_t n_steps, bool first_range, int write_final, int64_t write_steps, int64_t n_records, int backward,
+                       int s, const double *a, int adjoint, double inverse, double *d_rec, double *d_rec_fm, hipStream_t st)
+{
     const int64_t A = (int64_t)m->ndim * ld, L = n_tg * ld;
     const bool spec = use_spec(m, s, a);
     // general lower-triangular tableau on the register-resident kernels (partial stage sums in LDS)
@@ -1331,11 +1458,11 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
     double *stages = m->stages.f64();
     const qgs::DevTensor Jrow = adjoint ? m->dJ_by_j.view() : m->dJ_by_i.view();
 
-    int64_t begin = 0;
-    bool first = true;
+    int64_t begin = step_lo;
+    bool first = first_range;
     do {
-        const int64_t end = std::min(n_steps, begin + chunk);
-        const int final_chunk = (end == n_steps);
+        const int64_t end = std::min(step_hi, begin + chunk);
+        const int final_chunk = (end == step_hi) && write_final;
         const double *y_src = first ? d_ic : y_state;
         const double *w_src = first ? d_tg_ic : w_state;
         // which tangent kernel this chunk takes (decided first: the stepper has to know the layout of the stage record it feeds)
@@ -1422,8 +1549,30 @@ int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64
         }
         begin = end;
         first = false;
-    } while (begin < n_steps);
+    } while (begin < step_hi);
     return 0;
+}
+
+int qgs_rk_tgls_integrate_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_ic,
+                                 const double *d_tg_ic, const double *time, int64_t n_time, int time_direction,
+                                 int64_t write_steps, int s, const double *b, const double *c, const double *a,
+                                 int adjoint, double inverse, double *d_rec, double *d_rec_fm, void *stream)
+{
+    (void)c;
+    if (check_common(m, n_traj, ld)) return -1;
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    if (n_tg < 1) return fail("n_tg must be >= 1");
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    if (!d_ic || !d_tg_ic || !d_rec || !d_rec_fm) return fail("null device pointer");
+    HIPCHK(hipSetDevice(m->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, st, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    return tgls_launch(m, n_traj, ld, n_tg, d_ic, d_tg_ic, d_time, d_tab_spec, d_tab_full, 0, n_time - 1, n_time - 1, true, 1,
+                       write_steps, qgs_n_records(time, n_time, write_steps), time_direction == -1, s, a, adjoint, inverse,
+                       d_rec, d_rec_fm, st);
 }
 
 int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_cols, double *d_a, double *d_rdiag,
@@ -1488,10 +1637,101 @@ int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_
 
 static int64_t round_ld(int64_t n) { return (n + 63) / 64 * 64; }
 
+// ---- single state: f(x), Df(x) for one (ndim,) vector ----------------------------------------------------------------------
+// The callables the reference hands to SciPy / DiffEq solvers (documentation user_guide.rst:502-517) evaluate ONE state per
+// call.  For one member the reference's (ndim,) layout and the mode-major layout coincide (ld = 1), so nothing is packed or
+// unpacked: the state is copied (CPU memcpy, 288 bytes at ndim 36) into a page-locked block that the kernel reads over PCIe, the
+// kernel writes its result into the same block, one launch, one stream synchronisation.
+static int pin_ensure(qgs_model *m, size_t doubles)
+{
+    if (doubles <= m->pin_cap) return 0;
+    if (m->h_pin) (void)hipHostFree(m->h_pin);
+    m->h_pin = m->d_pin = nullptr;
+    m->pin_cap = 0;
+    HIPCHK(hipHostMalloc((void **)&m->h_pin, sizeof(double) * doubles, hipHostMallocMapped));
+    HIPCHK(hipHostGetDevicePointer((void **)&m->d_pin, m->h_pin, 0));
+    m->pin_cap = doubles;
+    return 0;
+}
+
+static int streams_ready(qgs_model *m)
+{
+    if (m->st_comp) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&m->st_comp, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&m->st_copy, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&m->ev_comp[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_copy[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+static int tendencies_one(qgs_model *m, const double *x, double *dx)
+{
+    const int nd = m->ndim;
+    if (streams_ready(m) || pin_ensure(m, 2 * (size_t)nd)) return -1;
+    hipStream_t st = m->st_comp;
+    std::memcpy(m->h_pin, x, sizeof(double) * nd);
+    const double *d_x = m->d_pin;
+    double *d_dx = m->d_pin + nd;
+    if (use_spec(m, 1, nullptr) && !m->prefer_lds) {
+        hipFunction_t f;
+        if (get_function(m, qgs::Kernel::Tend, 0, &f)) return -1;
+        long long nt = 1, l = 1;
+        void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
+        note_kernel(m, "qgs_spec_tend", f);
+        if (launch(f, 1, st, args)) return -1;
+    } else {
+        if (nd > 8190) return fail("ndim too large for the single-state kernel");
+        qgs::launch_gen_tend_one(m->dT.view(), nd, d_x, d_dx, st);
+        note_kernel(m, "gen_tend_one_kernel", nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    std::memcpy(dx, m->h_pin + nd, sizeof(double) * nd);
+    return 0;
+}
+
+static int jacobian_one(qgs_model *m, const double *x, double *jac)
+{
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    const int nd = m->ndim;
+    const size_t nn = (size_t)nd * nd;
+    if (streams_ready(m) || pin_ensure(m, (size_t)nd + nn)) return -1;
+    hipStream_t st = m->st_comp;
+    std::memcpy(m->h_pin, x, sizeof(double) * nd);
+    const double *d_x = m->d_pin;
+    if (use_spec(m, 1, nullptr) && m->spec_jac_possible) {
+        // the specialised kernel stores every structural entry exactly once: it writes the page-locked block itself
+        double *d_j = m->d_pin + nd;
+        std::memset(m->h_pin + nd, 0, sizeof(double) * nn);
+        hipFunction_t f;
+        if (get_function(m, qgs::Kernel::Jac, 0, &f)) return -1;
+        long long nt = 1, l = 1;
+        void *args[] = {(void *)&d_x, (void *)&d_j, &nt, &l};
+        note_kernel(m, "qgs_spec_jac", f);
+        if (launch(f, 1, st, args)) return -1;
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        // the generic kernel accumulates into its output: device buffer, then one copy into the page-locked block
+        if (nd > 8190) return fail("ndim too large for the single-state kernel");
+        if (m->b_fm_modes.ensure(sizeof(double) * nn)) return -1;
+        HIPCHK(hipMemsetAsync(m->b_fm_modes.p, 0, sizeof(double) * nn, st));
+        qgs::launch_gen_jac_one(m->dJ_by_i.view(), nd, d_x, m->b_fm_modes.f64(), st);
+        note_kernel(m, "gen_jac_one_kernel", nullptr);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(m->h_pin + nd, m->b_fm_modes.p, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    std::memcpy(jac, m->h_pin + nd, sizeof(double) * nn);
+    return 0;
+}
+
 int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx)
 {
     if (!m || !x || !dx || n_traj < 1) return fail("bad arguments");
     HIPCHK(hipSetDevice(m->device));
+    if (n_traj == 1 && m->kernel_kind != 1) return tendencies_one(m, x, dx);
     const int64_t ld = round_ld(n_traj);
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b)) return -1;
@@ -1507,6 +1747,7 @@ int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac)
 {
     if (!m || !x || !jac || n_traj < 1) return fail("bad arguments");
     HIPCHK(hipSetDevice(m->device));
+    if (n_traj == 1 && m->kernel_kind != 1) return jacobian_one(m, x, jac);
     const int64_t ld = round_ld(n_traj), nn = (int64_t)m->ndim * m->ndim;
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     const size_t jm_b = sizeof(double) * (size_t)ld * nn, jr_b = sizeof(double) * (size_t)n_traj * nn;
@@ -1520,25 +1761,148 @@ int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac)
     return 0;
 }
 
+// ---- record windows: the host-layout integrations --------------------------------------------------------------------------
+// The reference's record is a host array (integrate.py:196, integrator.py:378-395): its size limit is host memory, not HBM.  The
+// steppers therefore write W records at a time into one of two mode-major device windows; while window k + 1 is being
+// computed (compute stream), window k is transposed into the caller's (n_traj, n_inner, n_records) layout and leaves the device
+// (copy stream):
+//   * destination the GPU can address (page-locked host block of qgs_host_register, or device memory): the unpack kernel stores
+//     straight into it, runs of W doubles at record offset lo -- no second copy of the record on the device at all;
+//   * pageable host memory: unpack into a device staging block, then one (strided) device-to-host copy.
+// W = what QGS_HIP_RECORD_WINDOW_MB (default 8192) pays for; a record that fits is one window.
+struct WindowPlan {
+    int64_t n_records = 1, n_steps = 0, write_steps = 0, W = 1, n_windows = 1;
+    int backward = 0;
+    // window k: directed records [lo, hi), steps [sb, se), final record included?, first stored record index
+    void window(int64_t k, int64_t *lo, int64_t *hi, int64_t *sb, int64_t *se, int *wf, int64_t *lo_s) const
+    {
+        *lo = k * W;
+        *hi = std::min(n_records, *lo + W);
+        *wf = (*hi == n_records) ? 1 : 0;
+        *sb = write_steps > 0 ? std::min(n_steps, *lo * write_steps) : 0;
+        *se = *wf ? n_steps : std::min(n_steps, *hi * write_steps);
+        *lo_s = backward ? (n_records - *hi) : *lo;
+    }
+};
+
+static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_steps, int64_t write_steps, int backward,
+                               size_t bytes_per_record, int buffers)
+{
+    WindowPlan p;
+    p.n_records = n_records; p.n_steps = n_steps; p.write_steps = write_steps; p.backward = backward;
+    const size_t per = std::max<size_t>(1, bytes_per_record * (size_t)buffers);
+    p.W = (int64_t)std::max<size_t>(1, m->tune.window_bytes / per);
+    if (p.W >= n_records) { p.W = n_records; p.n_windows = 1; }
+    else p.n_windows = (n_records + p.W - 1) / p.W;
+    return p;
+}
+
+// device-side address of a destination block: the block itself when it is device memory, its mapped alias when it is
+// page-locked host memory (qgs_host_register / hipHostMalloc), null for pageable host memory
+static double *device_alias(qgs_model *m, double *dst)
+{
+    if (m->tune.d2h_mode == 2) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type == hipMemoryTypeDevice) return dst;
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (double *)dp;
+}
+
+// one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
+static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
+                        const double *d_win, double *alias, double *dst_host, Buffer &staging, hipStream_t st)
+{
+    if (alias) {
+        qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, n_records, d_win, alias + lo_s, st);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    const size_t rows = (size_t)n_traj * (size_t)n_inner;
+    if (staging.ensure(sizeof(double) * rows * (size_t)Wk)) return -1;
+    qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, Wk, d_win, staging.f64(), st);
+    HIPCHK(hipGetLastError());
+    if (Wk == n_records)
+        HIPCHK(hipMemcpyAsync(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, hipMemcpyDeviceToHost, st));
+    else
+        HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
+                                sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
+    return 0;
+}
+
+// ic_rows: (n_traj, ndim) in host memory (ic_on_device == 0) or device memory; traj: (n_traj, ndim, n_records) in host memory
+// (pageable or page-locked) or device memory.  Blocking.
+static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int ic_on_device, const double *time, int64_t n_time,
+                       int time_direction, int64_t write_steps, int s, const double *b, const double *a, double *traj)
+{
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    HIPCHK(hipSetDevice(m->device));
+    if (streams_ready(m)) return -1;
+    const int nd = m->ndim;
+    const int64_t ld = round_ld(n_traj), n_steps = n_time - 1;
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    const int backward = time_direction == -1;
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * nd, modes_b = sizeof(double) * (size_t)ld * nd;
+    hipStream_t sc = m->st_comp, sd = m->st_copy;
+    if (m->b_in_modes.ensure(modes_b)) return -1;
+    const double *d_rows = ic_rows;
+    if (!ic_on_device) {
+        if (m->b_in_rows.ensure(rows_b)) return -1;
+        HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic_rows, rows_b, hipMemcpyHostToDevice, sc));
+        d_rows = m->b_in_rows.f64();
+    }
+    qgs::launch_pack_states(nd, n_traj, ld, d_rows, m->b_in_modes.f64(), sc);
+    HIPCHK(hipGetLastError());
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    double *alias = device_alias(m, traj);
+    const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
+    m->last_windows = plan.n_windows;
+    const int nbuf = plan.n_windows > 1 ? 2 : 1;
+    for (int i = 0; i < nbuf; ++i) if (m->b_win[i].ensure(modes_b * (size_t)plan.W)) return -1;
+    if (plan.n_windows > 1 && (m->b_state2.ensure(modes_b) || m->b_carry.ensure(modes_b))) return -1;
+    const double *y_in = m->b_in_modes.f64();
+    for (int64_t k = 0; k < plan.n_windows; ++k) {
+        int64_t lo, hi, sb, se, lo_s;
+        int wf;
+        plan.window(k, &lo, &hi, &sb, &se, &wf, &lo_s);
+        const int q = (int)(k & 1);
+        double *win = m->b_win[q].f64();
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(sc, m->ev_copy[q], 0));            // the window's previous content has left
+        double *y_out = (k + 1 < plan.n_windows) ? ((k & 1) ? m->b_carry.f64() : m->b_state2.f64()) : nullptr;
+        if (rk_launch(m, n_traj, ld, y_in, y_out, win - lo_s * (int64_t)nd * ld, d_time, d_tab_spec, d_tab_full, sb, se, n_steps,
+                      write_steps, n_records, backward, wf, s, a, sc)) return -1;
+        if (y_out) y_in = y_out;
+        HIPCHK(hipEventRecord(m->ev_comp[q], sc));
+        HIPCHK(hipStreamWaitEvent(sd, m->ev_comp[q], 0));
+        if (drain_window(m, nd, n_traj, ld, hi - lo, n_records, lo_s, win, alias, traj, m->b_rec_rows, sd)) return -1;
+        HIPCHK(hipEventRecord(m->ev_copy[q], sd));
+    }
+    HIPCHK(hipStreamSynchronize(sc));
+    HIPCHK(hipStreamSynchronize(sd));
+    return 0;
+}
+
 int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
                      int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
                      double *traj)
 {
+    (void)c;
     if (!m || !ic || !traj || n_traj < 1) return fail("bad arguments");
-    if (!time || n_time < 1) return fail("bad time grid");
-    HIPCHK(hipSetDevice(m->device));
-    const int64_t ld = round_ld(n_traj);
-    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
-    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
-    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
-        m->b_rec_rows.ensure(rows_b * (size_t)n_records)) return -1;
-    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
-    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
-    if (qgs_rk_integrate_device(m, n_traj, ld, m->b_in_modes.f64(), time, n_time, time_direction, write_steps, s, b, c, a,
-                                m->b_rec_modes.f64(), nullptr)) return -1;
-    if (qgs_unpack_records(m, n_traj, ld, m->ndim, n_records, m->b_rec_modes.f64(), m->b_rec_rows.f64(), nullptr)) return -1;
-    HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
-    return 0;
+    return rk_windowed(m, n_traj, ic, 0, time, n_time, time_direction, write_steps, s, b, a, traj);
+}
+
+int qgs_rk_integrate_rows_device(qgs_model *m, int64_t n_traj, const double *d_ic_rows, const double *time, int64_t n_time,
+                                 int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
+                                 double *d_traj_rows)
+{
+    (void)c;
+    if (!m || !d_ic_rows || !d_traj_rows || n_traj < 1) return fail("bad arguments");
+    return rk_windowed(m, n_traj, d_ic_rows, 1, time, n_time, time_direction, write_steps, s, b, a, d_traj_rows);
 }
 
 int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
@@ -1582,37 +1946,64 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
                           const double *b, const double *c, const double *a, int adjoint, double inverse, double *traj,
                           double *fmatrix)
 {
+    (void)c;
     if (!m || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
-    if (!time || n_time < 1) return fail("bad time grid");
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
     if ((int64_t)m->ndim * n_tg > (int64_t)65535 * 64) return fail("ndim * n_tg too large for the layout conversion kernels");
     HIPCHK(hipSetDevice(m->device));
-    const int64_t ld = round_ld(n_traj);
+    if (streams_ready(m)) return -1;
+    const int nd = m->ndim;
+    const int64_t ld = round_ld(n_traj), n_steps = n_time - 1, n_inner = (int64_t)nd * n_tg;
     const int64_t n_records = qgs_n_records(time, n_time, write_steps);
-    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
+    const int backward = time_direction == -1;
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * nd, modes_b = sizeof(double) * (size_t)ld * nd;
     const size_t tg_rows_b = rows_b * (size_t)n_tg, tg_modes_b = modes_b * (size_t)n_tg;
-    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
-        m->b_rec_rows.ensure(rows_b * (size_t)n_records) || m->b_tg_rows.ensure(tg_rows_b) || m->b_tg_modes.ensure(tg_modes_b) ||
-        m->b_fm_modes.ensure(tg_modes_b * (size_t)n_records) || m->b_fm_rows.ensure(tg_rows_b * (size_t)n_records)) return -1;
-    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(m->b_tg_rows.p, tg_ic, tg_rows_b, hipMemcpyHostToDevice));
-    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
-    qgs::launch_pack_tangent(m->ndim, n_tg, n_traj, ld, m->b_tg_rows.f64(), m->b_tg_modes.f64(), nullptr);
+    hipStream_t sc = m->st_comp, sd = m->st_copy;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_tg_rows.ensure(tg_rows_b) || m->b_tg_modes.ensure(tg_modes_b)) return -1;
+    HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice, sc));
+    HIPCHK(hipMemcpyAsync(m->b_tg_rows.p, tg_ic, tg_rows_b, hipMemcpyHostToDevice, sc));
+    qgs::launch_pack_states(nd, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), sc);
+    // padding lanes of the tangent state are read (never stored) by the specialised kernel: the pack defines them
+    qgs::launch_pack_tangent(nd, n_tg, n_traj, ld, m->b_tg_rows.f64(), m->b_tg_modes.f64(), sc);
     HIPCHK(hipGetLastError());
-    // padding lanes of the tangent state are read (never stored) by the specialised kernel: define them
-    if (qgs_rk_tgls_integrate_device(m, n_traj, ld, n_tg, m->b_in_modes.f64(), m->b_tg_modes.f64(), time, n_time,
-                                     time_direction, write_steps, s, b, c, a, adjoint, inverse, m->b_rec_modes.f64(),
-                                     m->b_fm_modes.f64(), nullptr)) return -1;
-    if (qgs_unpack_records(m, n_traj, ld, m->ndim, n_records, m->b_rec_modes.f64(), m->b_rec_rows.f64(), nullptr)) return -1;
-    if (qgs_unpack_records(m, n_traj, ld, (int64_t)m->ndim * n_tg, n_records, m->b_fm_modes.f64(), m->b_fm_rows.f64(), nullptr)) return -1;
-    HIPCHK(hipMemcpy(traj, m->b_rec_rows.p, rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(fmatrix, m->b_fm_rows.p, tg_rows_b * (size_t)n_records, hipMemcpyDeviceToHost));
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    double *alias_t = device_alias(m, traj), *alias_f = device_alias(m, fmatrix);
+    const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
+                                         (alias_t && alias_f) ? 2 : 3);
+    m->last_windows = plan.n_windows;
+    const int nbuf = plan.n_windows > 1 ? 2 : 1;
+    for (int i = 0; i < nbuf; ++i)
+        if (m->b_win[i].ensure(modes_b * (size_t)plan.W) || m->b_fwin[i].ensure(tg_modes_b * (size_t)plan.W)) return -1;
+    for (int64_t k = 0; k < plan.n_windows; ++k) {
+        int64_t lo, hi, sb, se, lo_s;
+        int wf;
+        plan.window(k, &lo, &hi, &sb, &se, &wf, &lo_s);
+        const int q = (int)(k & 1);
+        double *win = m->b_win[q].f64(), *fwin = m->b_fwin[q].f64();
+        if (k >= 2) HIPCHK(hipStreamWaitEvent(sc, m->ev_copy[q], 0));
+        if (tgls_launch(m, n_traj, ld, n_tg, m->b_in_modes.f64(), m->b_tg_modes.f64(), d_time, d_tab_spec, d_tab_full, sb, se,
+                        n_steps, k == 0, wf, write_steps, n_records, backward, s, a, adjoint, inverse,
+                        win - lo_s * (int64_t)nd * ld, fwin - lo_s * n_inner * ld, sc)) return -1;
+        HIPCHK(hipEventRecord(m->ev_comp[q], sc));
+        HIPCHK(hipStreamWaitEvent(sd, m->ev_comp[q], 0));
+        if (drain_window(m, nd, n_traj, ld, hi - lo, n_records, lo_s, win, alias_t, traj, m->b_rec_rows, sd)) return -1;
+        if (drain_window(m, n_inner, n_traj, ld, hi - lo, n_records, lo_s, fwin, alias_f, fmatrix, m->b_fm_rows, sd)) return -1;
+        HIPCHK(hipEventRecord(m->ev_copy[q], sd));
+    }
+    HIPCHK(hipStreamSynchronize(sc));
+    HIPCHK(hipStreamSynchronize(sd));
     return 0;
 }
 
 int qgs_host_register(void *ptr, int64_t bytes)
 {
     if (!ptr || bytes <= 0) return fail("bad arguments");
-    HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault));
+    // portable + mapped: every GPU of the node can store into the block (the unpack kernels of all shards write their slices)
+    HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     return 0;
 }
 
@@ -1621,6 +2012,144 @@ int qgs_host_unregister(void *ptr)
     if (!ptr) return fail("bad arguments");
     HIPCHK(hipHostUnregister(ptr));
     return 0;
+}
+
+// ---- all GPUs of the node behind one handle ------------------------------------------------------------------------------------
+// The reference's integrators fan the trajectories out over every core of the machine by default (integrator.py:79-82,
+// 133-142, 386-395).  A qgs_group is the same for GPUs: one qgs_model per listed device (a device may be listed more than once:
+// two models, two pipelines on one GPU), members split into contiguous shards (remainder to the first shards), one host
+// thread per shard driving that shard's windowed pipeline; every shard reads its slice of the caller's input block and
+// delivers its slice of the result block itself -- G parallel device-to-host streams, no gather, no collective.
+}  // extern "C"
+
+struct qgs_group {
+    std::vector<qgs_model *> models;
+};
+
+namespace {
+
+void shard_of(int64_t n_total, int n_shards, int i, int64_t *start, int64_t *count)
+{
+    const int64_t base = n_total / n_shards, rem = n_total % n_shards;
+    *start = (int64_t)i * base + std::min<int64_t>(i, rem);
+    *count = base + (i < rem ? 1 : 0);
+}
+
+// run fn(i, start, count) for every non-empty shard, each on its own thread; first error wins
+template <class Fn>
+int for_each_shard(qgs_group *g, int64_t n_total, Fn fn)
+{
+    const int G = (int)g->models.size();
+    std::vector<std::string> errs((size_t)G);
+    std::vector<int> rcs((size_t)G, 0);
+    std::vector<std::thread> th;
+    for (int i = 0; i < G; ++i) {
+        int64_t start, count;
+        shard_of(n_total, G, i, &start, &count);
+        if (count < 1) continue;
+        th.emplace_back([&, i, start, count] {
+            rcs[(size_t)i] = fn(i, start, count);
+            if (rcs[(size_t)i]) errs[(size_t)i] = g_err;           // g_err is thread-local: carry the text over
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int i = 0; i < G; ++i)
+        if (rcs[(size_t)i]) return fail("shard " + std::to_string(i) + " (device " + std::to_string(g->models[(size_t)i]->device) + "): " + errs[(size_t)i]);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qgs_group_create(int n_devices, const int *devices, int ndim, int rank, int64_t nnz, const int32_t *coo, const double *val,
+                     int64_t jnnz, const int32_t *jcoo, const double *jval, qgs_group **out)
+{
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 1024 || !devices) return fail("a group needs 1..1024 devices");
+    qgs_group *g = new qgs_group();
+    g->models.assign((size_t)n_devices, nullptr);
+    // the models are built one after the other: the first compiles (or finds) the code objects, the others load them
+    for (int i = 0; i < n_devices; ++i)
+        if (qgs_model_create_rank(devices[i], ndim, rank, nnz, coo, val, jnnz, jcoo, jval, &g->models[(size_t)i])) {
+            const std::string e = g_err;
+            qgs_group_destroy(g);
+            return fail("device " + std::to_string(devices[i]) + ": " + e);
+        }
+    *out = g;
+    return 0;
+}
+
+int qgs_group_destroy(qgs_group *g)
+{
+    if (!g) return 0;
+    for (qgs_model *m : g->models) qgs_model_destroy(m);
+    delete g;
+    return 0;
+}
+
+int qgs_group_size(const qgs_group *g) { return g ? (int)g->models.size() : -1; }
+
+qgs_model *qgs_group_model(qgs_group *g, int i)
+{
+    if (!g || i < 0 || i >= (int)g->models.size()) { fail("shard index out of range"); return nullptr; }
+    return g->models[(size_t)i];
+}
+
+int qgs_group_shard(const qgs_group *g, int64_t n_traj, int i, int64_t *start, int64_t *count)
+{
+    if (!g || i < 0 || i >= (int)g->models.size() || n_traj < 0 || !start || !count) return fail("bad arguments");
+    shard_of(n_traj, (int)g->models.size(), i, start, count);
+    return 0;
+}
+
+int qgs_group_set_kernel(qgs_group *g, int kind)
+{
+    if (!g) return fail("null group");
+    for (qgs_model *m : g->models) if (qgs_model_set_kernel(m, kind)) return -1;
+    return 0;
+}
+
+int qgs_group_tendencies(qgs_group *g, int64_t n_traj, const double *x, double *dx)
+{
+    if (!g || !x || !dx || n_traj < 1) return fail("bad arguments");
+    const int64_t nd = g->models[0]->ndim;
+    return for_each_shard(g, n_traj, [&](int i, int64_t a, int64_t n) { return qgs_tendencies(g->models[(size_t)i], n, x + a * nd, dx + a * nd); });
+}
+
+int qgs_group_jacobian(qgs_group *g, int64_t n_traj, const double *x, double *jac)
+{
+    if (!g || !x || !jac || n_traj < 1) return fail("bad arguments");
+    const int64_t nd = g->models[0]->ndim;
+    return for_each_shard(g, n_traj, [&](int i, int64_t a, int64_t n) { return qgs_jacobian(g->models[(size_t)i], n, x + a * nd, jac + a * nd * nd); });
+}
+
+int qgs_group_rk_integrate(qgs_group *g, int64_t n_traj, const double *ic, const double *time, int64_t n_time, int time_direction,
+                           int64_t write_steps, int s, const double *b, const double *c, const double *a, double *traj)
+{
+    if (!g || !ic || !traj || n_traj < 1) return fail("bad arguments");
+    if (!time || n_time < 1) return fail("bad time grid");
+    const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
+    return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
+        return qgs_rk_integrate(g->models[(size_t)i], n, ic + a0 * nd, time, n_time, time_direction, write_steps, s, b, c, a,
+                                traj + a0 * nd * nrec);
+    });
+}
+
+int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                                const double *time, int64_t n_time, int time_direction, int64_t write_steps, int s,
+                                const double *b, const double *c, const double *a, int adjoint, double inverse, double *traj,
+                                double *fmatrix)
+{
+    if (!g || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
+    if (!time || n_time < 1) return fail("bad time grid");
+    const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
+    return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
+        return qgs_rk_tgls_integrate(g->models[(size_t)i], n, n_tg, ic + a0 * nd, tg_ic + a0 * nd * n_tg, time, n_time,
+                                     time_direction, write_steps, s, b, c, a, adjoint, inverse, traj + a0 * nd * nrec,
+                                     fmatrix + a0 * nd * n_tg * nrec);
+    });
 }
 
 // Compile (and cache) the specialised kernels of a model without touching a device: used by

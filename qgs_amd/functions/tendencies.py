@@ -23,7 +23,21 @@ class TensorOperands(object):
         self._models = {}
 
     def hip_model(self, device=0):
-        """`HipModel` of these tensors on `device` (created on first use, then shared by f, Df and integrators)."""
+        """GPU handle of these tensors (created on first use, then shared by f, Df and integrators): a `HipModel` on
+        GPU `device` (an index), or a `HipModelGroup` over several GPUs for ``device='all'`` (every visible GPU) or a
+        list / tuple of indices (an index may repeat: two pipelines on that GPU)."""
+        if isinstance(device, str):
+            if device != 'all':
+                raise ValueError("device must be a GPU index, a list of indices or 'all'")
+            device = tuple(_lib.visible_devices())
+        if isinstance(device, (list, tuple)):
+            key = tuple(int(d) for d in device)
+            m = self._models.get(key)
+            if m is None:
+                m = _lib.HipModelGroup(self.ndim, self.coo, self.val, self.jcoo, self.jval, devices=key)
+                self._models[key] = m
+            return m
+        device = int(device)
         m = self._models.get(device)
         if m is None:
             m = _lib.HipModel(self.ndim, self.coo, self.val, self.jcoo, self.jval, device=device)

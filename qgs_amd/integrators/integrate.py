@@ -54,6 +54,22 @@ def on_device(func):
     return getattr(func, 'hip_model', None) is not None
 
 
+#: ensembles of at least this many members are spread over all visible GPUs when no device was asked for (two full
+#: 65 536-member batches: below that one MI355X integrates the ensemble in about the time a second one needs to get its share)
+AUTO_ALL_DEVICES_MIN_TRAJ = 2 * 65536
+
+
+def resolve_device(device, n_traj=None):
+    """The `device` argument of the integrators: a GPU index, a list of indices, 'all', or None = the device the tendencies
+    were created for -- unless the ensemble has at least AUTO_ALL_DEVICES_MIN_TRAJ members and the node has several GPUs, in
+    which case None means all of them (the reference's default is every core of the machine, integrator.py:79-82)."""
+    if device is None and n_traj is not None and n_traj >= AUTO_ALL_DEVICES_MIN_TRAJ:
+        from qgs_amd import _lib
+        if len(_lib.visible_devices()) > 1:
+            return 'all'
+    return device
+
+
 def hip_model_of(func, what='f', device=None):
     """The GPU handle behind a tendencies callable (on `device`, default the one the callable was created for)."""
     get = getattr(func, 'hip_model', None)
@@ -114,6 +130,7 @@ def run_rk(f, time, ic, time_direction, write_steps, b, c, a, device=None):
     """One ensemble integration, (n_traj, n_dim, n_records): the fused HIP stepper for tensor tendencies, the host stepper
     for a user-written callable."""
     if on_device(f):
+        device = resolve_device(device, np.shape(ic)[0])
         return hip_model_of(f, device=device).rk_integrate(time, ic, time_direction, write_steps, b, c, a)
     return host_stepper.integrate_runge_kutta(f, time, np.ascontiguousarray(ic, dtype=np.float64), time_direction, write_steps, b, c, a)
 
@@ -122,6 +139,7 @@ def run_rk_tgls(f, fjac, time, ic, tg_ic, time_direction, write_steps, b, c, a, 
     """Trajectories + tangent / adjoint model.  On the device when `f`, `fjac` come from one create_tendencies() call and
     the boundary term is the default zero; otherwise on the host (a `boundary` callable, or user-written `f` / `fjac`)."""
     if on_device(f) and on_device(fjac) and boundary is None:
+        device = resolve_device(device, np.shape(ic)[0])
         model = hip_model_of(f, device=device)
         if hip_model_of(fjac, 'fjac', device=device) is not model:
             raise TypeError('f and fjac must come from the same create_tendencies() call')
@@ -130,19 +148,20 @@ def run_rk_tgls(f, fjac, time, ic, tg_ic, time_direction, write_steps, b, c, a, 
                                                    write_steps, b, c, a, adjoint, inverse, boundary)
 
 
-def integrate_runge_kutta(f, t0, t, dt, ic=None, forward=True, write_steps=1, b=None, c=None, a=None):
+def integrate_runge_kutta(f, t0, t, dt, ic=None, forward=True, write_steps=1, b=None, c=None, a=None, device=None):
     """Integrate dx/dt = f(t, x) for one state or an ensemble of states; returns ``(time, traj)`` with the
     reference's conventions: traj is ``np.squeeze`` of (n_traj, n_dim, n_records); time is a scalar when
-    ``write_steps == 0``."""
+    ``write_steps == 0``.  One keyword beyond the reference: ``device`` (a GPU index, a list of indices or 'all'; see
+    `resolve_device`)."""
     ic = normalise_ic(ic, None if ic is not None else dimension_of(f))
     b, c, a = resolve_tableau(b, c, a)
     time = time_grid(t0, t, dt)
-    recorded = run_rk(f, time, ic, 1 if forward else -1, write_steps, b, c, a)
+    recorded = run_rk(f, time, ic, 1 if forward else -1, write_steps, b, c, a, device=device)
     return record_times(time, write_steps, forward), np.squeeze(recorded)
 
 
 def integrate_runge_kutta_tgls(f, fjac, t0, t, dt, ic=None, tg_ic=None, forward=True, adjoint=False, inverse=False,
-                               boundary=None, write_steps=1, b=None, c=None, a=None):
+                               boundary=None, write_steps=1, b=None, c=None, a=None, device=None):
     """Integrate the trajectory together with its tangent linear (or adjoint) model; returns
     ``(time, traj, fmatrix)`` like integrate.py:240-552."""
     ic = normalise_ic(ic, None if ic is not None else dimension_of(f))
@@ -152,6 +171,6 @@ def integrate_runge_kutta_tgls(f, fjac, t0, t, dt, ic=None, tg_ic=None, forward=
     b, c, a = resolve_tableau(b, c, a)
     time = time_grid(t0, t, dt)
     traj, fm = run_rk_tgls(f, fjac, time, ic, tg, 1 if forward else -1, write_steps, b, c, a, adjoint,
-                           -1. if inverse else 1., boundary)
+                           -1. if inverse else 1., boundary, device=device)
     fm = restore_fmatrix_axes(fm, tg_user, n_dim)
     return record_times(time, write_steps, forward), np.squeeze(traj), np.squeeze(fm)

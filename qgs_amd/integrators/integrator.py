@@ -22,7 +22,10 @@ class _EnsembleIntegrator(object):
 
     def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, device=None):
         self.num_threads = multiprocessing.cpu_count() if num_threads is None else num_threads
-        self.device = device               # GPU index of the engine (None: the device the tendencies were created for)
+        # GPU(s) of the engine: an index, a list of indices (members are sharded over them, a device may repeat), 'all', or
+        # None = the device the tendencies were created for; ensembles of >= 131 072 members then take every visible GPU
+        # (integrate.resolve_device), as the reference takes every core by default (integrator.py:79-82)
+        self.device = device
         self.b, self.c, self.a = _fn.resolve_tableau(b, c, a)
         self.ic = None
         self._time = None
@@ -44,7 +47,7 @@ class _EnsembleIntegrator(object):
         """(Re)acquire the GPU engine for the current `func` (reference: restart the worker processes)."""
         self.terminate()
         if self.func is not None and _fn.on_device(self.func):
-            self._model = _fn.hip_model_of(self.func, device=self.device)
+            self._model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device))
 
     def set_bca(self, b=None, c=None, a=None, ic_init=True):
         """Set the Butcher tableau; `ic_init` resets the stored initial conditions."""
@@ -149,8 +152,11 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
 
     Parameters, attributes and methods as in the reference (integrator.py:27-450):
     ``RungeKuttaIntegrator(num_threads=None, b=None, c=None, a=None, number_of_dimensions=None)``; attributes
-    ``num_threads, b, c, a, n_dim, n_traj, n_records, ic, func``.  One keyword beyond the reference: ``device``, the index
-    of the GPU that integrates (multi-GPU jobs: one process per GPU, ``device=LOCAL_RANK``; see qgs_amd/parallel.py).
+    ``num_threads, b, c, a, n_dim, n_traj, n_records, ic, func``.  One keyword beyond the reference: ``device`` -- a GPU
+    index, a list of indices or ``'all'``: the members are split into contiguous shards, one per listed GPU, integrated
+    concurrently in this process, and every GPU delivers its slice of the result array itself (`_lib.HipModelGroup`).  Left at
+    None, ensembles of at least 131 072 members use every visible GPU, smaller ones the GPU the tendencies were created for.
+    (Multi-process jobs, one rank per GPU with an RCCL gather: ``device=LOCAL_RANK``, see qgs_amd/parallel.py.)
     """
 
     def set_func(self, f, ic_init=True):
@@ -182,10 +188,9 @@ class RungeKuttaIntegrator(_EnsembleIntegrator):
             return 0
         if not _fn.on_device(self.func):
             raise TypeError('integrate_moments reduces on the device: it needs tendencies from create_tendencies()')
-        if self._model is None:
-            self.start()
         self._prepare(t0, t, dt, ic, forward, write_steps)
-        mean, var, fin = self._model.rk_integrate_moments(self._time, self.ic, self._time_direction, write_steps,
+        model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
+        mean, var, fin = model.rk_integrate_moments(self._time, self.ic, self._time_direction, write_steps,
                                                           self.b, self.c, self.a, variance=variance, final_states=True)
         self.last_final_states = fin                           # (n_traj, n_dim): e.g. the next window's initial conditions
         return self._record_times(), mean, var
@@ -223,7 +228,7 @@ class RungeKuttaTglsIntegrator(_EnsembleIntegrator):
     def start(self):
         super(RungeKuttaTglsIntegrator, self).start()
         if self._model is not None and self.func_jac is not None and _fn.on_device(self.func_jac):
-            if _fn.hip_model_of(self.func_jac, 'fjac', device=self.device) is not self._model:
+            if _fn.hip_model_of(self.func_jac, 'fjac', device=_fn.resolve_device(self.device)) is not self._model:
                 raise TypeError('f and fjac must come from the same create_tendencies() call')
 
     def integrate(self, t0, t, dt, ic=None, tg_ic=None, forward=True, adjoint=False, inverse=False, boundary=None,

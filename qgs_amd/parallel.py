@@ -97,22 +97,18 @@ class RootGather(object):
 
 def _integrate_shard_on_device(f, device, local_ic, time, forward, write_steps, b, c, a):
     """One rank's block on its own GPU, results left in HBM: (n_local, n_dim, n_records) torch tensor on `device`.
-    pack -> fused stepper -> record unpack, all on the device (C-ABI device-layout entry points)."""
+    `qgs_rk_integrate_rows_device`: pack -> fused stepper -> record unpack on the device, the mode-major records held one
+    window at a time (QGS_HIP_RECORD_WINDOW_MB), so the only whole-record buffer in HBM is the result itself."""
     import torch
     from qgs_amd import _lib
     model = f.hip_model(device=device.index)
     n, ndim = local_ic.shape
     nrec = _lib.n_records(time, write_steps)
-    ld = (n + 63) // 64 * 64
     with torch.cuda.device(device):
-        st = torch.cuda.current_stream(device).cuda_stream
         d_rows = torch.from_numpy(local_ic).to(device)
-        d_modes = torch.empty((ndim, ld), dtype=torch.float64, device=device)
-        d_rec = torch.empty((nrec, ndim, ld), dtype=torch.float64, device=device)
         d_out = torch.empty((n, ndim, nrec), dtype=torch.float64, device=device)
-        model.pack_states(n, ld, d_rows.data_ptr(), d_modes.data_ptr(), st)
-        model.rk_integrate_device(n, ld, d_modes.data_ptr(), time, 1 if forward else -1, write_steps, b, c, a, d_rec.data_ptr(), st)
-        model.unpack_records(n, ld, ndim, nrec, d_rec.data_ptr(), d_out.data_ptr(), st)
+        torch.cuda.current_stream(device).synchronize()          # the library works on its own streams
+        model.rk_integrate_rows_device(n, d_rows.data_ptr(), time, 1 if forward else -1, write_steps, b, c, a, d_out.data_ptr())
     return d_out
 
 
@@ -124,8 +120,10 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
     On GPUs (backend "nccl", or no process group at all) each rank integrates `ic[shard]` on ITS OWN device --
     `device`, default the current CUDA device, i.e. LOCAL_RANK after `torch.cuda.set_device` -- and the results stay
     in HBM until they have been gathered: H2D of the shard, pack, fused stepper, record unpack, one RCCL all-gather,
-    one D2H.  `integrator_factory` is a test seam for CPU process groups (gloo): a callable returning an object with
-    the `RungeKuttaIntegrator` interface; its NumPy results are gathered through host tensors.
+    one D2H.  Tendencies that are a plain Python callable, and process groups on a CPU backend (gloo), take the host
+    route: each rank runs `RungeKuttaIntegrator` on its block and the NumPy results are gathered through host tensors.
+    `integrator_factory` (a callable returning an object with the `RungeKuttaIntegrator` interface) forces that route
+    with another engine (test seam).
     """
     import torch
     from qgs_amd.integrators.integrate import record_times, resolve_tableau, time_grid
@@ -136,7 +134,9 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
     local_ic = np.ascontiguousarray(ic[ens.local_slice])
     grid = time_grid(t0, t, dt)
     time = record_times(grid, write_steps, forward)
-    if integrator_factory is None:
+    backend = ens._dist.get_backend(process_group) if ens.distributed else None
+    on_gpu = getattr(f, 'hip_model', None) is not None and backend in (None, 'nccl')
+    if integrator_factory is None and on_gpu:
         # ---- device-resident route ----
         from qgs_amd import _lib
         if device is None:
@@ -151,7 +151,15 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
         else:
             local = torch.zeros((0, ic.shape[1], nrec), dtype=torch.float64, device=device)
         full = ens.gather(local)
+        del local
         return time, full.cpu().numpy()
+    if integrator_factory is None:
+        # a user-written Python callable (host stepper), or a CPU process group (gloo): every rank integrates its block through
+        # the integrator class and the NumPy results are gathered through host tensors
+        from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+        integrator_factory = RungeKuttaIntegrator
+        if backend is not None and backend != 'nccl':
+            device = torch.device('cpu')
     # ---- host route (test seam) ----
     integ = integrator_factory(b=b, c=c, a=a)
     integ.set_func(f)

@@ -55,3 +55,60 @@ def test_launcher_starts_one_child_per_rank_and_reports_their_failure():
     assert p.returncode == 1, err[-2000:]
     assert 'no GPU visible' in err and 'ranks failed (rank, exit code): [(0, 1), (1, 1)]' in err
     assert p.stdout.decode().strip() == ''
+
+
+_PREBUILD = ("import sys, numpy as np\n"
+             "sys.path.insert(0, %r)\n"
+             "from qgs_amd import _lib\n"
+             "g = np.load(%r)\n"
+             "_lib.prebuild(int(g['ndim']), g['coo'], g['val'], None, None, stage_counts=(2,))\n"
+             "print('PREBUILT')\n" % (REPO, os.path.join(REPO, 'tests', 'golden', 'rp20.npz')))
+
+
+def _hsaco(d):
+    return sorted(f for f in os.listdir(str(d)) if f.endswith('.hsaco'))
+
+
+def test_unwritable_kernel_cache_still_compiles(tmp_path):
+    """A cache directory that cannot be written (read-only shared install; here: a path below a regular file, which not even
+    root can create): every miss compiles through temp files under $TMPDIR and the publish is skipped -- no failure, nothing
+    left behind."""
+    blocker, scratch = tmp_path / 'blocker', tmp_path / 'scratch'
+    blocker.write_text('not a directory')
+    scratch.mkdir()
+    p = subprocess.run([sys.executable, '-c', _PREBUILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(blocker / 'kcache'), TMPDIR=str(scratch)))
+    assert p.returncode == 0 and b'PREBUILT' in p.stdout, p.stderr.decode()[-2000:]
+    assert os.listdir(str(scratch)) == []
+
+
+def test_helper_that_cannot_run_falls_back_to_the_in_process_compiler(tmp_path):
+    """`--version` failing (e.g. the helper's RPATH does not resolve on this host) selects the in-process hiprtc AND its cache
+    identity; a helper that answers `--version` but dies while compiling is dropped for the rest of the process, and what the
+    in-process compiler produced is filed under ITS identity, never under the helper's."""
+    inproc = tmp_path / 'inproc'
+    subprocess.run([sys.executable, '-c', _PREBUILD], check=True, timeout=900,
+                   env=dict(os.environ, QGS_HIP_CACHE_DIR=str(inproc), QGS_HIP_INPROC_RTC='1'))
+    want = _hsaco(inproc)
+    assert want
+    # (a) no usable helper at all
+    a = tmp_path / 'a'
+    p = subprocess.run([sys.executable, '-c', _PREBUILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(a), QGS_HIP_HELPER='/bin/false'))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b'--version failed' in p.stderr and _hsaco(a) == want
+    # (b) a helper that identifies itself and then fails for a non-compile reason (exit code 3)
+    fake = tmp_path / 'fake_helper.sh'
+    fake.write_text('#!/bin/sh\nif [ "$1" = "--version" ]; then echo hiprtc9.9-fake; exit 0; fi\nexit 3\n')
+    os.chmod(str(fake), 0o755)
+    b = tmp_path / 'b'
+    p = subprocess.run([sys.executable, '-c', _PREBUILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(b), QGS_HIP_HELPER=str(fake)))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert b'no longer usable' in p.stderr and _hsaco(b) == want
+    # (c) a real compile error (exit code 1) is reported, not papered over by a second compiler
+    fake.write_text('#!/bin/sh\nif [ "$1" = "--version" ]; then echo hiprtc9.9-fake; exit 0; fi\necho "error: nope" >&2\nexit 1\n')
+    c = tmp_path / 'c'
+    p = subprocess.run([sys.executable, '-c', _PREBUILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(c), QGS_HIP_HELPER=str(fake)))
+    assert p.returncode != 0 and b'error: nope' in p.stderr and not os.path.isdir(str(c)) or _hsaco(c) == []

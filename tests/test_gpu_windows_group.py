@@ -1,0 +1,436 @@
+"""GPU: the record-window pipeline of the host-layout entry points, the multi-device group (tested on ONE GPU by listing
+device 0 more than once: two models, two pipelines, two shards), BASELINE config 5 at its stated size through the shard
+bookkeeping, the single-state f / Df path, and the C-ABI's argument checks.
+
+Every comparison of two HIP runs here is BITWISE: cutting a run into record windows or an ensemble into shards must not change
+one bit (members are independent; a window boundary hands the state over through memory).  Comparisons with the oracle use the
+tolerances of test_gpu_parity.py.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+B, C, A = RK4['b'], RK4['c'], RK4['a']
+
+
+def _grid(steps, dt=0.1):
+    return np.concatenate((np.arange(0., steps * dt, dt), [steps * dt]))[:steps + 1]
+
+
+def _model(name, **kw):
+    from qgs_amd import _lib
+    g = load_golden(name)
+    return g, _lib.HipModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'], **kw)
+
+
+class _Knobs(object):
+    """Set QGS_HIP_* knobs and make the model re-read them (they are read at model creation and at set_kernel)."""
+
+    def __init__(self, monkeypatch, model, kind=0):
+        self.mp, self.model, self.kind = monkeypatch, model, kind
+
+    def set(self, **env):
+        for k, v in env.items():
+            if v is None:
+                self.mp.delenv(k, raising=False)
+            else:
+                self.mp.setenv(k, str(v))
+        self.model.set_kernel(self.kind)
+
+
+# ---- record windows ------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('d2h', ['kernel', 'copy'])
+@pytest.mark.parametrize('kind', [0, 1])
+def test_windowed_record_equals_unwindowed(monkeypatch, d2h, kind):
+    """A forced 64 MB window budget cuts a 4 113-member, 101-record run (1.2 MB per record) into windows with a ragged last
+    one; forward / backward, write_steps 1 and 3; page-locked destination written by the unpack kernel ('kernel') and the
+    staged strided copy ('copy')."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m, kind)
+    n, steps = (4113, 100) if kind == 0 else (700, 40)
+    ic = np.random.RandomState(11).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    for direction in (1, -1):
+        for ws in (1, 3):
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=None, QGS_HIP_D2H=None)
+            whole = np.array(m.rk_integrate(t, ic, direction, ws, B, C, A))
+            assert m.last_windows == 1
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=64 if kind == 0 else 2, QGS_HIP_D2H=d2h)
+            cut = m.rk_integrate(t, ic, direction, ws, B, C, A)
+            assert m.last_windows >= 2, m.last_windows
+            assert np.array_equal(whole, cut), (direction, ws, m.last_windows)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None, QGS_HIP_D2H=None)
+    m.close()
+
+
+def test_windowed_record_into_pageable_memory(monkeypatch):
+    """The result block of a plain C caller is pageable memory: staged copy per window, same bits."""
+    from qgs_amd import _lib
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    n, steps, ws = 1500, 60, 1
+    ic = np.random.RandomState(12).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    nrec = _lib.n_records(t, ws)
+    whole = np.array(m.rk_integrate(t, ic, 1, ws, B, C, A))
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=16)
+    out = np.full((n, g.ndim, nrec), np.nan)                     # a fresh NumPy array: not page-locked
+    rc = _lib.lib().qgs_rk_integrate(m._h, n, ic, t, len(t), 1, ws, 4, B, C, A, out)
+    assert rc == 0, _lib.last_error()
+    assert m.last_windows >= 3 and np.array_equal(out, whole)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
+def test_windowed_small_ensemble_and_zero_step_tail(monkeypatch):
+    """Wavefront-per-trajectory kernel (10 members, 18 KB per record) and a window that holds nothing but the final record: 9
+    steps, write_steps 3 -> records at steps 0, 3, 6 and the final one; 0.16 MB pays for W = 3 on the staged route, which puts
+    the final record alone into a zero-step window."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    ic = np.random.RandomState(13).rand(10, g.ndim) * 0.01
+    for steps, ws in ((9, 3), (50, 1), (7, 0)):
+        t = _grid(steps)
+        for direction in (1, -1):
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+            whole = np.array(m.rk_integrate(t, ic, direction, ws, B, C, A))
+            assert m.last_kernel_info()['name'] == 'gen_rk_wave_kernel'
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=0.16, QGS_HIP_D2H='copy')
+            cut = m.rk_integrate(t, ic, direction, ws, B, C, A)
+            assert m.last_windows == (2 if (steps, ws) == (9, 3) else (17 if ws == 1 else 1)), m.last_windows
+            assert np.array_equal(whole, cut), (steps, ws, direction)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None, QGS_HIP_D2H=None)
+    m.close()
+
+
+def test_window_plan_with_final_record_alone(monkeypatch):
+    """ndim 228 (LDS-resident stepper), 200 members: 0.45 MB per record, 2 MB budget -> windows of 1-2 records; 9 steps with
+    write_steps 3 ends on a window that only holds the final record."""
+    g, m = _model('t228')
+    knobs = _Knobs(monkeypatch, m, kind=2)
+    ic = np.random.RandomState(14).rand(200, g.ndim) * 0.01
+    t = _grid(9)
+    for direction in (1, -1):
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+        whole = np.array(m.rk_integrate(t, ic, direction, 3, B, C, A))
+        assert m.last_kernel_info()['name'].startswith('qgs_spec_rklds')
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=2)
+        cut = m.rk_integrate(t, ic, direction, 3, B, C, A)
+        assert m.last_windows >= 2 and np.array_equal(whole, cut), direction
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
+@pytest.mark.parametrize('kind', [0, 1])
+def test_windowed_tangent_model_equals_unwindowed(monkeypatch, kind):
+    """Trajectory + propagator records through windows: tangent forward, adjoint backward with `inverse`."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m, kind)
+    n, n_tg, steps = 300, 5, 24
+    rng = np.random.RandomState(15)
+    ic, tg = rng.rand(n, g.ndim) * 0.01, rng.randn(n, g.ndim, n_tg)
+    t = _grid(steps)
+    for direction, ws, adj, inv in ((1, 1, False, 1.), (-1, 5, True, -1.), (1, 0, False, 1.)):
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=None, QGS_HIP_D2H=None)
+        tr0, fm0 = (np.array(q) for q in m.rk_tgls_integrate(t, ic, tg, direction, ws, B, C, A, adj, inv))
+        for d2h in ('kernel', 'copy'):
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=2, QGS_HIP_D2H=d2h)           # (1 + 5) * 320 * 36 * 8 B = 0.53 MB per record
+            tr1, fm1 = m.rk_tgls_integrate(t, ic, tg, direction, ws, B, C, A, adj, inv)
+            assert ws == 0 or m.last_windows >= 3
+            assert np.array_equal(tr0, tr1) and np.array_equal(fm0, fm1), (direction, ws, d2h)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None, QGS_HIP_D2H=None)
+    m.close()
+
+
+def test_record_larger_than_its_device_budget_matches_the_oracle(monkeypatch):
+    """A 65 536-member run whose record (65 536 x 36 x 41 doubles = 774 MB) is forced through 128 MB of device windows:
+    sample members against the oracle, every record."""
+    from oracle.oracle import OracleModel
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    ora = OracleModel(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    n, steps = 65536, 40
+    ic = np.random.RandomState(16).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=128)
+    rec = m.rk_integrate(t, ic, 1, 1, B, C, A)
+    assert rec.shape == (n, g.ndim, steps + 1) and m.last_windows >= 6
+    pick = np.array([0, 1, 63, 64, 30000, 65535])
+    ref = ora.integrate_runge_kutta_jit(t, ic[pick], 1, 1, B, C, A)
+    assert rel_err(rec[pick], ref) < 1e-12
+    assert np.array_equal(rec[:, :, 0], ic)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
+def test_rows_device_entry_point_equals_host_call(monkeypatch):
+    """qgs_rk_integrate_rows_device (both blocks in HBM in the reference's layouts, what a rank of parallel.py runs)."""
+    import torch
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    n, steps, ws = 3000, 30, 2
+    ic = np.random.RandomState(17).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    whole = np.array(m.rk_integrate(t, ic, -1, ws, B, C, A))
+    d_ic = torch.from_numpy(ic).cuda()
+    d_out = torch.empty(whole.shape, dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    for mb in (None, 8):
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=mb)
+        d_out.fill_(float('nan'))
+        torch.cuda.synchronize()
+        m.rk_integrate_rows_device(n, d_ic.data_ptr(), t, -1, ws, B, C, A, d_out.data_ptr())
+        assert np.array_equal(d_out.cpu().numpy(), whole), mb
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
+# ---- several GPUs behind one handle (here: device 0 listed more than once) ----------------------------------------------------------
+
+def test_group_equals_single_model_bitwise():
+    from qgs_amd import _lib
+    g, m = _model('m36')
+    rng = np.random.RandomState(21)
+    for devices, n in (([0, 0], 1001), ([0, 0, 0], 64), ([0, 0, 0, 0, 0], 3)):
+        grp = _lib.HipModelGroup(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'], devices=devices)
+        assert len(grp) == len(devices)
+        shards = [grp.shard(n, i) for i in range(len(devices))]
+        assert sum(c for _, c in shards) == n and shards[0][0] == 0
+        assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(len(shards) - 1))
+        assert max(c for _, c in shards) - min(c for _, c in shards) <= 1            # remainder to the first shards
+        assert [int(_lib.lib().qgs_model_info(q._h, 3)) for q in grp.models] == devices
+        ic = rng.rand(n, g.ndim) * 0.01
+        assert np.array_equal(grp.tendencies(ic), m.tendencies(ic))
+        assert np.array_equal(grp.jacobian(ic), m.jacobian(ic))
+        t = _grid(23)
+        for direction, ws in ((1, 0), (-1, 1), (1, 4)):
+            assert np.array_equal(grp.rk_integrate(t, ic, direction, ws, B, C, A), m.rk_integrate(t, ic, direction, ws, B, C, A))
+        tg = rng.randn(n, g.ndim, 3)
+        a_tr, a_fm = grp.rk_tgls_integrate(t[:8], ic, tg, 1, 2, B, C, A, False, 1.)
+        b_tr, b_fm = m.rk_tgls_integrate(t[:8], ic, tg, 1, 2, B, C, A, False, 1.)
+        assert np.array_equal(a_tr, b_tr) and np.array_equal(a_fm, b_fm)
+        mean, var, fin = grp.rk_integrate_moments(t, ic, 1, 4, B, C, A, final_states=True)
+        rec = m.rk_integrate(t, ic, 1, 4, B, C, A)
+        assert rel_err(mean, rec.mean(axis=0)) < 1e-13 and np.abs(var - rec.var(axis=0)).max() < 1e-12 * max(rec.var(axis=0).max(), 1e-300) + 1e-22
+        assert np.array_equal(fin, rec[:, :, -1])
+        grp.close()
+    m.close()
+
+
+@pytest.mark.parametrize('name', ['rp20', 'm36', 'd38'])
+def test_integrator_classes_on_a_device_list_vs_reference_classes(name):
+    """The class-level goldens of test_gpu_api.py with `device=[0, 0]`: same outputs through the sharded engine."""
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator, RungeKuttaTglsIntegrator
+    from qgs_amd.integrators.integrate import integrate_runge_kutta
+    from qgs_amd import _lib
+    g = load_golden(name)
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = g['rk_ic']
+    integ = RungeKuttaIntegrator(num_threads=2, device=[0, 0])
+    integ.set_func(f)
+    assert isinstance(integ._model, _lib.HipModelGroup)
+    integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=5)
+    tt, tr = integ.get_trajectories()
+    assert np.array_equal(tt, g['cls_rk_w5_time']) and rel_err(tr, g['cls_rk_w5_traj']) < 1e-12
+    integ.integrate(0., 1., 0.1, ic=ic[:4], write_steps=0, forward=False)
+    tt, tr = integ.get_trajectories()
+    assert np.ndim(tt) == 0 and tt == g['cls_rk_w0b_time'] and rel_err(tr, g['cls_rk_w0b_traj']) < 1e-12
+    integ.terminate()
+    tinteg = RungeKuttaTglsIntegrator(num_threads=2, device='all')
+    tinteg.set_func(f, Df)
+    tinteg.integrate(0., 0.3, 0.1, ic=ic[:2], write_steps=1)
+    tt, tr, fm = tinteg.get_trajectories()
+    assert np.array_equal(tt, g['cls_tgls_time'])
+    assert rel_err(tr, g['cls_tgls_traj']) < 1e-12 and rel_err(fm, g['cls_tgls_fm']) < 1e-11
+    tinteg.terminate()
+    tt, tr = integrate_runge_kutta(f, t0=0., t=1., dt=0.1, ic=ic, forward=False, write_steps=3, device=[0, 0, 0])
+    assert np.array_equal(np.asarray(tt), g['api_b_w3_time']) and rel_err(tr, g['api_b_w3_traj']) < 1e-12
+    f.operands.release()
+
+
+def test_default_device_is_every_gpu_for_large_ensembles(monkeypatch):
+    from qgs_amd.integrators import integrate as fn
+    from qgs_amd import _lib
+    assert fn.resolve_device(None, 1000) is None and fn.resolve_device(0, 10 ** 7) == 0
+    monkeypatch.setattr(_lib, 'visible_devices', lambda: [0, 1, 2, 3, 4, 5, 6, 7])
+    assert fn.resolve_device(None, 2 * 65536) == 'all' and fn.resolve_device(None, 2 * 65536 - 1) is None
+    assert fn.resolve_device([0, 1], 10 ** 7) == [0, 1]
+    monkeypatch.setattr(_lib, 'visible_devices', lambda: [0])
+    assert fn.resolve_device(None, 10 ** 7) is None
+
+
+def test_config5_full_size_through_the_shard_bookkeeping():
+    """BASELINE config 5 as stated: MAOOAM-36 (the qgs_maooam.py parameter set of bench.py), 1 048 576 members, 1000 RK4
+    steps, write_steps 0, 8 shards of 131 072.  On the one GPU present: (a) one 1 048 576-member call, (b) a group of eight
+    models on device 0 (the in-process route of the integrator classes), (c) parallel.py's per-rank route, shard by shard with
+    `shard_bounds`, concatenated in rank order.  All three bitwise equal; a sample against the oracle."""
+    import sys
+    import torch
+    sys.path.insert(0, REPO)
+    from bench import load_model_tensors
+    from qgs_amd import _lib
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.parallel import shard_bounds, _integrate_shard_on_device
+    from oracle.oracle import OracleModel
+    ndim, coo, val, jcoo, jval, _ = load_model_tensors()
+    f, _ = tendencies_from_tensor(ndim, coo, val, jcoo, jval)
+    n, world, steps = 1048576, 8, 1000
+    ic = np.random.RandomState(21217).rand(n, ndim) * 0.01
+    t = _grid(steps)
+    one = np.array(f.hip_model(0).rk_integrate(t, ic, 1, 0, B, C, A))
+    assert f.hip_model(0).last_kernel_info()['name'] == 'qgs_spec_rk_s4'
+    grp = f.hip_model([0] * world)
+    assert [grp.shard(n, i) for i in range(world)] == [(r * 131072, 131072) for r in range(world)]
+    assert np.array_equal(grp.rk_integrate(t, ic, 1, 0, B, C, A), one)
+    bounds = shard_bounds(n, world)
+    assert bounds == [(r * 131072, (r + 1) * 131072) for r in range(world)]
+    dev = torch.device('cuda', 0)
+    parts = [_integrate_shard_on_device(f, dev, np.ascontiguousarray(ic[a:b]), t, True, 0, B, C, A).cpu().numpy() for a, b in bounds]
+    assert np.array_equal(np.concatenate(parts, axis=0), one)
+    pick = np.array([0, 131071, 131072, 524288, 1048575])
+    ref = OracleModel(ndim, coo, val, jcoo, jval).integrate_runge_kutta_jit(t, ic[pick], 1, 0, B, C, A)
+    assert rel_err(one[pick], ref) < 1e-10                       # 1000 steps: tolerance of test_gpu_parity.py
+    f.operands.release()
+
+
+# ---- one state: the callables handed to ODE solvers -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize('name', ['rp20', 'a36', 'm36', 't228', 'g30', 'd38', 'q38'])
+def test_single_state_f_and_Df(name):
+    """f(t, x) / Df(t, x) for ONE (ndim,) state (user_guide.rst:502-517): one launch on page-locked staging, against the
+    reference goldens, and equal to the same state inside a batch."""
+    g, m = _model(name)
+    xs = g['fx_x']
+    for i in (0, 3):
+        fx = m.tendencies(xs[i])
+        assert fx.shape == (g.ndim,) and rel_err(fx, g['fx_f'][i]) < 1e-14
+        assert rel_err(fx, m.tendencies(xs[:8])[i]) < 1e-14
+        if i < g['fx_Df'].shape[0]:
+            J = m.jacobian(xs[i])
+            assert J.shape == (g.ndim, g.ndim) and rel_err(J, g['fx_Df'][i]) < 1e-14
+    name_f = m.last_kernel_info()['name']
+    assert name_f in ('qgs_spec_jac', 'gen_jac_one_kernel'), name_f
+    # a solver calls f thousands of times with changing states: results must not depend on what the staging block held
+    rng = np.random.RandomState(5)
+    batch = rng.rand(20, g.ndim) * 0.01
+    ref = m.tendencies(batch)
+    for i in range(20):
+        assert rel_err(m.tendencies(batch[i]), ref[i]) < 1e-14
+    m.close()
+
+
+# ---- hostile arguments ------------------------------------------------------------------------------------------------------------
+
+def test_cabi_rejects_bad_arguments_and_stays_usable():
+    """Every bad argument returns < 0 with a message in qgs_last_error(); the model still works afterwards."""
+    import torch
+    from qgs_amd import _lib
+    L = _lib.lib()
+    g, m = _model('m36')
+    nd = g.ndim
+    ic = np.random.RandomState(1).rand(70, nd) * 0.01
+    t = _grid(5)
+    out = np.empty((70, nd, 6))
+    good = np.array(m.rk_integrate(t, ic, 1, 1, B, C, A))
+    vp = ctypes.c_void_p
+
+    def expect_fail(rc, what):
+        assert rc < 0, what
+        msg = _lib.last_error()
+        assert msg, what
+        return msg
+
+    # host-layout entry points: null handle, zero / negative sizes, bad direction, negative write_steps, empty time grid
+    expect_fail(L.qgs_rk_integrate(None, 70, ic, t, len(t), 1, 1, 4, B, C, A, out), 'null model')
+    expect_fail(L.qgs_rk_integrate(m._h, 0, ic, t, len(t), 1, 1, 4, B, C, A, out), 'n_traj 0')
+    expect_fail(L.qgs_rk_integrate(m._h, -5, ic, t, len(t), 1, 1, 4, B, C, A, out), 'n_traj < 0')
+    expect_fail(L.qgs_rk_integrate(m._h, 70, ic, t, 0, 1, 1, 4, B, C, A, out), 'n_time 0')
+    expect_fail(L.qgs_rk_integrate(m._h, 70, ic, t, len(t), 0, 1, 4, B, C, A, out), 'direction 0')
+    expect_fail(L.qgs_rk_integrate(m._h, 70, ic, t, len(t), 1, -1, 4, B, C, A, out), 'write_steps < 0')
+    expect_fail(L.qgs_rk_integrate(m._h, 70, ic, t, len(t), 1, 1, 0, B, C, A, out), 'zero stages')
+    tg = np.zeros((70, nd, 2))
+    fm = np.empty((70, nd, 2, 6))
+    expect_fail(L.qgs_rk_tgls_integrate(m._h, 70, 0, ic, tg, t, len(t), 1, 1, 4, B, C, A, 0, 1., out, fm), 'n_tg 0')
+    expect_fail(L.qgs_rk_tgls_integrate(m._h, 70, 2, ic, tg, t, len(t), 2, 1, 4, B, C, A, 0, 1., out, fm), 'direction 2')
+    expect_fail(L.qgs_tendencies(m._h, 0, ic, out), 'n_traj 0')
+    expect_fail(L.qgs_tendencies(None, 1, ic, out), 'null model')
+    expect_fail(L.qgs_jacobian(m._h, -1, ic, out), 'n_traj < 0')
+    # device-layout entry points: ld not a multiple of 64, ld < n_traj, null pointers
+    d_x = torch.zeros((nd, 128), dtype=torch.float64, device='cuda')
+    d_r = torch.zeros((6, nd, 128), dtype=torch.float64, device='cuda')
+    msg = expect_fail(L.qgs_rk_integrate_device(m._h, 70, 100, d_x.data_ptr(), t, len(t), 1, 1, 4, B, C, A, d_r.data_ptr(), None), 'ld 100')
+    assert 'multiple of 64' in msg
+    expect_fail(L.qgs_rk_integrate_device(m._h, 70, 64, d_x.data_ptr(), t, len(t), 1, 1, 4, B, C, A, d_r.data_ptr(), None), 'ld < n_traj')
+    expect_fail(L.qgs_rk_integrate_device(m._h, 70, 128, None, t, len(t), 1, 1, 4, B, C, A, d_r.data_ptr(), None), 'null d_ic')
+    expect_fail(L.qgs_rk_integrate_device(m._h, 70, 128, d_x.data_ptr(), t, len(t), 1, 1, 4, B, C, A, None, None), 'null d_rec')
+    expect_fail(L.qgs_tendencies_device(m._h, 70, 96, d_x.data_ptr(), d_x.data_ptr(), None), 'ld 96')
+    expect_fail(L.qgs_pack_states(m._h, 0, 64, d_x.data_ptr(), d_x.data_ptr(), None), 'n_traj 0')
+    expect_fail(L.qgs_unpack_records(m._h, 70, 128, 0, 6, d_r.data_ptr(), d_r.data_ptr(), None), 'n_inner 0')
+    expect_fail(L.qgs_batched_qr_device(m._h, 70, 128, 4, 5, d_r.data_ptr(), d_x.data_ptr(), None), 'cols > rows')
+    expect_fail(L.qgs_ensemble_moments_device(m._h, 70, 128, 0, d_r.data_ptr(), d_x.data_ptr(), None, None), 'n_rows 0')
+    expect_fail(L.qgs_model_set_kernel(m._h, 7), 'kind 7')
+    # model creation: rank, ndim, coordinates out of range, device out of range
+    h = vp()
+    coo, val = np.ascontiguousarray(g['coo'], dtype=np.int32), np.ascontiguousarray(g['val'])
+    pc, pv = coo.ctypes.data_as(vp), val.ctypes.data_as(vp)
+    expect_fail(L.qgs_model_create_rank(0, nd, 4, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'rank 4')
+    expect_fail(L.qgs_model_create_rank(0, 0, 3, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'ndim 0')
+    expect_fail(L.qgs_model_create_rank(0, nd - 1, 3, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'coordinate > ndim')
+    expect_fail(L.qgs_model_create_rank(99, nd, 3, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'device 99')
+    expect_fail(L.qgs_model_create_rank(0, nd, 3, -1, pc, pv, 0, None, None, ctypes.byref(h)), 'nnz < 0')
+    expect_fail(L.qgs_model_create_rank(0, nd, 3, len(val), None, pv, 0, None, None, ctypes.byref(h)), 'null coo')
+    assert not h.value
+    devs = (ctypes.c_int * 2)(0, 99)
+    expect_fail(L.qgs_group_create(2, devs, nd, 3, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'group device 99')
+    expect_fail(L.qgs_group_create(0, devs, nd, 3, len(val), pc, pv, 0, None, None, ctypes.byref(h)), 'empty group')
+    # a model without a Jacobian tensor refuses the tangent model
+    from qgs_amd import _lib as lib_mod
+    bare = lib_mod.HipModel(nd, g['coo'], g['val'])
+    expect_fail(L.qgs_rk_tgls_integrate(bare._h, 70, 2, ic, tg, t, len(t), 1, 1, 4, B, C, A, 0, 1., out, fm), 'no jacobian')
+    expect_fail(L.qgs_jacobian(bare._h, 1, ic, out), 'no jacobian, single state')
+    bare.close()
+    # ... and the model is still usable
+    assert np.array_equal(m.rk_integrate(t, ic, 1, 1, B, C, A), good)
+    m.close()
+
+
+def test_cache_miss_compiles_the_same_lds_stepper(tmp_path):
+    """ndim 228 on an empty kernel cache: the LDS-resident stepper (requested with set_kernel(2)) is compiled by the
+    out-of-process helper and must come out as the pre-built one: 128 VGPRs (16 wavefronts per workgroup) and no more scratch
+    than the shipped kernel (404 B per lane) -- a compiler change that spills more is caught here."""
+    import json
+    import subprocess
+    import sys
+    code = ("import os, sys, json, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from qgs_amd import _lib\n"
+            "g = np.load(%r)\n"
+            "ndim = int(g['ndim'])\n"
+            "m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval'])\n"
+            "m.set_kernel(2)\n"
+            "n = 256\n"
+            "ic = torch.rand((ndim, n), dtype=torch.float64, device='cuda') * 0.01\n"
+            "rec = torch.empty((1, ndim, n), dtype=torch.float64, device='cuda')\n"
+            "t = np.arange(0., 0.35, 0.1)\n"
+            "b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); c = np.array([0., .5, .5, 1.]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.\n"
+            "m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), torch.cuda.current_stream().cuda_stream)\n"
+            "torch.cuda.synchronize()\n"
+            "print('INFO ' + json.dumps(m.last_kernel_info()))\n"
+            "print('FINITE %%d' %% int(torch.isfinite(rec).all().item()))\n"
+            % (REPO, os.path.join(GOLDEN_DIR, 't228.npz')))
+    p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1500,
+                       env=dict(os.environ, QGS_HIP_CACHE_DIR=str(tmp_path)))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    out = p.stdout.decode()
+    info = json.loads([ln for ln in out.splitlines() if ln.startswith('INFO ')][0][5:])
+    assert info['name'] == 'qgs_spec_rklds16', info
+    assert info['vgprs'] <= 128 and info['scratch_bytes'] <= 404, info
+    assert 'FINITE 1' in out
