@@ -40,6 +40,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+# thread placement of the CPU-baseline leg (one thread per physical core): set before anything loads an OpenMP runtime --
+# PyTorch brings one, and a runtime reads these variables once, when it starts
+os.environ.setdefault('OMP_PLACES', 'cores')
+os.environ.setdefault('OMP_PROC_BIND', 'spread')
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
@@ -217,8 +221,6 @@ def cpu_baseline(ndim, coo, val, rk_steps, dt, seconds_1=5.0, seconds_all=12.0):
     physical_all = physical
     if quota is not None:                                 # more threads than the container's CPU quota only fight each other
         physical = max(1, min(physical, int(quota)))
-    os.environ.setdefault('OMP_PLACES', 'cores')          # one thread per physical core for the all-cores figure
-    os.environ.setdefault('OMP_PROC_BIND', 'spread')
     from oracle.oracle import OracleModel
     flavour = 'fast'
     try:
@@ -338,6 +340,52 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
         'kernel': model.last_kernel_info()['name'], 'ms': el * 1e3, 'traj_steps_per_s': n * steps / el,
         'roofline': {'bound': 'fp64_valu', 'achieved': flops36 * n * steps / el / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': flops36 * n * steps / el / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+
+    # -- the same run through the host-pointer API: records delivered window by window into a page-locked block ----------
+    n, steps = 65536, 100
+    t = grid(steps, 0.1)
+    ic_h = np.random.RandomState(21217).rand(n, ndim) * 0.01
+    out_h = model.rk_integrate(t, ic_h, 1, 1, b, c, a)
+    rec_bytes_h = float(out_h.nbytes)
+    del out_h
+    ts = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        out_h = model.rk_integrate(t, ic_h, 1, 1, b, c, a)
+        ts.append(time.perf_counter() - t0)
+        del out_h
+    el = float(np.median(ts))
+    # the PCIe floor of the same bytes: one page-locked device-to-host copy
+    d_probe = torch.empty(int(rec_bytes_h) // 8, dtype=torch.float64, device=dev)
+    h_probe = torch.empty(int(rec_bytes_h) // 8, dtype=torch.float64).pin_memory()
+    tp = []
+    for _ in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        h_probe.copy_(d_probe, non_blocking=True)
+        torch.cuda.synchronize()
+        tp.append(time.perf_counter() - t0)
+    del d_probe, h_probe
+    out['config2_write_steps_1_host_api'] = {
+        'workload': 'MAOOAM-36, 65 536 members, 100 RK4 steps, write_steps=1 through qgs_rk_integrate: %.2f GB of records into a '
+                    'page-locked host block in the reference layout (n_traj, ndim, n_records)' % (rec_bytes_h / 1e9),
+        'kernel': model.last_kernel_info()['name'], 'record_windows': model.last_windows, 'ms': el * 1e3,
+        'traj_steps_per_s': n * steps / el, 'host_gb_per_s': rec_bytes_h / el / 1e9,
+        'plain_pinned_d2h_copy_ms': float(np.median(tp)) * 1e3,
+        'note': 'PCIe-bound: the wall time is the device-to-host transfer; compute (0.6 ms) and layout conversion run under it'}
+
+    # -- config 5 on ONE GPU: all 1 048 576 members x 1000 steps in one launch (the denominator of the 8-GPU curve) -------
+    n, steps = 1048576, 1000
+    t = grid(steps, 0.1)
+    ic = torch.from_numpy(np.random.RandomState(5).rand(ndim, n) * 0.01).to(dev)
+    rec = torch.empty((1, ndim, n), dtype=torch.float64, device=dev)
+    ms, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 3)
+    out['config5_one_gpu'] = {
+        'workload': 'BASELINE configs[4] on one GPU: MAOOAM-36, 1 048 576 members, 1000 RK4 steps, write_steps=0, one launch',
+        'kernel': model.last_kernel_info()['name'], 'ms': ms, 'traj_steps_per_s': n * steps / (ms * 1e-3),
+        'roofline': {'bound': 'fp64_valu', 'achieved': flops36 * n * steps / (ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
+                     'unit': 'TFLOP/s', 'frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+    del ic, rec
 
     # -- config 4: tangent model, 16 384 members x 36 columns, 10 sub-steps per call, 100 calls; QR separately -------
     n, steps, n_tg, calls = 16384, 10, ndim, 100

@@ -127,7 +127,9 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
  * shards, shard i = members [start, start + count) with the remainder going to the first shards (qgs_group_shard); every
  * shard is integrated by its own model from a host thread of its own and delivers its slice of the result block itself
  * (G parallel device-to-host streams; no collective).  Arguments and results exactly as for the qgs_model entry points of
- * the same name; results are bitwise those of a single model.  SURVEY 8(b)'s `device_mask`. */
+ * the same name.  A shard's results are bitwise what a qgs_model returns for those members alone; against one qgs_model call
+ * over the whole ensemble they agree to rounding (the library chooses its kernel by the size of the ensemble it is handed).
+ * SURVEY 8(b)'s `device_mask`. */
 int qgs_group_create(int n_devices, const int *devices, int ndim, int rank,
                      int64_t nnz, const int32_t *coo, const double *val,
                      int64_t jnnz, const int32_t *jcoo, const double *jval, qgs_group **out);

@@ -50,10 +50,22 @@ void launch_gen_tend(const DevTensor &T, int ndim, int64_t n_traj, int64_t ld, c
 // Df(x) -> jm[(i-1)*ndim + (j-1)][member]   (output must be zero-filled by the caller)
 void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, const double *x, double *jm, hipStream_t st);
 
-// One state (n_traj == 1, the f / Df handed to an ODE solver): x, dx are plain (ndim,) vectors, possibly in page-locked host
-// memory; jm is (ndim, ndim) row-major in device memory, zero-filled by the caller.  ndim <= 8190 (LDS copy of x).
-void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, hipStream_t st);
-void launch_gen_jac_one(const DevTensor &Jt, int ndim, const double *x, double *jm, hipStream_t st);
+// One state (n_traj == 1, the f / Df handed to an ODE solver): x, dx, jm are plain (ndim,) / (ndim, ndim) arrays in a
+// page-locked host block; when the grid has finished, `seq` appears in *flag (host memory) -- the host spins on it instead of
+// synchronising the stream.  `counter` is a zero-initialised device word.  ndim <= 8190 (LDS copy of x).
+// Df works on the Jacobian tensor grouped by output element: pair p = entries [ptr[p], ptr[p + 1]) with idx = k (and idx2 for
+// rank 5), lut[(i - 1) * ndim + (j - 1)] = p or -1.
+struct OnePairs {
+    const int32_t *lut;      // ndim * ndim
+    const int32_t *ptr;      // n_pairs + 1
+    const uint32_t *idx;     // n_entries: k
+    const double *val;       // n_entries
+    const uint32_t *idx2;    // n_entries or null
+};
+void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, unsigned *counter, unsigned long long *flag,
+                         unsigned long long seq, hipStream_t st);
+void launch_gen_jac_one(const OnePairs &P, int ndim, const double *x, double *jm, unsigned *counter, unsigned long long *flag,
+                        unsigned long long seq, hipStream_t st);
 
 // Explicit s-stage RK with the full `a` matrix (integrate.py:204-221).
 //   work: (s + 2) * ndim * ld doubles of scratch;  stages: optional S[(step-step_begin)*s+stage][mode][member]

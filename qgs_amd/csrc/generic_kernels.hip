@@ -69,43 +69,70 @@ __global__ void __launch_bounds__(WAVE) gen_jac_kernel(DevTensor Jt, int ndim, i
 }
 
 // ---- one state: f(x) and Df(x) for a single (ndim,) vector (the callables handed to SciPy / DiffEq solvers) -----------
-// One workgroup, thread = tensor row; x may live in page-locked host memory (read once, into LDS), so may dx.
-__global__ void __launch_bounds__(256) gen_tend_one_kernel(DevTensor T, int ndim, const double *__restrict__ x, double *__restrict__ dx)
+// x and the results live in a page-locked host block the kernel addresses directly.  The host does not call
+// hipStreamSynchronize (12 us per launch + wait on this stack): the workgroup that finishes last writes the call's sequence
+// number into the block and the host spins on it (7.8 us; tools/ubench/launch_latency.hip).
+__device__ __forceinline__ void one_state_done(unsigned *counter, volatile unsigned long long *flag, unsigned long long seq)
+{
+    __threadfence_system();                                 // this workgroup's results are visible to the host ...
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(counter, 1u);
+        if (done == gridDim.x - 1) {                        // ... and so are everybody else's: they fenced before they counted
+            *counter = 0;
+            __threadfence_system();
+            *flag = seq;
+        }
+    }
+}
+
+// f: one wavefront per tensor row, lanes stride over the row's entries (coalesced), butterfly sum
+__global__ void __launch_bounds__(256) gen_tend_one_kernel(DevTensor T, int ndim, const double *__restrict__ x, double *__restrict__ dx,
+                                                           unsigned *counter, volatile unsigned long long *flag, unsigned long long seq)
 {
     extern __shared__ double xs[];                         // slot 0 = 1 (the constant), slot d = x_d
     for (int d = threadIdx.x; d <= ndim; d += blockDim.x) xs[d] = d ? x[d - 1] : 1.0;
     __syncthreads();
-    for (int i = threadIdx.x + 1; i <= ndim; i += blockDim.x) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    for (int i = 1 + blockIdx.x * nwv + wv; i <= ndim; i += gridDim.x * nwv) {
         double r = 0.0;
         const int e1 = T.rowptr[i + 1];
-        for (int e = T.rowptr[i]; e < e1; ++e) {
+        for (int e = T.rowptr[i] + lane; e < e1; e += 64) {
             const uint32_t jk = T.idx[e];
             double t = xs[jk >> 16] * xs[jk & 0xffffu];
             if (T.idx2) { const uint32_t cd = T.idx2[e]; t *= xs[cd >> 16] * xs[cd & 0xffffu]; }
             r = __builtin_fma(t, T.val[e], r);
         }
-        dx[i - 1] = r;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+        if (lane == 0) dx[i - 1] = r;
     }
+    one_state_done(counter, flag, seq);
 }
 
-// jm is (ndim, ndim) row-major in DEVICE memory, zero-filled by the caller; thread i owns row i
-__global__ void __launch_bounds__(256) gen_jac_one_kernel(DevTensor Jt, int ndim, const double *__restrict__ x, double *__restrict__ jm)
+// Df: one thread per element of the (ndim, ndim) output; lut[i * ndim + j] = index of the (i, j) pair in the pair-grouped
+// Jacobian tensor (OnePairs) or -1 where the Jacobian is structurally zero.  Every element is written: no zero-fill.
+__global__ void __launch_bounds__(256) gen_jac_one_kernel(OnePairs P, int ndim, const double *__restrict__ x, double *__restrict__ jm,
+                                                          unsigned *counter, volatile unsigned long long *flag, unsigned long long seq)
 {
     extern __shared__ double xs[];
     for (int d = threadIdx.x; d <= ndim; d += blockDim.x) xs[d] = d ? x[d - 1] : 1.0;
     __syncthreads();
-    for (int i = threadIdx.x + 1; i <= ndim; i += blockDim.x) {
-        const int e1 = Jt.rowptr[i + 1];
-        for (int e = Jt.rowptr[i]; e < e1; ++e) {
-            const uint32_t jk = Jt.idx[e];
-            const uint32_t j = jk >> 16;
-            if (j == 0) continue;
-            double xk = xs[jk & 0xffffu];
-            if (Jt.idx2) { const uint32_t cd = Jt.idx2[e]; xk *= xs[cd >> 16] * xs[cd & 0xffffu]; }
-            double *q = jm + (int64_t)(i - 1) * ndim + (j - 1);
-            *q = __builtin_fma(xk, Jt.val[e], *q);
+    const int total = ndim * ndim;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        double r = 0.0;
+        const int p = P.lut[t];
+        if (p >= 0) {
+            const int e1 = P.ptr[p + 1];
+            for (int e = P.ptr[p]; e < e1; ++e) {
+                const uint32_t w = P.idx[e];
+                double xk = xs[w & 0xffffu];
+                if (P.idx2) { const uint32_t cd = P.idx2[e]; xk *= xs[cd >> 16] * xs[cd & 0xffffu]; }
+                r = __builtin_fma(xk, P.val[e], r);
+            }
         }
+        jm[t] = r;
     }
+    one_state_done(counter, flag, seq);
 }
 
 __device__ __forceinline__ int64_t rec_index(int64_t iw, int64_t n_records, int backward)
@@ -899,14 +926,20 @@ void launch_gen_jac(const DevTensor &Jt, int ndim, int64_t n_traj, int64_t ld, c
     hipLaunchKernelGGL(gen_jac_kernel, dim3(blocks_for(n_traj, WAVE)), dim3(WAVE), 0, st, Jt, ndim, n_traj, ld, x, jm);
 }
 
-void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, hipStream_t st)
+void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *dx, unsigned *counter,
+                         unsigned long long *flag, unsigned long long seq, hipStream_t st)
 {
-    hipLaunchKernelGGL(gen_tend_one_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, T, ndim, x, dx);
+    const int blocks = std::min(256, (ndim + 3) / 4);
+    hipLaunchKernelGGL(gen_tend_one_kernel, dim3(blocks), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, T, ndim, x, dx, counter,
+                       flag, seq);
 }
 
-void launch_gen_jac_one(const DevTensor &Jt, int ndim, const double *x, double *jm, hipStream_t st)
+void launch_gen_jac_one(const OnePairs &P, int ndim, const double *x, double *jm, unsigned *counter, unsigned long long *flag,
+                        unsigned long long seq, hipStream_t st)
 {
-    hipLaunchKernelGGL(gen_jac_one_kernel, dim3(1), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, Jt, ndim, x, jm);
+    const int blocks = std::min(256, (ndim * ndim + 255) / 256);
+    hipLaunchKernelGGL(gen_jac_one_kernel, dim3(blocks), dim3(256), sizeof(double) * (size_t)(ndim + 1), st, P, ndim, x, jm, counter,
+                       flag, seq);
 }
 
 void launch_gen_rk(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,

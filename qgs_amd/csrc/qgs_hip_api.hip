@@ -586,6 +586,12 @@ struct qgs_model {
     // single-state fast path of f / Df: page-locked staging block the kernels read and write directly
     double *h_pin = nullptr, *d_pin = nullptr;
     size_t pin_cap = 0;
+    unsigned *d_one_counter = nullptr;                 // "workgroups finished" word of the single-state kernels
+    unsigned long long one_seq = 0;                    // sequence number of the last single-state call (the kernel echoes it into h_pin[0])
+    // Jacobian tensor grouped by output element (generic_kernels.h OnePairs), models of up to 1024 variables
+    int32_t *p_lut = nullptr, *p_ptr = nullptr;
+    uint32_t *p_idx = nullptr, *p_idx2 = nullptr;
+    double *p_val = nullptr;
     int64_t last_windows = 0;      // windows of the last host-layout integration (qgs_model_info 8)
     KernelInfo last;
 };
@@ -696,6 +702,39 @@ int upload_tiled(qgs_model *m, const std::vector<Entry> &Tr)
     if (upload_vec(row_map, &m->t_row_map)) return -1;
     if (upload_vec(row_term, &m->t_row_term) || upload_vec(joff, &m->t_term_joff) || upload_vec(koff, &m->t_term_koff) ||
         upload_vec(c, &m->t_term_c)) return -1;
+    return 0;
+}
+
+// Jacobian tensor grouped by output element (i, j) for the single-state Df kernel (generic_kernels.h OnePairs): entries keep
+// their incoming order inside a pair.  Only for ndim <= QGS_ONE_MAX_NDIM (the lookup table is ndim^2 words).
+#ifndef QGS_ONE_MAX_NDIM
+#define QGS_ONE_MAX_NDIM 1024
+#endif
+int upload_pairs(qgs_model *m, const std::vector<Entry> &Jr, bool rank5)
+{
+    const int ndim = m->ndim;
+    if (Jr.empty() || ndim > QGS_ONE_MAX_NDIM) return 0;
+    std::vector<int32_t> lut((size_t)ndim * ndim, -1), count;
+    for (const auto &t : Jr) {
+        int32_t &p = lut[(size_t)(t.i - 1) * ndim + (t.j - 1)];
+        if (p < 0) { p = (int32_t)count.size(); count.push_back(0); }
+        count[(size_t)p]++;
+    }
+    // pairs numbered in row-major order of (i, j): neighbouring threads walk neighbouring entries
+    std::vector<int32_t> ptr(1, 0);
+    for (auto &p : lut)
+        if (p >= 0) { const int32_t c = count[(size_t)p]; p = (int32_t)ptr.size() - 1; ptr.push_back(ptr.back() + c); }
+    std::vector<int32_t> pos(ptr.begin(), ptr.end() - 1);
+    std::vector<uint32_t> idx(Jr.size()), idx2(rank5 ? Jr.size() : 0);
+    std::vector<double> val(Jr.size());
+    for (const auto &t : Jr) {
+        const int32_t e = pos[(size_t)lut[(size_t)(t.i - 1) * ndim + (t.j - 1)]]++;
+        idx[(size_t)e] = (uint32_t)t.k;
+        val[(size_t)e] = t.v;
+        if (rank5) idx2[(size_t)e] = ((uint32_t)t.l << 16) | (uint32_t)t.m;
+    }
+    if (upload_vec(lut, &m->p_lut) || upload_vec(ptr, &m->p_ptr) || upload_vec(idx, &m->p_idx) || upload_vec(val, &m->p_val)) return -1;
+    if (rank5 && upload_vec(idx2, &m->p_idx2)) return -1;
     return 0;
 }
 
@@ -1129,6 +1168,7 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     HostCsr hJi = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.i; }, [&](const Entry &t) { return pack(t.j, t.k); });
     HostCsr hJj = build_csr(ndim, Jr, r5, [](const Entry &t) { return t.j; }, [&](const Entry &t) { return pack(t.i, t.k); });
     if (upload_csr(hT, m->dT) || upload_csr(hJi, m->dJ_by_i) || upload_csr(hJj, m->dJ_by_j)) { qgs_model_destroy(m); return -1; }
+    if (upload_pairs(m, Jr, r5)) { qgs_model_destroy(m); return -1; }
     if (!r5 && upload_tiled(m, Tr)) { qgs_model_destroy(m); return -1; }
     if (r5 && upload_reduced(m)) { qgs_model_destroy(m); return -1; }
     classify_model(m);
@@ -1167,6 +1207,8 @@ int qgs_model_destroy(qgs_model *m)
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
+    for (void *q : {(void *)m->d_one_counter, (void *)m->p_lut, (void *)m->p_ptr, (void *)m->p_idx, (void *)m->p_idx2, (void *)m->p_val})
+        if (q) (void)hipFree(q);
     delete m;
     return 0;
 }
@@ -1650,6 +1692,7 @@ static int pin_ensure(qgs_model *m, size_t doubles)
     m->pin_cap = 0;
     HIPCHK(hipHostMalloc((void **)&m->h_pin, sizeof(double) * doubles, hipHostMallocMapped));
     HIPCHK(hipHostGetDevicePointer((void **)&m->d_pin, m->h_pin, 0));
+    std::memset(m->h_pin, 0, sizeof(double) * doubles);       // word 0 is the completion flag: sequence numbers start at 1
     m->pin_cap = doubles;
     return 0;
 }
@@ -1666,64 +1709,66 @@ static int streams_ready(qgs_model *m)
     return 0;
 }
 
+// wait until the single-state kernel has echoed `seq` into the page-locked block; the stream is only consulted now and then
+// (a kernel that died would otherwise never be noticed)
+static int one_state_wait(qgs_model *m, hipStream_t st, unsigned long long seq)
+{
+    volatile unsigned long long *flag = (volatile unsigned long long *)m->h_pin;
+    for (unsigned long long spins = 1;; ++spins) {
+        if (*flag == seq) return 0;
+        if ((spins & 0xfffffull) == 0) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) { if (*flag == seq) return 0; return fail("single-state kernel finished without reporting completion"); }
+            if (e != hipErrorNotReady) return fail(std::string("single-state kernel failed: ") + hipGetErrorString(e));
+        }
+    }
+}
+
+static int one_state_ready(qgs_model *m, size_t doubles)
+{
+    if (streams_ready(m) || pin_ensure(m, doubles + 1)) return -1;
+    if (!m->d_one_counter) {
+        HIPCHK(hipMalloc((void **)&m->d_one_counter, sizeof(unsigned)));
+        HIPCHK(hipMemset(m->d_one_counter, 0, sizeof(unsigned)));
+    }
+    return 0;
+}
+
+static bool one_state_possible(const qgs_model *m, bool jac)
+{
+    if (m->kernel_kind != 0 || m->ndim > 8190) return false;     // an explicit kernel family keeps the batched route of that family
+    return !jac || m->p_lut != nullptr;
+}
+
 static int tendencies_one(qgs_model *m, const double *x, double *dx)
 {
     const int nd = m->ndim;
-    if (streams_ready(m) || pin_ensure(m, 2 * (size_t)nd)) return -1;
+    if (one_state_ready(m, 2 * (size_t)nd)) return -1;
     hipStream_t st = m->st_comp;
-    std::memcpy(m->h_pin, x, sizeof(double) * nd);
-    const double *d_x = m->d_pin;
-    double *d_dx = m->d_pin + nd;
-    if (use_spec(m, 1, nullptr) && !m->prefer_lds) {
-        hipFunction_t f;
-        if (get_function(m, qgs::Kernel::Tend, 0, &f)) return -1;
-        long long nt = 1, l = 1;
-        void *args[] = {(void *)&d_x, (void *)&d_dx, &nt, &l};
-        note_kernel(m, "qgs_spec_tend", f);
-        if (launch(f, 1, st, args)) return -1;
-    } else {
-        if (nd > 8190) return fail("ndim too large for the single-state kernel");
-        qgs::launch_gen_tend_one(m->dT.view(), nd, d_x, d_dx, st);
-        note_kernel(m, "gen_tend_one_kernel", nullptr);
-        HIPCHK(hipGetLastError());
-    }
-    HIPCHK(hipStreamSynchronize(st));
-    std::memcpy(dx, m->h_pin + nd, sizeof(double) * nd);
+    std::memcpy(m->h_pin + 1, x, sizeof(double) * nd);
+    const unsigned long long seq = ++m->one_seq;
+    qgs::launch_gen_tend_one(m->dT.view(), nd, m->d_pin + 1, m->d_pin + 1 + nd, m->d_one_counter, (unsigned long long *)m->d_pin, seq, st);
+    note_kernel(m, "gen_tend_one_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    if (one_state_wait(m, st, seq)) return -1;
+    std::memcpy(dx, m->h_pin + 1 + nd, sizeof(double) * nd);
     return 0;
 }
 
 static int jacobian_one(qgs_model *m, const double *x, double *jac)
 {
-    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
     const int nd = m->ndim;
     const size_t nn = (size_t)nd * nd;
-    if (streams_ready(m) || pin_ensure(m, (size_t)nd + nn)) return -1;
+    if (one_state_ready(m, (size_t)nd + nn)) return -1;
     hipStream_t st = m->st_comp;
-    std::memcpy(m->h_pin, x, sizeof(double) * nd);
-    const double *d_x = m->d_pin;
-    if (use_spec(m, 1, nullptr) && m->spec_jac_possible) {
-        // the specialised kernel stores every structural entry exactly once: it writes the page-locked block itself
-        double *d_j = m->d_pin + nd;
-        std::memset(m->h_pin + nd, 0, sizeof(double) * nn);
-        hipFunction_t f;
-        if (get_function(m, qgs::Kernel::Jac, 0, &f)) return -1;
-        long long nt = 1, l = 1;
-        void *args[] = {(void *)&d_x, (void *)&d_j, &nt, &l};
-        note_kernel(m, "qgs_spec_jac", f);
-        if (launch(f, 1, st, args)) return -1;
-        HIPCHK(hipStreamSynchronize(st));
-    } else {
-        // the generic kernel accumulates into its output: device buffer, then one copy into the page-locked block
-        if (nd > 8190) return fail("ndim too large for the single-state kernel");
-        if (m->b_fm_modes.ensure(sizeof(double) * nn)) return -1;
-        HIPCHK(hipMemsetAsync(m->b_fm_modes.p, 0, sizeof(double) * nn, st));
-        qgs::launch_gen_jac_one(m->dJ_by_i.view(), nd, d_x, m->b_fm_modes.f64(), st);
-        note_kernel(m, "gen_jac_one_kernel", nullptr);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(m->h_pin + nd, m->b_fm_modes.p, sizeof(double) * nn, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-    }
-    std::memcpy(jac, m->h_pin + nd, sizeof(double) * nn);
+    std::memcpy(m->h_pin + 1, x, sizeof(double) * nd);
+    const unsigned long long seq = ++m->one_seq;
+    const qgs::OnePairs P{m->p_lut, m->p_ptr, m->p_idx, m->p_val, m->p_idx2};
+    qgs::launch_gen_jac_one(P, nd, m->d_pin + 1, m->d_pin + 1 + nd, m->d_one_counter, (unsigned long long *)m->d_pin, seq, st);
+    note_kernel(m, "gen_jac_one_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    if (one_state_wait(m, st, seq)) return -1;
+    std::memcpy(jac, m->h_pin + 1 + nd, sizeof(double) * nn);
     return 0;
 }
 
@@ -1731,7 +1776,7 @@ int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx)
 {
     if (!m || !x || !dx || n_traj < 1) return fail("bad arguments");
     HIPCHK(hipSetDevice(m->device));
-    if (n_traj == 1 && m->kernel_kind != 1) return tendencies_one(m, x, dx);
+    if (n_traj == 1 && one_state_possible(m, false)) return tendencies_one(m, x, dx);
     const int64_t ld = round_ld(n_traj);
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b)) return -1;
@@ -1747,7 +1792,8 @@ int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac)
 {
     if (!m || !x || !jac || n_traj < 1) return fail("bad arguments");
     HIPCHK(hipSetDevice(m->device));
-    if (n_traj == 1 && m->kernel_kind != 1) return jacobian_one(m, x, jac);
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    if (n_traj == 1 && one_state_possible(m, true)) return jacobian_one(m, x, jac);
     const int64_t ld = round_ld(n_traj), nn = (int64_t)m->ndim * m->ndim;
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     const size_t jm_b = sizeof(double) * (size_t)ld * nn, jr_b = sizeof(double) * (size_t)n_traj * nn;
@@ -1799,16 +1845,26 @@ static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_
 
 // device-side address of a destination block: the block itself when it is device memory, its mapped alias when it is
 // page-locked host memory (qgs_host_register / hipHostMalloc), null for pageable host memory
-static double *device_alias(qgs_model *m, double *dst)
+static double *device_alias(qgs_model *m, double *dst, bool *is_device = nullptr)
 {
-    if (m->tune.d2h_mode == 2) return nullptr;
+    if (is_device) *is_device = false;
     hipPointerAttribute_t at;
     if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (at.type == hipMemoryTypeDevice) return dst;
-    if (at.type != hipMemoryTypeHost) return nullptr;
+    if (at.type == hipMemoryTypeDevice) { if (is_device) *is_device = true; return dst; }
+    if (at.type != hipMemoryTypeHost || m->tune.d2h_mode == 2) return nullptr;
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return (double *)dp;
+}
+
+// Which way a page-locked host block is filled (measured, tools/d2h_routes.py, 1.9 GB of records, PCIe floor 33.4 ms): one
+// window -> staging + one contiguous DMA copy, 35.6 ms (the unpack kernel's own stores over PCIe: 38.0 ms); several windows ->
+// the kernel's stores, whose runs of W doubles per (member, variable) cost 40 / 49 ms at W = 105 / 13, where the strided
+// copy of the staged window costs 50 / 119 ms.  So: the copy when the whole record fits the budget three times, else stores.
+static bool prefer_copy_route(const qgs_model *m, bool dst_is_device, int64_t n_records, size_t bytes_per_record)
+{
+    if (dst_is_device || m->tune.d2h_mode == 1) return false;
+    return m->tune.window_bytes / std::max<size_t>(1, bytes_per_record * 3) >= (size_t)n_records;
 }
 
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
@@ -1859,7 +1915,9 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     HIPCHK(hipGetLastError());
     const double *d_time, *d_tab_spec, *d_tab_full;
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
-    double *alias = device_alias(m, traj);
+    bool dst_dev = false;
+    double *alias = device_alias(m, traj, &dst_dev);
+    if (alias && prefer_copy_route(m, dst_dev, n_records, modes_b)) alias = nullptr;
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
@@ -1971,7 +2029,9 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     HIPCHK(hipGetLastError());
     const double *d_time, *d_tab_spec, *d_tab_full;
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
-    double *alias_t = device_alias(m, traj), *alias_f = device_alias(m, fmatrix);
+    bool dev_t = false, dev_f = false;
+    double *alias_t = device_alias(m, traj, &dev_t), *alias_f = device_alias(m, fmatrix, &dev_f);
+    if (prefer_copy_route(m, dev_t || dev_f, n_records, modes_b + tg_modes_b)) alias_t = alias_f = nullptr;
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
                                          (alias_t && alias_f) ? 2 : 3);
     m->last_windows = plan.n_windows;

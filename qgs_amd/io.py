@@ -11,7 +11,6 @@ tensor assembly (5 s for MAOOAM 6x6 here, 94 s in the reference) run once per pa
 """
 import hashlib
 import os
-import pickle
 
 import numpy as np
 
@@ -53,16 +52,54 @@ def save_trajectory_txt(filename, time, traj, **savetxt_kwargs):
     np.savetxt(filename, np.column_stack((time, traj.T)), **savetxt_kwargs)
 
 
+def _assembly_version():
+    """Hash of the source files that turn a parameter set into tensors: a fix to the inner products or the tensor assembly must
+    not keep serving tensors cached by the old code."""
+    import qgs_amd.inner_products.analytic as ipa
+    import qgs_amd.inner_products.symbolic as ips
+    import qgs_amd.tensors.qgtensor as qgt
+    import qgs_amd.basis.fourier as bf
+    h = hashlib.sha256(b'qgs_amd tensor cache v2')
+    for mod in (ipa, ips, qgt, bf):
+        with open(mod.__file__, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def _canonical(obj, depth=0):
+    """Parameter objects as nested plain data with sorted keys (pickle bytes are not canonical: memoisation and attribute
+    order let equal parameter sets hash differently)."""
+    if depth > 12:
+        return repr(obj)
+    if isinstance(obj, (bool, int, str, bytes, type(None))):
+        return obj
+    if isinstance(obj, float):
+        return float(obj).hex()
+    if isinstance(obj, np.ndarray):
+        return ('ndarray', obj.dtype.str, obj.shape, hashlib.sha256(np.ascontiguousarray(obj).tobytes()).hexdigest())
+    if isinstance(obj, np.generic):
+        return _canonical(obj.item(), depth + 1)
+    if isinstance(obj, (list, tuple)):
+        return [_canonical(q, depth + 1) for q in obj]
+    if isinstance(obj, dict):
+        return sorted((repr(k), _canonical(v, depth + 1)) for k, v in obj.items())
+    state = getattr(obj, '__dict__', None)
+    if state is not None:
+        return (type(obj).__name__, _canonical(state, depth + 1))
+    return repr(obj)
+
+
 def params_key(params):
-    """Hash of a parameter set: the pickled `QgParams` object (the reference's parameter objects are picklable,
-    documentation user_guide.rst "saving the model"), so any change of a physical parameter or of the mode selection gives
-    another key."""
-    return hashlib.sha256(pickle.dumps(params, protocol=4)).hexdigest()[:24]
+    """Hash of a parameter set (canonical form of the `QgParams` object: every physical parameter and the mode selection) and
+    of the tensor-assembly code: a change to either gives another key."""
+    text = repr((_assembly_version(), int(params.ndim), _canonical(params)))
+    return hashlib.sha256(text.encode()).hexdigest()[:24]
 
 
 def cached_tendencies(params, cache_dir, device=0):
     """``[f, Df]`` of `create_tendencies(params)`, with the tensor operands read from / written to
-    ``<cache_dir>/qgs_tensor_<key>.npz`` (key = `params_key(params)`)."""
+    ``<cache_dir>/qgs_tensor_<key>.npz`` (key = `params_key(params)`); `f` and `Df` are bound to GPU `device` whether the
+    tensors came from the cache or were just assembled."""
     from qgs_amd.functions.tendencies import create_tendencies, tendencies_from_tensor
     os.makedirs(cache_dir, exist_ok=True)
     path = os.path.join(cache_dir, 'qgs_tensor_%s.npz' % params_key(params))
@@ -70,8 +107,9 @@ def cached_tendencies(params, cache_dir, device=0):
         z = np.load(path)
         f, Df = tendencies_from_tensor(int(z['ndim']), z['coo'], z['val'], z['jcoo'], z['jval'], device=device)
         return [f, Df]
-    f, Df = create_tendencies(params)
+    f0, Df0 = create_tendencies(params)
     tmp = path + '.tmp%d.npz' % os.getpid()
-    np.savez_compressed(tmp, ndim=np.int64(f.ndim), coo=f.coo, val=f.val, jcoo=Df.coo, jval=Df.val)
+    np.savez_compressed(tmp, ndim=np.int64(f0.ndim), coo=f0.coo, val=f0.val, jcoo=Df0.coo, jval=Df0.val)
     os.replace(tmp, path)
+    f, Df = tendencies_from_tensor(f0.ndim, f0.coo, f0.val, Df0.coo, Df0.val, device=device)
     return [f, Df]

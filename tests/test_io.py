@@ -48,3 +48,13 @@ def test_tensor_cache_is_keyed_by_the_parameter_set(tmp_path):
     q = params_rp20()
     q.set_params({'kd': 0.05})
     assert params_key(q) != params_key(p)
+    # a miss and a hit return functions bound to the same device
+    miss = cached_tendencies(q, str(tmp_path), device=3)
+    hit = cached_tendencies(q, str(tmp_path), device=3)
+    assert miss[0].device == 3 and miss[1].device == 3 and hit[0].device == 3
+    assert params_key(pickle_round_trip(q)) == params_key(q)         # an equal parameter set that took another road hashes equally
+
+
+def pickle_round_trip(obj):
+    import pickle
+    return pickle.loads(pickle.dumps(obj))

@@ -1,0 +1,61 @@
+"""GPU box: a record larger than the device budget (or than HBM) through the host-pointer API.
+
+    python tools/big_record.py [n_records-1 = steps, default 1000] [members, default 65536]
+
+BASELINE config 2 with write_steps=1 over `steps` RK4 steps: the (members, 36, steps + 1) record goes to a page-locked host
+block window by window while the next window is computed.  10 000 steps at 65 536 members is 189 GB of records -- more than the
+MI355X's 288 GB HBM could hold twice (what the round-2 API needed), and the size VERDICT r02 asked for.  Refuses when the host
+has less than twice the record free.  Checks: sample members' first 101 records against the oracle, the initial conditions in
+record 0, finite values at a stride."""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from qgs_amd import _lib                                                      # noqa: E402
+from bench import load_model_tensors, rk4_tableau, grid                      # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+ndim, coo, val, jcoo, jval, _ = load_model_tensors()
+nbytes = n * ndim * (steps + 1) * 8
+avail = 0
+for ln in open('/proc/meminfo'):
+    if ln.startswith('MemAvailable'):
+        avail = int(ln.split()[1]) * 1024
+print('record %.1f GB, host memory available %.1f GB' % (nbytes / 1e9, avail / 1e9))
+if avail < 2 * nbytes:
+    print('not enough host memory for this record; nothing run')
+    sys.exit(0)
+b, c, a = rk4_tableau()
+t = grid(steps, 0.1)
+ic = np.random.RandomState(21217).rand(n, ndim) * 0.01
+m = _lib.HipModel(ndim, coo, val, jcoo, jval)
+t0 = time.perf_counter()
+out = np.empty((n, ndim, steps + 1))
+L = _lib.lib()
+import ctypes                                                                  # noqa: E402
+t1 = time.perf_counter()
+pinned = L.qgs_host_register(out.ctypes.data_as(ctypes.c_void_p), out.nbytes) == 0
+t2 = time.perf_counter()
+print('allocation %.2f s, page-locking %.2f s (%s)' % (t1 - t0, t2 - t1, 'ok' if pinned else _lib.last_error()))
+for rep in range(2):
+    t3 = time.perf_counter()
+    rc = L.qgs_rk_integrate(m._h, n, ic, t, len(t), 1, 1, 4, b, c, a, out)
+    el = time.perf_counter() - t3
+    assert rc == 0, _lib.last_error()
+    print('run %d: %d windows, %.3f s wall = %.1f GB/s of records to the host, %.3g traj-steps/s (compute alone would take %.3f s)'
+          % (rep, m.last_windows, el, nbytes / el / 1e9, n * steps / el, 6.2e-6 * steps))
+from oracle.oracle import OracleModel                                         # noqa: E402  (checker only)
+pick = np.array([0, 63, 64, n - 1])
+k = min(steps, 100) + 1                                                       # a run's first records do not depend on its length
+ref = OracleModel(ndim, coo, val, jcoo, jval).integrate_runge_kutta_jit(t[:k], ic[pick], 1, 1, b, c, a)
+err = float(np.abs(out[pick][:, :, :k] - ref).max() / np.abs(ref).max())
+print('members %s, first %d records against the oracle: max rel err %.1e (tolerance 1e-12)' % (pick.tolist(), k, err))
+print('record 0 == initial conditions:', bool(np.array_equal(out[:, :, 0], ic)))
+print('finite at stride 997:', bool(np.isfinite(out.reshape(-1)[::997]).all()))
+if pinned:
+    L.qgs_host_unregister(out.ctypes.data_as(ctypes.c_void_p))
