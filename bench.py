@@ -408,6 +408,18 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
     ms_qr, _ = event_ms(torch, lambda: model.batched_qr_device(n, n, ndim, n_tg, recm.data_ptr(), rdiag.data_ptr(), st), 5)
     flops_tgls = 4 * (2 * jnnz) + 4 * 2 * ndim ** 3 + 7 * 2 * ndim * ndim + flops36     # 4.02e5 at ndim 36
     rate = n * steps / (ms_call * 1e-3)
+    # what the two kernels of a call EXECUTE: fp64 instructions of their step loops, counted in the ISA (tools/kisa.py ->
+    # profiles/r03_kernel_isa.json; the tangent kernel's loop holds the tangent and the adjoint branch: half of it runs)
+    executed = None
+    try:
+        with open(os.path.join(HERE, 'profiles', 'r03_kernel_isa.json')) as f:
+            isa = json.load(f)
+        tg_i = isa['bench:' + kname['name']]['hot_loop']['fp64'] / 2.0
+        st_i = isa['bench:qgs_spec_rkstagesp_s4']['hot_loop']['fp64']
+        executed = {'fp64_instr_per_column_step': tg_i, 'fp64_instr_per_member_step_trajectory_pass': st_i,
+                    'flops_per_traj_step': 2.0 * (n_tg * tg_i + st_i)}
+    except (OSError, KeyError, ValueError):
+        pass
     out['config4_tgls'] = {
         'workload': 'MAOOAM-36 tangent model, 16 384 members x 36 tangent vectors (identity), 10 sub-steps per call, '
                     '%d calls timed together (trajectory pass + tangent pass per call)' % calls,
@@ -418,6 +430,8 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
                      'flops_per_traj_step': flops_tgls,
                      'note': 'dense-matrix flop count of SURVEY 8(a) a8 (the kernel evaluates the sparse J w directly and '
                              'executes fewer)',
+                     'executed': executed,
+                     'executed_fp64_frac': (rate * executed['flops_per_traj_step'] / 1e12 / FP64_VALU_PEAK_TFLOPS) if executed else None,
                      'hbm_algorithmic_frac': rate * 2 * 8 * (ndim + ndim * n_tg) / 1e9 / HBM_PEAK_GBS}}
     del tg, recm, rdiag
 

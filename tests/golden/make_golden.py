@@ -498,6 +498,39 @@ def gen_callables():
     print('[callables] wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.), flush=True)
 
 
+def gen_initialize():
+    """`RungeKuttaIntegrator.initialize` of the reference (integrator.py:198-295) on RP-20: the random draws it consumes and
+    the states it leaves in `ic`, (a) with num_threads >= number_of_trajectories -- ONE batch: every member is a random state
+    converged over `convergence_time` -- and (b) with fewer workers than members, where the set grows batch by batch from
+    perturbed converged states."""
+    t_start = time.time()
+    f, Df = create_tendencies(params_rp20())
+    out = {}
+    integ = RungeKuttaIntegrator(num_threads=6)
+    integ.set_func(f)
+    np.random.seed(2023)
+    integ.initialize(3.0, 0.1, number_of_trajectories=6)
+    out['one_batch_ic'] = np.asarray(integ.get_ic())
+    out['one_batch_next_draw'] = np.random.rand(3)               # where the generator stands afterwards
+    integ.terminate()
+    integ = RungeKuttaIntegrator(num_threads=2)
+    integ.set_func(f)
+    np.random.seed(2024)
+    integ.initialize(3.0, 0.1, pert_size=0.01, reconvergence_time=1.0, number_of_trajectories=5)
+    out['batched_ic'] = np.asarray(integ.get_ic())
+    out['batched_next_draw'] = np.random.rand(3)
+    integ.terminate()
+    integ = RungeKuttaIntegrator(num_threads=2)
+    integ.set_func(f)
+    np.random.seed(2025)
+    integ.initialize(2.0, 0.1, number_of_trajectories=2, forward=False)
+    out['backward_ic'] = np.asarray(integ.get_ic())
+    integ.terminate()
+    path = os.path.join(HERE, 'init_rp20.npz')
+    np.savez_compressed(path, **out)
+    print('[init] wrote %s (%.1f KB) in %.1fs' % (path, os.path.getsize(path) / 1024., time.time() - t_start), flush=True)
+
+
 def copy_ref_data():
     """gzip copies of the reference tests' own DATA files (model_test/*.ref)."""
     dst = os.path.join(HERE, 'ref')
@@ -510,7 +543,7 @@ def copy_ref_data():
 
 
 if __name__ == '__main__':
-    names = sys.argv[1:] or (list(CONFIGS) + ['lyap', 'callables'])
+    names = sys.argv[1:] or (list(CONFIGS) + ['lyap', 'callables', 'init'])
     copy_ref_data()
     for nm in names:
         if nm == 'lyap':
@@ -520,5 +553,7 @@ if __name__ == '__main__':
             gen_lyapunov(nm[5:])
         elif nm == 'callables':
             gen_callables()
+        elif nm == 'init':
+            gen_initialize()
         else:
             gen(nm)

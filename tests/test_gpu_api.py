@@ -301,3 +301,37 @@ def test_dynamic_T_model_end_to_end():
     assert rel_err(tr, g['cls_tgls_traj']) < 1e-10 and rel_err(fm, g['cls_tgls_fm']) < 1e-10
     tinteg.terminate()
     f.operands.release()
+
+
+def test_initialize_vs_the_reference_classes():
+    """`initialize` against the reference's own (tests/golden/init_rp20.npz, make_golden.py gen_initialize): the states left in
+    `ic` and where np.random stands afterwards.  `num_threads >= number_of_trajectories` is the fast way to spin up a large
+    ensemble here -- ONE launch for all members -- and is exactly the reference's behaviour for that setting; fewer workers than
+    members reproduce the reference's batch-by-batch growth (as many dependent launches as it has batches)."""
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.integrators.integrator import RungeKuttaIntegrator
+    g = load_golden('rp20')
+    z = np.load(os.path.join(GOLDEN_DIR, 'init_rp20.npz'))
+    f, _ = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    integ = RungeKuttaIntegrator(num_threads=6)
+    integ.set_func(f)
+    np.random.seed(2023)
+    integ.initialize(3.0, 0.1, number_of_trajectories=6)
+    assert rel_err(integ.get_ic(), z['one_batch_ic']) < 1e-11
+    assert np.array_equal(np.random.rand(3), z['one_batch_next_draw'])
+    integ = RungeKuttaIntegrator(num_threads=2)
+    integ.set_func(f)
+    np.random.seed(2024)
+    integ.initialize(3.0, 0.1, pert_size=0.01, reconvergence_time=1.0, number_of_trajectories=5)
+    assert rel_err(integ.get_ic(), z['batched_ic']) < 1e-11
+    assert np.array_equal(np.random.rand(3), z['batched_next_draw'])
+    np.random.seed(2025)
+    integ.initialize(2.0, 0.1, number_of_trajectories=2, forward=False)
+    assert rel_err(integ.get_ic(), z['backward_ic']) < 1e-11
+    # the one-batch spin-up of a large ensemble is one stepper launch per call
+    big = RungeKuttaIntegrator(num_threads=20000)
+    big.set_func(f)
+    np.random.seed(1)
+    big.initialize(1.0, 0.1, number_of_trajectories=20000)
+    assert big.get_ic().shape == (20000, g.ndim) and np.isfinite(big.get_ic()).all()
+    f.operands.release()
