@@ -47,9 +47,8 @@ std::string coef_fma(const std::string &acc, double c, const std::string &factor
 
 // Replace the @K<value>@ placeholders of one stage's text by sequential table references.
 //
-// group == 0: plain `kt[n]` references; the compiler places the scalar loads (it merges them into
-//   s_load_dwordx16 and issues each ~8 instructions ahead of its first use).
-// group == 16: explicit software pipeline.  SMEM returns out of order, so every wait is lgkmcnt(0) and also
+// Explicit software pipeline (left to itself the compiler merges the scalar loads into s_load_dwordx16 and issues each ~8
+//   instructions ahead of its first use: 5.75 instead of 4.6 ms for the stepper).  SMEM returns out of order, so every wait is lgkmcnt(0) and also
 //   waits for whatever was issued last; a lone wavefront then stalls (L - 45) cycles per 8 coefficients (PMC:
 //   21 % of the stepper's cycles).  Here the coefficients are consumed in groups of 16 held in two 8-double vectors
 //   `kq<2g>`, `kq<2g+1>`; the loads of group g+1 are issued right AFTER the first statement that uses group g
@@ -58,7 +57,7 @@ std::string coef_fma(const std::string &acc, double c, const std::string &factor
 // not fetched again, the statement refers to that entry (negated if the sign differs).  MAOOAM 6x6: cos / sin partner
 // modes and the psi / theta copies of the advection terms repeat their coefficients in neighbouring statements, 21 657
 // fetches per workgroup-stage become ~15 000 -- and the coefficient stream is what bounds that kernel.
-std::string resolve_ktab(const std::string &text, KTable &t, int group, bool dedupe = false)
+std::string resolve_ktab(const std::string &text, KTable &t, bool dedupe = false)
 {
     std::string out;
     t.cursor = 0;
@@ -67,21 +66,6 @@ std::string resolve_ktab(const std::string &text, KTable &t, int group, bool ded
         *ok = (t.vals[t.cursor] == v);        // always true: every stage emits the same sequence
         return t.cursor++;
     };
-    if (group != 16) {
-        size_t pos = 0;
-        while (true) {
-            size_t a = text.find("@K", pos);
-            if (a == std::string::npos) { out.append(text, pos, std::string::npos); break; }
-            size_t b = text.find('@', a + 2);
-            out.append(text, pos, a - pos);
-            const double v = std::strtod(text.substr(a + 2, b - a - 2).c_str(), nullptr);
-            bool ok;
-            const size_t n = next_ref(v, &ok);
-            out += ok ? "kt[" + std::to_string(n) + "]" : hexlit(v);
-            pos = b + 1;
-        }
-        return out;
-    }
     // count the coefficients of this stage first (number of 8-double blocks that exist)
     size_t total = 0;
     for (size_t p = text.find("@K"); p != std::string::npos; p = text.find("@K", text.find('@', p + 2) + 1)) ++total;
@@ -233,13 +217,9 @@ void emit_group(std::ostringstream &o, const char *indent, const std::string &g,
 
 // Group items by |coefficient| (exact equality of the doubles), keeping first-appearance order.
 template <class T>
-std::vector<std::vector<T>> group_by_abs(const std::vector<T> &items, bool enable)
+std::vector<std::vector<T>> group_by_abs(const std::vector<T> &items)
 {
     std::vector<std::vector<T>> groups;
-    if (!enable) {
-        for (const T &t : items) groups.push_back({t});
-        return groups;
-    }
     std::map<double, size_t> where;
     for (const T &t : items) {
         double a = std::fabs(t.c);
@@ -257,7 +237,7 @@ void emit_tend_row(std::ostringstream &o, const char *indent, const Row &row, co
     Acc acc(o, res, indent);
     if (row.has_c0 && row.c0 != 0.0) acc.set_const(row.c0);
     for (const Lin &l : row.lin) acc.add(lit(l.c), X(l.k));
-    auto groups = group_by_abs(row.bil, opt.group_coeff);
+    auto groups = group_by_abs(row.bil);
     int gi = 0;
     for (auto &g : groups) {
         if (g.size() == 1) {
@@ -300,7 +280,7 @@ void emit_wx_row(std::ostringstream &o, const char *indent, const std::vector<WX
     std::vector<WX> lin, bil;
     for (const WX &a : items) (a.x == 0 ? lin : bil).push_back(a);
     for (const WX &a : lin) acc.add(lit(a.c), W(a.w));
-    auto groups = group_by_abs(bil, opt.group_coeff);
+    auto groups = group_by_abs(bil);
     int gi = 0;
     for (auto &g : groups) {
         if (g.size() == 1) {
@@ -570,10 +550,8 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             o << "                }\n            }\n";
         }
         emit_derived(o, "            ", ndim, der, names(in));
-        if (opt.const_table) {
-            g_ktab = &table;
+        g_ktab = &table;
             o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
-        }
         std::ostringstream so;
         for (int i = 1; i <= ndim; ++i) {
             const std::string rn = "r" + std::to_string(i);
@@ -588,7 +566,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
             else if (last && S > 1) so << "            y" << i << " = qgs_fma3(hb, " << rn << ", acc" << i << ");\n";
             else so << "            acc" << i << " = __builtin_fma(hb, " << rn << ", " << (st == 0 ? "y" : "acc") << i << ");\n";
         }
-        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
+        o << resolve_ktab(so.str(), table);
         g_ktab = nullptr;
         o << "        }\n";
     }
@@ -602,7 +580,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
     o << "        }\n    }\n}\n";
-    if (opt.const_table) emit_ktable(out, kname + "_kt", table);
+    emit_ktable(out, kname + "_kt", table);
     out << o.str();
 }
 
@@ -659,10 +637,8 @@ void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<R
         for (int d = 1; d <= ndim; ++d) o << "                sp[" << (d - 1) << " * ld] = " << in << d << ";\n";
         o << "            }\n";
         emit_derived(o, "            ", ndim, der, names(in));
-        if (opt.const_table) {
-            g_ktab = &table;
+        g_ktab = &table;
             o << "            kf64* kt = (kf64*)" << kname << "_kt; asm volatile(\"\" : \"+s\"(kt));\n";
-        }
         std::ostringstream so;
         for (int i = 1; i <= ndim; ++i) {
             const std::string rn = "r" + std::to_string(i);
@@ -680,7 +656,7 @@ void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<R
                 }
             }
         }
-        o << (opt.const_table ? resolve_ktab(so.str(), table, opt.ktab_group) : so.str());
+        o << resolve_ktab(so.str(), table);
         g_ktab = nullptr;
         o << "        }\n";
     }
@@ -692,7 +668,7 @@ void emit_rk_dense_kernel(std::ostringstream &out, int ndim, const std::vector<R
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
     o << "        }\n    }\n}\n";
-    if (opt.const_table) emit_ktable(out, kname + "_kt", table);
+    emit_ktable(out, kname + "_kt", table);
     out << o.str();
 }
 
@@ -707,7 +683,7 @@ std::vector<int> partition_rows(int ndim, const std::vector<Row> &rows, int R, c
     std::vector<std::pair<int64_t, int>> cost;
     for (int i = 1; i <= ndim; ++i) {
         int64_t c = 2 + (int64_t)rows[i].lin.size();
-        for (auto &g : group_by_abs(rows[i].bil, opt.group_coeff)) c += (int64_t)g.size() + 1;
+        for (auto &g : group_by_abs(rows[i].bil)) c += (int64_t)g.size() + 1;
         cost.push_back({c, i});
     }
     std::sort(cost.begin(), cost.end(), [](const std::pair<int64_t, int> &a, const std::pair<int64_t, int> &b) {
@@ -749,7 +725,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
         o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
         for (int i : own) o << " " << i;
         o << "\n";
-        if (opt.const_table) g_ktab = &tables[w];
+        g_ktab = &tables[w];
         o << "        " << decl_list("y", ndim) << "\n";
         for (int d = 1; d <= ndim; ++d) o << "        y" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
         emit_settle_loads(o, "        ", "y", all_rows(ndim));
@@ -776,9 +752,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
             if (!last) o << "                const f64 ha = dt * ta" << st << ";\n";
             o << "                const int pb = (par0 + " << st << ") & 1;\n";
             emit_derived(o, "                ", ndim, der, names(in));      // unused ones are dead code in this wavefront's branch
-            if (opt.const_table) {
-                o << "                kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
-            }
+            o << "                kf64* kt = (kf64*)" << kname << "_kt" << w << "; asm volatile(\"\" : \"+s\"(kt));\n";
             {
                 std::ostringstream so;
                 const int W = std::max(1, opt.interleave);
@@ -800,7 +774,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
                     }
                     so << interleave(lists);
                 }
-                o << (opt.const_table ? resolve_ktab(so.str(), tables[w], opt.ktab_group) : so.str());
+                o << resolve_ktab(so.str(), tables[w]);
             }
             o << "                __syncthreads();\n";
             if (!last) {
@@ -821,8 +795,7 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
         g_ktab = nullptr;
     }
     o << "}\n";
-    if (opt.const_table)
-        for (int w = 0; w < R; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    for (int w = 0; w < R; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
 }
 
@@ -964,10 +937,8 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
         emit_derived(o, "            ", ndim, der, names("x"));
         for (int pass = 0; pass < 2; ++pass) {
             o << "            if (" << (pass == 0 ? "!adjoint" : "adjoint") << ") {\n";
-            if (opt.const_table) {
-                g_ktab = &tables[pass];
-                o << "                kf64* kt = (kf64*)" << kname << "_kt" << pass << "; asm volatile(\"\" : \"+s\"(kt));\n";
-            }
+            g_ktab = &tables[pass];
+            o << "                kf64* kt = (kf64*)" << kname << "_kt" << pass << "; asm volatile(\"\" : \"+s\"(kt));\n";
             std::ostringstream so_all;
             std::vector<std::vector<std::string>> row_lines;
             for (int i = 1; i <= ndim; ++i) {                 // brace-less rows: the coefficient group vectors stay in scope
@@ -1005,7 +976,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
                 }
             }
             const std::ostringstream &so = so_all;
-            o << (opt.const_table ? resolve_ktab(so.str(), tables[pass], opt.ktab_group, opt.tgl_coeff_dedupe) : so.str());
+            o << resolve_ktab(so.str(), tables[pass], opt.tgl_coeff_dedupe);
             g_ktab = nullptr;
             o << "            }\n";
         }
@@ -1027,8 +998,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * L] = v" << d << ";\n";
     o << "        }\n    }\n}\n";
-    if (opt.const_table)
-        for (int pass = 0; pass < 2; ++pass) emit_ktable(out, kname + "_kt" + std::to_string(pass), tables[pass]);
+    for (int pass = 0; pass < 2; ++pass) emit_ktable(out, kname + "_kt" + std::to_string(pass), tables[pass]);
     out << o.str();
 }
 
@@ -1452,7 +1422,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                             for (int d : own) h << I4 << "const f64 yg" << d << " = ywp[" << slot[d] * 64 << "];\n";
 
                         }, stats);
-        o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
+        o << resolve_ktab(so.str(), tables[w], opt.lds_coeff_dedupe);
         g_ktab = nullptr;
         if (tend_kernel) {
             o << I4 << "if (tend_only) {          // uniform: every wavefront leaves here, nobody is left waiting at a barrier\n"
@@ -1612,7 +1582,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = vwp[" << slot[d] * 64 << "];\n";
                         }, stats);
-        o << resolve_ktab(so.str(), tables[w], opt.ktab_group, opt.lds_coeff_dedupe);
+        o << resolve_ktab(so.str(), tables[w], opt.lds_coeff_dedupe);
         g_ktab = nullptr;
         for (int d : own) {
             o << I4 << "acc" << d << " = __builtin_fma(hb, k" << d << ", acc" << d << ");\n";
@@ -1918,7 +1888,7 @@ int64_t count_tendency_flops_instr(int ndim, const std::vector<Term> &tensor, co
     for (int i = 1; i <= ndim; ++i) {
         const Row &r = rows[i];
         n += (int64_t)r.lin.size();
-        auto groups = group_by_abs(r.bil, opt.group_coeff);
+        auto groups = group_by_abs(r.bil);
         for (auto &g : groups) n += (int64_t)g.size() + 1;
     }
     return n;

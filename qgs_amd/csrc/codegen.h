@@ -20,12 +20,12 @@ struct Term {          // one COO entry (i, j, k, value); index 0 is the constan
     double v;
 };
 
+// Always on (the alternatives were measured slower and removed in round 3): equal-|coefficient| bilinear terms of a row are
+// factored, c * (m1 +- m2 ...); coefficients come from a __constant__ table walked by s_load_dwordx16 in a software pipeline
+// of 16-coefficient groups (literal s_mov pairs: 7.4 instead of 4.6 ms for the stepper; compiler-placed loads: 5.75 ms).
 struct CodegenOptions {
-    bool group_coeff = true;   // factor equal-|coefficient| bilinear terms of a row: c*(m1 +- m2 ...)
     int min_waves_per_simd = 1;
     int interleave = 2;        // rows whose statements are interleaved in the row-split stepper (ILP)
-    int ktab_group = 16;       // 16: software-pipelined coefficient fetch in groups of 16; 0: compiler-placed loads
-    bool const_table = true;   // coefficients from a __constant__ table (s_load) instead of literals (s_mov)
     int tgl_interleave = 2;    // tangent kernel: rows whose statements are emitted round-robin (config 4, 100 calls: 0.949 -> 0.933 ms with park_v)
     bool tgl_park_v = true;    // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
     bool tgl_pair = true;      // stage record in mode pairs between qgs_spec_rkstagesp_s<S> and qgs_spec_tglp_s<S> (128-bit accesses)

@@ -7,7 +7,7 @@
 #include <cstring>
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s ndim tensor.txt [nogroup] [waves=N] [stages=4] [all]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s ndim tensor.txt [waves=N] [stages=4] [all]\n", argv[0]); return 2; }
     int ndim = std::atoi(argv[1]);
     std::vector<qgs::Term> T, J;
     FILE *f = std::fopen(argv[2], "r");
@@ -34,12 +34,9 @@ int main(int argc, char **argv)
     bool all = false;
     for (int a = 3; a < argc; ++a) {
         if (!std::strcmp(argv[a], "all")) all = true;
-        if (!std::strcmp(argv[a], "nogroup")) opt.group_coeff = false;
         if (!std::strncmp(argv[a], "waves=", 6)) opt.min_waves_per_simd = std::atoi(argv[a] + 6);
         if (!std::strncmp(argv[a], "stages=", 7)) stages = {std::atoi(argv[a] + 7)};
         if (!std::strncmp(argv[a], "split=", 6)) opt.row_split = std::atoi(argv[a] + 6);
-        if (!std::strcmp(argv[a], "ktab")) opt.const_table = true;
-        if (!std::strncmp(argv[a], "kgroup=", 7)) opt.ktab_group = std::atoi(argv[a] + 7);
         if (!std::strncmp(argv[a], "ilv=", 4)) opt.interleave = std::atoi(argv[a] + 4);
     }
     if (rank == 5) opt.row_split = 1;

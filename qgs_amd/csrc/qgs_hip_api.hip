@@ -111,17 +111,18 @@ std::string target_arch(int device)
 std::vector<std::string> default_extra_flags() { return {}; }
 
 // source -> code object (hsaco), through the on-disk cache
-// developer knob: extra compiler flags, e.g. QGS_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp"
+// (developer build: extra compiler flags, e.g. QGS_HIP_EXTRA_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp")
 std::vector<std::string> extra_flags()
 {
-    std::vector<std::string> extra;
+#ifdef QGS_HIP_DEV_KNOBS
     if (const char *e = std::getenv("QGS_HIP_EXTRA_FLAGS")) {
+        std::vector<std::string> extra;
         std::istringstream is(e);
         for (std::string tok; is >> tok;) extra.push_back(tok);
-    } else {
-        extra = default_extra_flags();
+        return extra;
     }
-    return extra;
+#endif
+    return default_extra_flags();
 }
 
 // Flags a generated source asks for itself: a line "// qgs-compile-flags: <flags>" (codegen.cpp; the general-tableau
@@ -319,8 +320,7 @@ int compile_in_process(const std::string &src, const std::string &arch, const st
 
 std::string scratch_dir()
 {
-    for (const char *v : {"QGS_HIP_TMPDIR", "TMPDIR"})
-        if (const char *e = std::getenv(v)) if (*e && access(e, W_OK) == 0) return e;
+    if (const char *e = std::getenv("TMPDIR")) if (*e && access(e, W_OK) == 0) return e;
     return "/tmp";
 }
 
@@ -381,10 +381,12 @@ int compile_source(const std::string &src, const std::string &arch, std::vector<
     CacheLock lock(path);
     if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }      // somebody else compiled it meanwhile
     if (from_cache) *from_cache = false;
-    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // developer knob: keep the generated source
+#ifdef QGS_HIP_DEV_KNOBS
+    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // keep the generated source
         std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
         f << src;
     }
+#endif
     if (cc.helper) {
         // source and object travel through private temp files under $TMPDIR, not through the cache directory
         std::string why;
@@ -502,11 +504,13 @@ struct LaunchTuning {
     void read_env()
     {
         if (const char *e = std::getenv("QGS_HIP_WAVE_MAX_TRAJ")) wave_max_traj = std::atoll(e);
+#ifdef QGS_HIP_DEV_KNOBS
         if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MIN_PAIRS")) lds_tgl_min_pairs = std::atoll(e);
+        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) rk_spread_rec = (*e == '1');
+#endif
         if (const char *e = std::getenv("QGS_HIP_LDS")) lds_force = (*e == '1') ? 1 : 0;
         if (const char *e = std::getenv("QGS_HIP_GENERIC")) generic_simple = !std::strcmp(e, "simple");
         if (const char *e = std::getenv("QGS_HIP_RK_VARIANT")) rk_variant = !std::strcmp(e, "plain") ? 1 : (!std::strcmp(e, "split") ? 2 : 0);
-        if (const char *e = std::getenv("QGS_HIP_RK_SPREAD_REC")) rk_spread_rec = (*e == '1');
         if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) tgls_chunk = std::max<int64_t>(1, std::atoll(e));
         if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) tgl_share_min_bytes = (size_t)std::atoll(e) << 20;
         if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_plain = !std::strcmp(e, "plain");
@@ -620,7 +624,9 @@ void classify_model(qgs_model *m)
     m->spec_possible = (m->ndim <= QGS_SPEC_MAX_NDIM) && nt <= QGS_SPEC_MAX_DERIVED;
     m->spec_jac_possible = m->spec_possible && nj <= QGS_SPEC_MAX_DERIVED;
     m->prefer_lds = m->spec_possible && nt > QGS_PREFER_LDS_DERIVED;
+#ifdef QGS_HIP_DEV_KNOBS
     if (const char *e = std::getenv("QGS_HIP_PREFER_LDS")) m->prefer_lds = m->spec_possible && (*e == '1');
+#endif
     const bool fits = (ndim + nt) * 512 <= (size_t)QGS_LDS_STATE_BYTES && m->T.size() <= 200000;
     m->lds_spec_possible = fits && (!m->spec_possible || m->prefer_lds);
     if (const char *e = std::getenv("QGS_HIP_LDS_TGL_MEMBERS")) m->cg.lds_tgl_members = (std::atoi(e) == 8) ? 8 : 16;
@@ -665,8 +671,7 @@ int upload_tiled(qgs_model *m, const std::vector<Entry> &Tr)
     std::vector<double> c;
     // long rows (MAOOAM 6x6: ~120 terms) take 16 terms per loop trip to amortise the scalar-load latency
     const size_t pad = (Tr.size() >= (size_t)32 * ndim) ? 16 : 4;
-    if (const char *e = std::getenv("QGS_HIP_TILED_TPI")) m->t_terms_per_trip = (std::atoi(e) == 16) ? 16 : 4;
-    else m->t_terms_per_trip = (int)pad;
+    m->t_terms_per_trip = (int)pad;
     for (int i = 0; i <= ndim; ++i) {
         row_term[i] = (int32_t)c.size();
         for (const Entry *t : by_row[i]) {
@@ -889,13 +894,14 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     return 0;
 }
 
-// Generator knobs (the defaults are what ships)
+// Generator knobs.  The shipped defaults are what was measured fastest.  A normal build reads one of them (exercised by the
+// parity tests); the experiment knobs of DESIGN.md section 3 exist only in a developer build (`make DEV=1`,
+// -DQGS_HIP_DEV_KNOBS), where their variants can be re-measured.
 void apply_env_options(qgs::CodegenOptions &cg)
 {
-    if (const char *e = std::getenv("QGS_HIP_NO_GROUP")) if (*e == '1') cg.group_coeff = false;
+    if (const char *e = std::getenv("QGS_HIP_TGL_PAIR")) cg.tgl_pair = (*e == '1');
+#ifdef QGS_HIP_DEV_KNOBS
     if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
-    if (const char *e = std::getenv("QGS_HIP_KTAB")) cg.const_table = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) cg.ktab_group = (std::atoi(e) == 16) ? 16 : 0;
     if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_X")) cg.tgl_share_x = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
@@ -905,8 +911,10 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_LDS_DEDUPE")) cg.lds_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_DEDUPE")) cg.tgl_coeff_dedupe = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_PARK_V")) cg.tgl_park_v = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_TGL_PAIR")) cg.tgl_pair = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_TGL_INTERLEAVE")) cg.tgl_interleave = std::max(1, std::atoi(e));
+#else
+    (void)cg;
+#endif
 }
 
 // explicit scheme: a[i][j] == 0 for j >= i
@@ -1632,8 +1640,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         HIPCHK(hipGetLastError());
         return 0;
     }
-    static const bool lds_only = [] { const char *e = std::getenv("QGS_HIP_QR"); return e && !std::strcmp(e, "lds"); }();
-    if (!lds_only && m->kernel_kind != 1 && n_rows <= 64) {
+    if (m->kernel_kind != 1 && n_rows <= 64) {
         // shape-specialised kernel, columns in registers (codegen generate_qr_kernel), compiled once per shape
         const std::string fname = "qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols);
         hipFunction_t f = nullptr;

@@ -32,8 +32,11 @@ class LyapunovsEstimator(object):
     ``num_threads, b, c, a, n_dim, n_vec, n_traj, n_records, ic, func, func_jac`` as in the reference.
     """
 
-    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None):
+    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, device=None):
         self.num_threads = multiprocessing.cpu_count() if num_threads is None else num_threads
+        # GPU(s): an index, a list of indices or 'all' (members sharded over them, one host thread per shard), None = the
+        # device the tendencies were created for (as for the integrator classes, qgs_amd/integrators/integrator.py)
+        self.device = device
         self.b, self.c, self.a = _fn.resolve_tableau(b, c, a)
         self.ic = None
         self._time = None
@@ -59,8 +62,8 @@ class LyapunovsEstimator(object):
     def start(self):
         self.terminate()
         if self.func is not None:
-            self._model = _fn.hip_model_of(self.func)
-            if self.func_jac is not None and _fn.hip_model_of(self.func_jac, 'fjac') is not self._model:
+            self._model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device))
+            if self.func_jac is not None and _fn.hip_model_of(self.func_jac, 'fjac', device=_fn.resolve_device(self.device)) is not self._model:
                 raise TypeError('f and fjac must come from the same create_tendencies() call')
 
     def set_bca(self, b=None, c=None, a=None, ic_init=True):
@@ -89,7 +92,6 @@ class LyapunovsEstimator(object):
         if self.func is None or self.func_jac is None:
             print('No function to integrate defined!')
             return 0
-        import torch
         if self._model is None:
             self.start()
         self.ic = np.zeros(_fn.dimension_of(self.func)) if ic is None else ic
@@ -110,24 +112,58 @@ class LyapunovsEstimator(object):
             tot = rec_grid[::write_steps]
             self.n_records = len(tot) + (1 if tot[-1] != rec_grid[-1] else 0)
 
-        m, ndim, nv, n = self._model, self.n_dim, self.n_vec, self.n_traj
+        # random start bases: the matrices are drawn like the reference's (one draw per trajectory, in order:
+        # `np.random.random((ndim, nv))` consumes the generator exactly as n such calls in a row do) -- for the WHOLE ensemble
+        # before it is split over devices
+        a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))
+        model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
+        shards = getattr(model, 'models', None)
+        if shards is None:
+            self._recorded_traj, self._recorded_vec, self._recorded_exp = self._compute_shard(model, self.ic, a0, mdt)
+            return
+        # several GPUs: contiguous member shards, one host thread each (the work of a shard is a chain of kernel launches)
+        import threading
+        parts, errors = [None] * len(shards), []
+
+        def run(i):
+            try:
+                a, cnt = model.shard(self.n_traj, i)
+                if cnt > 0:
+                    parts[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt)
+            except Exception as e:                       # re-raised on the calling thread
+                errors.append(e)
+        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shards))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        parts = [q for q in parts if q is not None]
+        self._recorded_traj, self._recorded_vec, self._recorded_exp = (np.concatenate([q[k] for q in parts], axis=0) for k in range(3))
+
+    def _compute_shard(self, m, ic, a0, mdt):
+        """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
+        returns (traj, vectors, exponents) in the reference's layouts."""
+        import torch
+        forward, adjoint, write_steps = self._forward == 1, self._adjoint, self.write_steps
+        ndim, nv, n = self.n_dim, self.n_vec, ic.shape[0]
         ld = (n + 63) // 64 * 64
         dev = torch.device('cuda', m.device)
         f64 = torch.float64
+        torch.cuda.set_device(dev)                      # per thread: allocations and the current stream of THIS shard's GPU
         stream = torch.cuda.current_stream(dev).cuda_stream
 
         # base trajectory, every step recorded: R[step][mode][member]            (lyapunov.py:558 / :474)
         full_grid = np.concatenate((self._pretime[:-1], self._time))
         ic_modes = torch.zeros((ndim, ld), dtype=f64, device=dev)
-        ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(self.ic.T)).to(dev)
+        ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
         base = torch.empty((len(full_grid), ndim, ld), dtype=f64, device=dev)
         m.rk_integrate_device(n, ld, ic_modes.data_ptr(), full_grid, 1, 1, self.b, self.c, self.a, base.data_ptr(), stream)
         n_pre = len(self._pretime)
 
-        # random orthonormal start basis: the matrices are drawn like the reference's (one draw per trajectory, in order:
-        # `np.random.random((ndim, nv))` consumes the generator exactly as n such calls in a row do), their QR is the same
-        # batched Householder kernel as in the loop (np.linalg.qr on the host took 30 us per member: 0.5 s at 16 384)
-        a0 = np.random.random((n, ndim, nv))
+        # orthonormal start basis: QR of the drawn matrices with the same batched Householder kernel as in the loop
+        # (np.linalg.qr on the host took 30 us per member: 0.5 s at 16 384)
         q = torch.zeros((ndim, nv, ld), dtype=f64, device=dev)
         q[:, :, :n] = torch.from_numpy(np.ascontiguousarray(a0.transpose(1, 2, 0))).to(dev)
         # diag(R) of that first QR: with an empty spin-up the reference's `r = qr[1]` is still this one
@@ -213,11 +249,10 @@ class LyapunovsEstimator(object):
         out_vec = torch.empty((n, ndim, nv, self.n_records), dtype=f64, device=dev)
         m.unpack_records(n, ld, ndim, self.n_records, rec_traj.data_ptr(), out_traj.data_ptr(), stream)
         m.unpack_records(n, ld, ndim * nv, self.n_records, rec_vec.data_ptr(), out_vec.data_ptr(), stream)
-        self._recorded_traj = out_traj.cpu().numpy()
-        self._recorded_vec = out_vec.cpu().numpy()
-        self._recorded_exp = np.zeros((n, nv, self.n_records))
+        recorded_exp = np.zeros((n, nv, self.n_records))
         for iw, rd, d in exp_sources:
-            self._recorded_exp[:, :, iw] = (np.log(np.abs(rd[:, :n].cpu().numpy())) / d).T
+            recorded_exp[:, :, iw] = (np.log(np.abs(rd[:, :n].cpu().numpy())) / d).T
+        return out_traj.cpu().numpy(), out_vec.cpu().numpy(), recorded_exp
 
     def get_lyapunovs(self):
         """``(time, traj, exponents, vectors)``: traj (n_traj, n_dim, n_records), exponents (n_traj, n_vec, n_records),

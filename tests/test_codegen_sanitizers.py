@@ -36,7 +36,7 @@ def test_generator_is_clean_under_asan_ubsan(dump_binary, tmp_path, name):
     txt = str(tmp_path / (name + '.txt'))
     _tensor_text(g, txt)
     env = dict(os.environ, ASAN_OPTIONS='detect_leaks=1:abort_on_error=0', UBSAN_OPTIONS='print_stacktrace=1')
-    for extra in (['all'], ['stages=2', 'nogroup']):
+    for extra in (['all'], ['stages=2', 'split=2']):
         p = subprocess.run([dump_binary, str(g.ndim), txt] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, env=env)
         err = p.stderr.decode()
         assert p.returncode == 0, err[-3000:]

@@ -38,17 +38,18 @@ def test_batched_qr_matches_lapack():
     f.operands.release()
 
 
-@pytest.mark.parametrize('name', ['rp20', 'm36', 'd38'])
-def test_lyapunov_estimator_vs_reference(name):
+@pytest.mark.parametrize('name,device', [('rp20', None), ('m36', None), ('d38', None), ('rp20', [0, 0]), ('m36', 'all')])
+def test_lyapunov_estimator_vs_reference(name, device):
     """d38: the dynamic-T model (rank-5 tensor); its goldens come from the reference's loops on the reference's own tensor,
-    which differs from ours by its quadrature error (2e-14), well inside the tolerances below."""
+    which differs from ours by its quadrature error (2e-14), well inside the tolerances below.  device=[0, 0] / 'all': the
+    members sharded over a device list (two shards on the one GPU of the test box), same goldens, same random draws."""
     from model_configs import MAKERS, MAKERS_RANK5
     from qgs_amd.functions.tendencies import create_tendencies
     from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
     g = np.load(os.path.join(GOLDEN_DIR, 'lyap_%s.npz' % name))
     meta = json.loads(bytes(g['meta_json']).decode())
     f, Df = create_tendencies(dict(MAKERS, **MAKERS_RANK5)[name]())
-    est = LyapunovsEstimator(num_threads=1)
+    est = LyapunovsEstimator(num_threads=1, device=device)
     est.set_func(f, Df)
     for cs in meta['cases']:
         np.random.seed(cs['seed'])

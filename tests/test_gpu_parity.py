@@ -437,13 +437,14 @@ def test_linearity_of_tangent_model(models):
 
 
 @pytest.mark.parametrize('env', [{'QGS_HIP_RK_VARIANT': 'plain'}, {'QGS_HIP_RK_VARIANT': 'split'},
-                                 {'QGS_HIP_KTAB': '0', 'QGS_HIP_INTERLEAVE': '1'}, {'QGS_HIP_ROW_SPLIT': '2'}, {'QGS_HIP_KTAB_GROUP': '0'},
-                                 {'QGS_HIP_NO_GROUP': '1'}, {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'},
+                                 {'QGS_HIP_GENERIC': 'simple'}, {'QGS_HIP_WAVE_MAX_TRAJ': '0'},
                                  {'QGS_HIP_TGL_VARIANT': 'plain', 'QGS_HIP_WAVE_MAX_TRAJ': '0'},
-                                 {'QGS_HIP_TGL_SHARE_X': '5', 'QGS_HIP_TGL_SHARE_MIN_MB': '0', 'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
+                                 {'QGS_HIP_TGL_PAIR': '0', 'QGS_HIP_WAVE_MAX_TRAJ': '0'},
+                                 {'QGS_HIP_TGL_SHARE_MIN_MB': '0', 'QGS_HIP_WAVE_MAX_TRAJ': '0'}])
 def test_kernel_variants_agree_with_oracle(monkeypatch, env):
-    """Every code-generation / kernel-selection variant (plain one-wave stepper, row split 2 and 3, literal
-    coefficients, ungrouped terms, simple generic kernel) against the oracle on the same inputs."""
+    """Every kernel-selection variant a normal build offers (plain / row-split stepper, simple generic kernel, lane kernels
+    instead of the wavefront-per-trajectory ones, plain / paired / shared stage record of the tangent model) against the
+    oracle on the same inputs.  (The generator's experiment knobs exist in developer builds only: `make DEV=1`.)"""
     from qgs_amd import _lib
     from oracle.oracle import OracleModel
     for k, v in env.items():

@@ -25,10 +25,8 @@ int main(int argc, char **argv)
     qgs::CodegenOptions opt;
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) opt.lds_waves = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) opt.lds_cap = std::atoi(e);
-    if (const char *e = std::getenv("QGS_HIP_KTAB")) opt.const_table = (*e == '1');
     if (const char *e = std::getenv("QGS_HIP_LDS_YLOAD")) opt.lds_yload_ahead = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) opt.lds_group = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_KTAB_GROUP")) opt.ktab_group = std::atoi(e);
     const int S = argc > 3 ? std::atoi(argv[3]) : 4;
     qgs::Kernel k = qgs::Kernel::Tend;
     if (!std::strcmp(argv[2], "rk")) k = qgs::Kernel::Rk;
