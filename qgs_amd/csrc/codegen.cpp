@@ -96,7 +96,9 @@ std::string resolve_ktab(const std::string &text, KTable &t, bool dedupe = false
             size_t n = 0;
             bool reused = false;
             if (dedupe && t.cursor > 0) {
-                const size_t g0 = (t.cursor - 1) / 16 * 16;                       // first entry of the group being consumed
+                // first entry of the group being consumed.  (Searching the group before it as well -- its registers would have to
+                // stay live -- finds 7 % more repeats at ndim 228 and costs more in SGPR spills: 52.2 instead of 50.6 ms.)
+                const size_t g0 = (t.cursor - 1) / 16 * 16;
                 for (size_t q = t.cursor; q-- > g0;)
                     if (std::fabs(t.vals[q]) == std::fabs(v) && v != 0.0) { n = q; reused = true; break; }
             }
@@ -556,6 +558,9 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
         for (int i = 1; i <= ndim; ++i) {
             const std::string rn = "r" + std::to_string(i);
             emit_tend_row(so, "            ", rows[i], rn, names(in), opt, st * 1000 + i);
+            // (Record rows in mode pairs, one 128-bit store per pair as in the stage record of rkstagesp: 18 instead of 36 vector-
+            // memory instructions per step, but 36 more VALU instructions to bring the pairs into aligned registers; measured
+            // 0.599-0.630 against 0.609-0.624 ms per 100 steps: nothing, profiles/r03_record_path.txt.)
             if (spread_rec && (i - 1) % S == st) so << "            qgs_store_row(prow + " << (i - 1) << " * ld, lane8, y" << i << ");\n";
             // Whenever the addend stays live (y_i in every stage but the last) the sum is formed by an explicit three-address
             // v_fma_f64 (qgs_fma3): the compiler otherwise picks the two-address v_fmac_f64 plus a v_mov_b64 copy of the
@@ -1180,7 +1185,7 @@ std::vector<std::vector<int>> lds_partition(int n_rows, int n_nodes, const RowTe
 // `hook_phase` (== phases.size(): behind the last one).
 void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<Phase> &phases, const NodeFn &node,
                      const std::vector<std::string> &lane_vars, const std::string &lds_ptr, bool group, int hook_phase,
-                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st)
+                     const std::function<void(std::ostringstream &)> &hook, LdsStats &st, int order = 0)
 {
     int ph_id = 0, prod_id = 0;
     for (const Phase &ph : phases) {
@@ -1216,8 +1221,20 @@ void emit_lds_phases(std::ostringstream &so, const char *ind, const std::vector<
             if (t.j == 0 || !group) singles.push_back(t);
             else pieces[{t.row, std::fabs(t.c)}].push_back(t);
         }
-        for (auto &kv : pieces) {
-            const std::vector<PTerm> &g = kv.second;
+        // Order of the grouped statements inside a phase: by (row, |c|) (order 0), or by (|c|, row) (order 1).  Equal magnitudes
+        // of different rows then sit next to each other -- the cos / sin partner rows of MAOOAM repeat their coefficients (219
+        // of the 222 of rows 2 and 3 of the 6x6 model coincide) -- where the coefficient de-duplication of resolve_ktab (a
+        // window of 16 entries) finds them: 15 175 instead of 15 472 table entries per workgroup-stage, 51.8 instead of 52.7 ms
+        // (profiles/r03_lds228.md; sorting ALL statements of a phase by |c| gets 14 552 entries but separates the uses of the
+        // shared products: 644 B of scratch, 65 ms -- not kept).
+        std::vector<const std::vector<PTerm> *> piece_list;
+        for (auto &kv : pieces) piece_list.push_back(&kv.second);
+        if (order >= 1)
+            std::stable_sort(piece_list.begin(), piece_list.end(), [](const std::vector<PTerm> *x, const std::vector<PTerm> *y) {
+                return std::fabs((*x)[0].c) < std::fabs((*y)[0].c);
+            });
+        for (const std::vector<PTerm> *gp : piece_list) {
+            const std::vector<PTerm> &g = *gp;
             if (g.size() == 1) { singles.push_back(g[0]); continue; }
             const std::string gname = "g" + std::to_string(prod_id++);
             const bool ref_neg = std::signbit(g[0].c);
@@ -1421,7 +1438,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
                         [&](std::ostringstream &h) {
                             for (int d : own) h << I4 << "const f64 yg" << d << " = ywp[" << slot[d] * 64 << "];\n";
 
-                        }, stats);
+                        }, stats, opt.lds_order);
         o << resolve_ktab(so.str(), tables[w], opt.lds_coeff_dedupe);
         g_ktab = nullptr;
         if (tend_kernel) {
@@ -1464,6 +1481,11 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
     o << "}\n";
     out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
+    {
+        size_t entries = 0;
+        for (const KTable &t : tables) entries += t.vals.size();
+        out << "// statement order " << opt.lds_order << ": " << entries << " coefficient table entries after de-duplication\n";
+    }
     // general-tableau flavour: CodeGenPrepare takes 3.3 min on this kernel at ndim 228 and changes nothing in the result
     // (same registers, same scratch); qgs_hip_api.hip reads the line below and passes the flags to hiprtc
     if (dense) out << "// qgs-compile-flags: -mllvm -disable-cgp\n";

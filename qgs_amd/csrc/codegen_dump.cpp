@@ -38,6 +38,8 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "stages=", 7)) stages = {std::atoi(argv[a] + 7)};
         if (!std::strncmp(argv[a], "split=", 6)) opt.row_split = std::atoi(argv[a] + 6);
         if (!std::strncmp(argv[a], "ilv=", 4)) opt.interleave = std::atoi(argv[a] + 4);
+        if (!std::strncmp(argv[a], "ldsorder=", 9)) opt.lds_order = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "ldscap=", 7)) opt.lds_cap = std::atoi(argv[a] + 7);
     }
     if (rank == 5) opt.row_split = 1;
     std::fprintf(stderr, "ndim %d rank %d terms %zu jac terms %zu derived %zu / %zu tendency fp64 instr %lld\n", ndim, rank, T.size(),
