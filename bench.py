@@ -40,10 +40,9 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-# thread placement of the CPU-baseline leg (one thread per physical core): set before anything loads an OpenMP runtime --
-# PyTorch brings one, and a runtime reads these variables once, when it starts
-os.environ.setdefault('OMP_PLACES', 'cores')
-os.environ.setdefault('OMP_PROC_BIND', 'spread')
+# (No OMP_PLACES / OMP_PROC_BIND here: set before the first OpenMP runtime starts -- PyTorch brings one -- they bind the main
+# thread to one core, the process then sees 2 CPUs and the CPU-baseline leg runs on 2 threads (measured, round 3); set later
+# they are never read.  The baseline's threads are left to the scheduler; its thread count follows the container's CPU quota.)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
