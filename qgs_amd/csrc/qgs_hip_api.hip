@@ -1756,7 +1756,7 @@ static int tendencies_one(qgs_model *m, const double *x, double *dx)
     std::memcpy(m->h_pin + 1, x, sizeof(double) * nd);
     const unsigned long long seq = ++m->one_seq;
     qgs::launch_gen_tend_one(m->dT.view(), nd, m->d_pin + 1, m->d_pin + 1 + nd, m->d_one_counter, (unsigned long long *)m->d_pin, seq, st);
-    note_kernel(m, "gen_tend_one_kernel", nullptr);
+    if (m->last.name != "gen_tend_one_kernel") note_kernel(m, "gen_tend_one_kernel", nullptr);
     HIPCHK(hipGetLastError());
     if (one_state_wait(m, st, seq)) return -1;
     std::memcpy(dx, m->h_pin + 1 + nd, sizeof(double) * nd);
@@ -1773,7 +1773,7 @@ static int jacobian_one(qgs_model *m, const double *x, double *jac)
     const unsigned long long seq = ++m->one_seq;
     const qgs::OnePairs P{m->p_lut, m->p_ptr, m->p_idx, m->p_val, m->p_idx2};
     qgs::launch_gen_jac_one(P, nd, m->d_pin + 1, m->d_pin + 1 + nd, m->d_one_counter, (unsigned long long *)m->d_pin, seq, st);
-    note_kernel(m, "gen_jac_one_kernel", nullptr);
+    if (m->last.name != "gen_jac_one_kernel") note_kernel(m, "gen_jac_one_kernel", nullptr);
     HIPCHK(hipGetLastError());
     if (one_state_wait(m, st, seq)) return -1;
     std::memcpy(jac, m->h_pin + 1 + nd, sizeof(double) * nn);

@@ -452,3 +452,39 @@ def test_cache_miss_compiles_the_same_lds_stepper(tmp_path):
     assert info['name'] == 'qgs_spec_rklds16', info
     assert info['vgprs'] <= 128 and info['scratch_bytes'] <= 412, info
     assert 'FINITE 1' in out
+
+
+def test_cache_miss_compiles_the_batched_qr(tmp_path):
+    """The shape-specialised QR kernels of the Lyapunov estimator on an empty cache: compiled on first use (helper process),
+    published, correct (against np.linalg.qr), and found in the cache by the next process."""
+    import json
+    import subprocess
+    import sys
+    code = ("import os, sys, json, numpy as np, torch\n"
+            "sys.path.insert(0, %r)\n"
+            "from qgs_amd import _lib\n"
+            "m = _lib.HipModel(2, np.array([[1, 0, 1]], dtype=np.int32), np.array([1.0]))\n"
+            "rng = np.random.RandomState(0)\n"
+            "worst = 0.0\n"
+            "for rows, cols in ((36, 36), (20, 5)):\n"
+            "    a = rng.randn(3, rows, cols)\n"
+            "    d = torch.zeros((rows, cols, 64), dtype=torch.float64, device='cuda')\n"
+            "    d[:, :, :3] = torch.from_numpy(np.ascontiguousarray(a.transpose(1, 2, 0))).cuda()\n"
+            "    rd = torch.zeros((cols, 64), dtype=torch.float64, device='cuda')\n"
+            "    m.batched_qr_device(3, 64, rows, cols, d.data_ptr(), rd.data_ptr())\n"
+            "    torch.cuda.synchronize()\n"
+            "    assert m.last_kernel_info()['name'] == 'qgs_spec_qr_%%dx%%d' %% (rows, cols)\n"
+            "    q = d[:, :, :3].cpu().numpy().transpose(2, 0, 1)\n"
+            "    for i in range(3):\n"
+            "        worst = max(worst, float(np.abs(q[i] - np.linalg.qr(a[i])[0]).max()))\n"
+            "print('WORST %%.3e' %% worst)\n"
+            "print('FILES %%d' %% len([f for f in os.listdir(os.environ['QGS_HIP_CACHE_DIR']) if f.endswith('.hsaco')]))\n" % REPO)
+    counts = []
+    for _ in range(2):
+        p = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
+                           env=dict(os.environ, QGS_HIP_CACHE_DIR=str(tmp_path)))
+        assert p.returncode == 0, p.stderr.decode()[-3000:]
+        out = p.stdout.decode()
+        assert float([ln for ln in out.splitlines() if ln.startswith('WORST ')][0][6:]) < 1e-13
+        counts.append(int([ln for ln in out.splitlines() if ln.startswith('FILES ')][0][6:]))
+    assert counts == [2, 2], counts
