@@ -70,6 +70,39 @@ def test_windowed_record_equals_unwindowed(monkeypatch, d2h, kind):
     m.close()
 
 
+@pytest.mark.parametrize('case', ['rksplit4', 'dense_tableau', 'rank5', 'heun2'])
+def test_windowed_record_in_the_other_stepper_families(monkeypatch, case):
+    """The remaining steppers behind `rk_launch` carry their state across a window boundary as well: the 4-way row-split kernel
+    (mid-size ensembles; also with two stages), the general-tableau kernel (3/8 rule: partial stage sums in LDS), a rank-5 model
+    (derived monomials)."""
+    name = 'd38' if case == 'rank5' else 'm36'
+    g, m = _model(name)
+    knobs = _Knobs(monkeypatch, m)
+    n, steps = (6000, 30) if case == 'rksplit4' else (700, 30)
+    ic = np.random.RandomState(31).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    b, c, a = B, C, A
+    if case == 'dense_tableau':
+        b = np.array([1. / 8, 3. / 8, 3. / 8, 1. / 8])
+        c = np.array([0., 1. / 3, 2. / 3, 1.])
+        a = np.array([[0., 0, 0, 0], [1. / 3, 0, 0, 0], [-1. / 3, 1., 0, 0], [1., -1., 1., 0]])
+    elif case == 'heun2':
+        b, c, a = np.array([0.5, 0.5]), np.array([0., 1.]), np.array([[0., 0.], [1., 0.]])
+    expect = {'rksplit4': 'qgs_spec_rksplit4_s4', 'dense_tableau': 'qgs_spec_rkd_s4', 'rank5': 'qgs_spec_rk_s4', 'heun2': 'qgs_spec_rksplit4_s2'}[case]
+    m.set_kernel(2 if case in ('rank5', 'heun2', 'dense_tableau') else 0)
+    knobs.kind = 2 if case in ('rank5', 'heun2', 'dense_tableau') else 0
+    for direction, ws in ((1, 2), (-1, 1)):
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+        whole = np.array(m.rk_integrate(t, ic, direction, ws, b, c, a))
+        assert m.last_kernel_info()['name'] in (expect, expect.replace('_rk_s', '_rkr_s')), m.last_kernel_info()['name']
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=8 if case == 'rksplit4' else 1)
+        cut = m.rk_integrate(t, ic, direction, ws, b, c, a)
+        assert m.last_windows >= 3, m.last_windows
+        assert np.array_equal(whole, cut), (case, direction, ws)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
 def test_windowed_record_into_pageable_memory(monkeypatch):
     """The result block of a plain C caller is pageable memory: staged copy per window, same bits."""
     from qgs_amd import _lib
