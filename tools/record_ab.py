@@ -15,7 +15,7 @@ rec = torch.zeros((steps + 1, ndim, n), dtype=torch.float64, device='cuda')
 for rep in range(2):
     for var in sys.argv[1:]:
         for kv in var.split(','):
-            k, v = kv.split('='); os.environ[k] = v
+            k, v = kv.split('=', 1); os.environ[k] = v
         m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
         def run():
             for _ in range(10):
