@@ -1975,35 +1975,63 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
                              int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
                              double *mean, double *var, double *final_states)
 {
+    (void)c;
     if (!m || !ic || !mean || n_traj < 1) return fail("bad arguments");
-    if (!time || n_time < 1) return fail("bad time grid");
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
     HIPCHK(hipSetDevice(m->device));
-    const int64_t ld = round_ld(n_traj);
+    if (streams_ready(m)) return -1;
+    const int nd = m->ndim;
+    const int64_t ld = round_ld(n_traj), n_steps = n_time - 1;
     const int64_t n_records = qgs_n_records(time, n_time, write_steps);
-    const int64_t n_rows = n_records * m->ndim;
-    const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
-    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b * (size_t)n_records) ||
-        m->b_mom_out.ensure(sizeof(double) * 2 * (size_t)n_rows)) return -1;
-    HIPCHK(hipMemcpy(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice));
-    if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
-    if (qgs_rk_integrate_device(m, n_traj, ld, m->b_in_modes.f64(), time, n_time, time_direction, write_steps, s, b, c, a,
-                                m->b_rec_modes.f64(), nullptr)) return -1;
-    double *d_mean = m->b_mom_out.f64(), *d_var = d_mean + n_rows;
-    if (qgs_ensemble_moments_device(m, n_traj, ld, n_rows, m->b_rec_modes.f64(), d_mean, var ? d_var : nullptr, nullptr)) return -1;
+    const int64_t n_rows = n_records * nd;
+    const int backward = time_direction == -1;
+    const size_t rows_b = sizeof(double) * (size_t)n_traj * nd, modes_b = sizeof(double) * (size_t)ld * nd;
+    hipStream_t sc = m->st_comp;
+    // the record never exists as a whole: window after window is integrated and reduced in place (the rows of the moments are
+    // (record, variable) pairs, so a window's rows are its own); one window buffer, one stream
+    const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, 1);
+    m->last_windows = plan.n_windows;
+    if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_win[0].ensure(modes_b * (size_t)plan.W) ||
+        m->b_state2.ensure(modes_b) || m->b_carry.ensure(modes_b) || m->b_mom_out.ensure(sizeof(double) * 2 * (size_t)n_rows)) return -1;
+    HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice, sc));
+    qgs::launch_pack_states(nd, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), sc);
+    HIPCHK(hipGetLastError());
+    const double *d_time, *d_tab_spec, *d_tab_full;
+    if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
+    double *d_mean = m->b_mom_out.f64(), *d_var = d_mean + n_rows, *win = m->b_win[0].f64();
+    const double *y_in = m->b_in_modes.f64();
+    double *y_last = nullptr;
+    for (int64_t k = 0; k < plan.n_windows; ++k) {
+        int64_t lo, hi, sb, se, lo_s;
+        int wf;
+        plan.window(k, &lo, &hi, &sb, &se, &wf, &lo_s);
+        double *y_out = (k & 1) ? m->b_carry.f64() : m->b_state2.f64();        // always: the final states may be wanted
+        if (rk_launch(m, n_traj, ld, y_in, y_out, win - lo_s * (int64_t)nd * ld, d_time, d_tab_spec, d_tab_full, sb, se, n_steps,
+                      write_steps, n_records, backward, wf, s, a, sc)) return -1;
+        y_in = y_last = y_out;
+        const int64_t rows_k = (hi - lo) * nd;
+        if (rows_k > 0x7fffffff) return fail("too many rows in a record window");
+        if (m->b_mom_part.ensure(sizeof(double) * 2 * (size_t)rows_k * (size_t)qgs::moments_splits(rows_k, n_traj))) return -1;
+        qgs::launch_moments(rows_k, n_traj, ld, win, m->b_mom_part.f64(), d_mean + lo_s * nd, var ? d_var + lo_s * nd : nullptr, sc);
+        HIPCHK(hipGetLastError());
+    }
     // device rows are (record, mode); the reference's axis order is (mode, record)
     std::vector<double> h((size_t)n_rows * 2);
-    HIPCHK(hipMemcpy(h.data(), d_mean, sizeof(double) * (size_t)n_rows * (var ? 2 : 1), hipMemcpyDeviceToHost));
-    for (int64_t r = 0; r < n_records; ++r)
-        for (int d = 0; d < m->ndim; ++d) {
-            mean[(int64_t)d * n_records + r] = h[(size_t)(r * m->ndim + d)];
-            if (var) var[(int64_t)d * n_records + r] = h[(size_t)(n_rows + r * m->ndim + d)];
-        }
+    HIPCHK(hipMemcpyAsync(h.data(), d_mean, sizeof(double) * (size_t)n_rows * (var ? 2 : 1), hipMemcpyDeviceToHost, sc));
     if (final_states) {
-        // last record of the directed run = index n_records-1 (forward) or 0 (backward) in the stored order
-        const int64_t last = (time_direction == -1) ? 0 : n_records - 1;
-        if (qgs_unpack_states(m, n_traj, ld, m->b_rec_modes.f64() + (size_t)last * m->ndim * ld, m->b_in_rows.f64(), nullptr)) return -1;
-        HIPCHK(hipMemcpy(final_states, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost));
+        // the state after the last step of the directed run
+        qgs::launch_unpack_states(nd, n_traj, ld, y_last, m->b_in_rows.f64(), sc);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(final_states, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost, sc));
     }
+    HIPCHK(hipStreamSynchronize(sc));
+    for (int64_t r = 0; r < n_records; ++r)
+        for (int d = 0; d < nd; ++d) {
+            mean[(int64_t)d * n_records + r] = h[(size_t)(r * nd + d)];
+            if (var) var[(int64_t)d * n_records + r] = h[(size_t)(n_rows + r * nd + d)];
+        }
     return 0;
 }
 

@@ -103,6 +103,29 @@ def test_windowed_record_in_the_other_stepper_families(monkeypatch, case):
     m.close()
 
 
+def test_windowed_ensemble_moments(monkeypatch):
+    """`rk_integrate_moments` never holds the record: window after window is integrated and reduced.  Mean / variance against
+    NumPy on the record of `rk_integrate`, final states bitwise, forward and backward, for one window and for many."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    n, steps = 3000, 40
+    ic = np.random.RandomState(41).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    for direction, ws in ((1, 1), (-1, 3), (1, 0)):
+        knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+        rec = np.array(m.rk_integrate(t, ic, direction, ws, B, C, A))
+        last = rec[:, :, 0 if direction == -1 else -1]
+        for mb in (None, 4):
+            knobs.set(QGS_HIP_RECORD_WINDOW_MB=mb)
+            mean, var, fin = m.rk_integrate_moments(t, ic, direction, ws, B, C, A, variance=True, final_states=True)
+            assert (m.last_windows == 1) == (mb is None or ws == 0), (mb, m.last_windows)
+            assert rel_err(mean, rec.mean(axis=0)) < 1e-13
+            assert np.abs(var - rec.var(axis=0)).max() < 1e-10 * rec.var(axis=0).max()
+            assert np.array_equal(fin, last)
+    knobs.set(QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
 def test_windowed_record_into_pageable_memory(monkeypatch):
     """The result block of a plain C caller is pageable memory: staged copy per window, same bits."""
     from qgs_amd import _lib
