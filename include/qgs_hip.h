@@ -114,7 +114,8 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg,
                           double *traj, double *fmatrix);
 
 /* Same run as qgs_rk_integrate, but only the ensemble mean and variance of every variable at every record come back:
- * mean, var are (ndim, n_records) row-major (var may be null); final_states (n_traj, ndim) may be null.
+ * mean, var are (ndim, n_records) row-major (var may be null); final_states (n_traj, ndim) may be null.  The record never
+ * exists as a whole, on the device or anywhere else: it is integrated and reduced window by window.
  * Replaces integrate() + get_trajectories() + np.mean / np.var over the member axis
  * (qgs/integrators/statistics.py:33-66) without moving the ensemble trajectories to the host. */
 int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
