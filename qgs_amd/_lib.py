@@ -407,6 +407,23 @@ def visible_devices():
     return list(range(backend_info()[0]))
 
 
+def pool_moments(parts, variance=True):
+    """Mean and population variance of a set from the (count, mean, variance) of its disjoint parts (Chan et al.'s pairwise
+    update; arrays of any common shape)."""
+    n_acc, mean, m2 = 0, None, None
+    for n, mu, var in parts:
+        if mean is None:
+            n_acc, mean, m2 = n, np.array(mu, dtype=np.float64), (np.asarray(var) * n if variance else None)
+            continue
+        delta = mu - mean
+        tot = n_acc + n
+        if variance:
+            m2 = m2 + np.asarray(var) * n + delta * delta * (n_acc * n / tot)
+        mean = mean + delta * (n / tot)
+        n_acc = tot
+    return mean, (m2 / n_acc if variance else None)
+
+
 class _ShardModel(HipModel):
     """A group's model of one shard: borrowed handle, destroyed with the group."""
 
@@ -544,16 +561,6 @@ class HipModelGroup(object):
         if errors:
             raise errors[0]
         parts = [q for q in parts if q is not None]
-        n_acc, mean, m2 = 0, None, None
-        for n, mu, var, _ in parts:
-            if mean is None:
-                n_acc, mean, m2 = n, mu.copy(), (var * n if variance else None)
-                continue
-            delta = mu - mean
-            tot = n_acc + n
-            if variance:
-                m2 = m2 + var * n + delta * delta * (n_acc * n / tot)
-            mean = mean + delta * (n / tot)
-            n_acc = tot
+        mean, var = pool_moments([(n, mu, v) for n, mu, v, _ in parts], variance)
         fin = np.concatenate([q[3] for q in parts], axis=0) if final_states else None
-        return mean, (m2 / n_acc if variance else None), fin
+        return mean, var, fin

@@ -331,17 +331,6 @@ def test_integrator_classes_on_a_device_list_vs_reference_classes(name):
     f.operands.release()
 
 
-def test_default_device_is_every_gpu_for_large_ensembles(monkeypatch):
-    from qgs_amd.integrators import integrate as fn
-    from qgs_amd import _lib
-    assert fn.resolve_device(None, 1000) is None and fn.resolve_device(0, 10 ** 7) == 0
-    monkeypatch.setattr(_lib, 'visible_devices', lambda: [0, 1, 2, 3, 4, 5, 6, 7])
-    assert fn.resolve_device(None, 2 * 65536) == 'all' and fn.resolve_device(None, 2 * 65536 - 1) is None
-    assert fn.resolve_device([0, 1], 10 ** 7) == [0, 1]
-    monkeypatch.setattr(_lib, 'visible_devices', lambda: [0])
-    assert fn.resolve_device(None, 10 ** 7) is None
-
-
 def test_config5_full_size_through_the_shard_bookkeeping():
     """BASELINE config 5 as stated: MAOOAM-36 (the qgs_maooam.py parameter set of bench.py), 1 048 576 members, 1000 RK4
     steps, write_steps 0, 8 shards of 131 072.  On the one GPU present: (a) one 1 048 576-member call, (b) a group of eight
