@@ -866,21 +866,6 @@ __global__ void __launch_bounds__(256) unpack_kernel(int64_t n_inner, int64_t n_
     }
 }
 
-// in: R[n_records][n_inner][ld] -> out (n_traj, n_inner, n_records).  One thread per (member, q);
-// the record axis is innermost in the output, so each thread writes a contiguous run.
-__global__ void __launch_bounds__(256) unpack_records_kernel(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t n_records,
-                                                             const double *__restrict__ in, double *__restrict__ out)
-{
-    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (m >= n_traj) return;
-    for (int64_t q = blockIdx.y; q < n_inner; q += gridDim.y) {        // gridDim.y is capped at 65 535
-        double *o = out + (m * n_inner + q) * n_records;
-        const double *i = in + q * ld + m;
-        for (int64_t r = 0; r < n_records; ++r) o[r] = i[r * n_inner * ld];
-    }
-}
-
-
 // A window of W records R[W][n_inner][ld] -> columns [0, W) of out, where element (m, q, r) of the output sits at
 // out[(m * n_inner + q) * out_stride + r] (out already points at the window's first record column; out_stride = the
 // record count of the whole run).  64 members x 64 consecutive (q, r) pairs per block through an LDS tile: reads are
@@ -1242,8 +1227,9 @@ void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t 
                            n_inner, n_traj, ld, in, out);
         return;
     }
-    hipLaunchKernelGGL(unpack_records_kernel, dim3(blocks_for(n_traj, 256), (unsigned)std::min<int64_t>(n_inner, 65535)), dim3(256), 0, st,
-                       n_inner, n_traj, ld, n_records, in, out);
+    // the whole record as one window of the tile kernel: 3.5 TB/s moved at config-2 size (101 records of 65 536 x 36), where one
+    // thread per (member, inner) writing its run of records 8 bytes at a time reached 0.94 (tools/unpack_ab.py)
+    launch_unpack_window(n_inner, n_traj, ld, n_records, n_records, in, out, st);
 }
 
 void launch_unpack_window(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W, int64_t out_stride, const double *in,
