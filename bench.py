@@ -461,8 +461,8 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=200, help='timed passes (default 200: 0.9 s of GPU work, long enough for an smi sampler to see it)')
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--members', type=int, default=None,
                     help='ensemble members per GPU (default: 131 072 with --gpus 8 = BASELINE configs[4], 1 048 576 members over 8 GPUs; '
                          '65 536 = configs[1] otherwise)')

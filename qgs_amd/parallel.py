@@ -69,6 +69,28 @@ class ShardedEnsemble(object):
         return torch.cat([p[:n] for p, n in zip(parts, self.counts)], dim=0)
 
 
+def gather_to_host(ens, local, max_bytes=None):
+    """The full (n_total, n_dim, n_records) result as a NumPy array on every rank, gathered from the per-rank blocks `local`
+    (torch tensors, first axis = local members).  The gathered tensor lives where `local` lives; when the whole result would
+    exceed `max_bytes` there (default: QGS_GATHER_BYTES or 32 GiB -- every rank of an all-gather holds the full result), it is
+    gathered and copied to the host in chunks of records instead, so that no rank ever holds more than `max_bytes` of gathered
+    data in device memory."""
+    import os
+    import torch
+    if max_bytes is None:
+        max_bytes = int(os.environ.get('QGS_GATHER_BYTES', str(32 << 30)))
+    n_rec = int(local.shape[2])
+    per_record = ens.n_total * int(local.shape[1]) * local.element_size()
+    if not ens.distributed or per_record * n_rec <= max_bytes or n_rec <= 1:
+        return ens.gather(local).cpu().numpy()
+    chunk = max(1, int(max_bytes // max(1, per_record)))
+    out = np.empty((ens.n_total, int(local.shape[1]), n_rec))
+    for r0 in range(0, n_rec, chunk):
+        r1 = min(n_rec, r0 + chunk)
+        out[:, :, r0:r1] = ens.gather(local[:, :, r0:r1].contiguous()).cpu().numpy()
+    return out
+
+
 class RootGather(object):
     """Gather of equal per-rank blocks onto one rank, optionally asynchronous so that it overlaps the next
     compute step (RCCL runs it on its own stream).  xGMI is point-to-point: N-1 ranks sending their block
@@ -150,9 +172,7 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
             local = _integrate_shard_on_device(f, device, local_ic, grid, forward, write_steps, b, c, a)
         else:
             local = torch.zeros((0, ic.shape[1], nrec), dtype=torch.float64, device=device)
-        full = ens.gather(local)
-        del local
-        return time, full.cpu().numpy()
+        return time, gather_to_host(ens, local)
     if integrator_factory is None:
         # a user-written Python callable (host stepper), or a CPU process group (gloo): every rank integrates its block through
         # the integrator class and the NumPy results are gathered through host tensors
@@ -180,5 +200,4 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
     ens._dist.all_reduce(nrec, op=ens._dist.ReduceOp.MAX, group=process_group)
     if ens.n_local == 0:
         local = np.zeros((0, ic.shape[1], int(nrec.item())))
-    full = ens.gather(torch.from_numpy(np.ascontiguousarray(local)).to(device))
-    return time, full.cpu().numpy()
+    return time, gather_to_host(ens, torch.from_numpy(np.ascontiguousarray(local)).to(device))

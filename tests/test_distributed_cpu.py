@@ -40,8 +40,10 @@ class _OracleIntegrator(object):
         pass
 
 
-def _worker(rank, world, port, n_traj, write_steps, out_dir):
+def _worker(rank, world, port, n_traj, write_steps, out_dir, gather_bytes=None):
     import torch.distributed as dist
+    if gather_bytes:                                     # forces the record-chunked gather (parallel.gather_to_host)
+        os.environ['QGS_GATHER_BYTES'] = str(gather_bytes)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -58,12 +60,12 @@ def _worker(rank, world, port, n_traj, write_steps, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_traj,write_steps', [(8, 0), (7, 3), (1, 1)])
-def test_sharded_ensemble_gloo_world2(tmp_path, n_traj, write_steps):
+@pytest.mark.parametrize('n_traj,write_steps,gather_bytes', [(8, 0, None), (7, 3, None), (1, 1, None), (7, 1, 5000), (8, 2, 3000)])
+def test_sharded_ensemble_gloo_world2(tmp_path, n_traj, write_steps, gather_bytes):
     import torch.multiprocessing as mp
     from oracle.oracle import OracleModel
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, n_traj, write_steps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, n_traj, write_steps, str(tmp_path), gather_bytes), nprocs=2, join=True)
     g = load_golden('a36')
     ic = np.random.RandomState(0).rand(n_traj, g.ndim) * 0.01
     from qgs_amd.integrators.integrate import time_grid
