@@ -15,7 +15,7 @@ from bench import load_model_tensors, rk4_tableau, grid                      # n
 
 ndim, coo, val, jcoo, jval, _ = load_model_tensors()
 b, c, a = rk4_tableau()
-n, steps = 65536, 100
+n, steps = 65536, (int(sys.argv[1]) if len(sys.argv) > 1 else 100)
 t = grid(steps, 0.1)
 ic = np.random.RandomState(21217).rand(n, ndim) * 0.01
 
@@ -38,8 +38,9 @@ ms = wall(lambda: (h.copy_(d, non_blocking=True), torch.cuda.synchronize()))
 print('plain page-locked D2H of %.2f GB: %.1f ms = %.1f GB/s' % (nbytes / 1e9, ms, nbytes / ms / 1e6))
 del d, h
 ref = None
-for mode in ('kernel', 'copy'):
-    for mb in (None, 2048, 512, 128):
+modes = ('kernel', 'copy') if len(sys.argv) <= 2 else tuple(sys.argv[2].split(','))
+for mode in modes:
+    for mb in ((None, 2048, 512, 128) if len(sys.argv) <= 3 else tuple(None if q == 'dflt' else int(q) for q in sys.argv[3].split(','))):
         os.environ['QGS_HIP_D2H'] = mode
         if mb is None:
             os.environ.pop('QGS_HIP_RECORD_WINDOW_MB', None)
