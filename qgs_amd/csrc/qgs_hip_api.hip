@@ -1875,6 +1875,23 @@ static bool prefer_copy_route(const qgs_model *m, bool dst_is_device, int64_t n_
     return m->tune.window_bytes / std::max<size_t>(1, bytes_per_record * 3) >= (size_t)n_records;
 }
 
+// A pageable destination that needs several windows is page-locked for the duration of the call: the strided copies of staged
+// windows into pageable memory reach 5-16 GB/s (tools/d2h_routes.py), the unpack kernel's stores into a page-locked block 40-50,
+// and page-locking costs about 0.04 s per GB (7.8 s for 189 GB).  Failure to lock (limits, foreign memory) just keeps the copies.
+struct TempPin {
+    void *p = nullptr;
+    double *lock(qgs_model *m, double *dst, size_t bytes)
+    {
+        if (m->tune.d2h_mode == 2) return nullptr;
+        if (hipHostRegister(dst, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        p = dst;
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return (double *)dp;
+    }
+    ~TempPin() { if (p) (void)hipHostUnregister(p); }
+};
+
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
 static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
                         const double *d_win, double *alias, double *dst_host, Buffer &staging, hipStream_t st)
@@ -1926,6 +1943,9 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     bool dst_dev = false;
     double *alias = device_alias(m, traj, &dst_dev);
     if (alias && prefer_copy_route(m, dst_dev, n_records, modes_b)) alias = nullptr;
+    TempPin pin;
+    if (!alias && !dst_dev && !prefer_copy_route(m, false, n_records, modes_b))
+        alias = pin.lock(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records);
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
@@ -2068,6 +2088,11 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     bool dev_t = false, dev_f = false;
     double *alias_t = device_alias(m, traj, &dev_t), *alias_f = device_alias(m, fmatrix, &dev_f);
     if (prefer_copy_route(m, dev_t || dev_f, n_records, modes_b + tg_modes_b)) alias_t = alias_f = nullptr;
+    TempPin pin_t, pin_f;
+    if (!dev_t && !dev_f && !prefer_copy_route(m, false, n_records, modes_b + tg_modes_b)) {
+        if (!alias_t) alias_t = pin_t.lock(m, traj, rows_b * (size_t)n_records);
+        if (!alias_f) alias_f = pin_f.lock(m, fmatrix, tg_rows_b * (size_t)n_records);
+    }
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
                                          (alias_t && alias_f) ? 2 : 3);
     m->last_windows = plan.n_windows;
@@ -2227,6 +2252,11 @@ int qgs_group_rk_integrate(qgs_group *g, int64_t n_traj, const double *ic, const
     if (!g || !ic || !traj || n_traj < 1) return fail("bad arguments");
     if (!time || n_time < 1) return fail("bad time grid");
     const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
+    // a large pageable result block is page-locked once here, as a whole (the shards' slices share boundary pages, so they could
+    // not each lock their own): every GPU then stores its slice itself
+    TempPin pin;
+    const size_t bytes = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec;
+    if (bytes >= ((size_t)32 << 20) && !device_alias(g->models[0], traj)) (void)pin.lock(g->models[0], traj, bytes);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_integrate(g->models[(size_t)i], n, ic + a0 * nd, time, n_time, time_direction, write_steps, s, b, c, a,
                                 traj + a0 * nd * nrec);
@@ -2241,6 +2271,10 @@ int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, cons
     if (!g || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
     if (!time || n_time < 1) return fail("bad time grid");
     const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
+    TempPin pin_t, pin_f;
+    const size_t bytes_t = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec, bytes_f = bytes_t * (size_t)n_tg;
+    if (bytes_t >= ((size_t)32 << 20) && !device_alias(g->models[0], traj)) (void)pin_t.lock(g->models[0], traj, bytes_t);
+    if (bytes_f >= ((size_t)32 << 20) && !device_alias(g->models[0], fmatrix)) (void)pin_f.lock(g->models[0], fmatrix, bytes_f);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_tgls_integrate(g->models[(size_t)i], n, n_tg, ic + a0 * nd, tg_ic + a0 * nd * n_tg, time, n_time,
                                      time_direction, write_steps, s, b, c, a, adjoint, inverse, traj + a0 * nd * nrec,

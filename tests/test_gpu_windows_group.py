@@ -299,6 +299,33 @@ def test_group_equals_its_shards_bitwise():
     m.close()
 
 
+def test_group_into_a_pageable_block_of_a_c_caller(monkeypatch):
+    """A plain C caller hands `qgs_group_rk_integrate` an ordinary (pageable) result block: it is page-locked once for the call,
+    as a whole (the shards' slices share boundary pages), and every shard stores its slice itself -- also window by window."""
+    from qgs_amd import _lib
+    g, m = _model('m36')
+    grp = _lib.HipModelGroup(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'], devices=[0, 0, 0])
+    n, steps, ws = 20001, 40, 1
+    ic = np.random.RandomState(51).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    nrec = _lib.n_records(t, ws)
+    expect = np.concatenate([np.array(m.rk_integrate(t, ic[a0:a0 + c], -1, ws, B, C, A)) for a0, c in (grp.shard(n, i) for i in range(3))], axis=0)
+    for mb in (None, 64):
+        if mb is None:
+            monkeypatch.delenv('QGS_HIP_RECORD_WINDOW_MB', raising=False)
+        else:
+            monkeypatch.setenv('QGS_HIP_RECORD_WINDOW_MB', str(mb))
+        grp.set_kernel(0)
+        out = np.full((n, g.ndim, nrec), np.nan)                 # 236 MB, not page-locked
+        rc = _lib.lib().qgs_group_rk_integrate(grp._h, n, ic, t, len(t), -1, ws, 4, B, C, A, out)
+        assert rc == 0, _lib.last_error()
+        assert np.array_equal(out, expect), mb
+        assert (grp.models[0].last_windows > 1) == (mb is not None)
+    monkeypatch.delenv('QGS_HIP_RECORD_WINDOW_MB', raising=False)
+    grp.close()
+    m.close()
+
+
 @pytest.mark.parametrize('name', ['rp20', 'm36', 'd38'])
 def test_integrator_classes_on_a_device_list_vs_reference_classes(name):
     """The class-level goldens of test_gpu_api.py with `device=[0, 0]`: same outputs through the sharded engine."""
