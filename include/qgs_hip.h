@@ -82,7 +82,8 @@ int qgs_model_set_kernel(qgs_model *m, int kind);
 /* ---- host-layout entry points (copy in, run on the GPU, copy out; blocking) --------------
  * Results may be larger than the device memory: the integrations keep only a window of records on the device
  * (QGS_HIP_RECORD_WINDOW_MB, default 8192) and hand window k to the host while window k + 1 is computed.  The result
- * block may be pageable memory (staged copy) or page-locked (qgs_host_register: the device stores into it directly). */
+ * block may be page-locked (qgs_host_register: the device stores into it directly) or pageable (staged copy; a pageable
+ * block that needs several windows is page-locked for the duration of the call). */
 
 /* f(t, x) for n_traj states at once.   qgs/functions/tendencies.py:111-115 + sparse_mul.py:48-81 */
 int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx);
