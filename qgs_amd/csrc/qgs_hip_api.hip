@@ -1892,6 +1892,13 @@ struct TempPin {
     ~TempPin() { if (p) (void)hipHostUnregister(p); }
 };
 
+// Whatever way a pipelined call ends -- also on an error in the middle of it -- nothing of it may still be in flight when its
+// buffers, its page-lock (TempPin, declared before the guard: released after it) or the caller's blocks go away.
+struct DrainGuard {
+    hipStream_t a, b;
+    ~DrainGuard() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
+};
+
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
 static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
                         const double *d_win, double *alias, double *dst_host, Buffer &staging, hipStream_t st)
@@ -1946,6 +1953,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     TempPin pin;
     if (!alias && !dst_dev && !prefer_copy_route(m, false, n_records, modes_b))
         alias = pin.lock(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records);
+    DrainGuard drain{sc, sd};
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
@@ -2093,6 +2101,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
         if (!alias_t) alias_t = pin_t.lock(m, traj, rows_b * (size_t)n_records);
         if (!alias_f) alias_f = pin_f.lock(m, fmatrix, tg_rows_b * (size_t)n_records);
     }
+    DrainGuard drain{sc, sd};
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
                                          (alias_t && alias_f) ? 2 : 3);
     m->last_windows = plan.n_windows;
