@@ -172,6 +172,8 @@ int qgs_rk_integrate_rows_device(qgs_model *m, int64_t n_traj, const double *d_i
 /* (n_traj, ndim) host-layout device buffer  <->  mode-major X[ndim][ld] */
 int qgs_pack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_rows, double *d_x_modes, void *stream);
 int qgs_unpack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_modes, double *d_x_rows, void *stream);
+/* tangent vectors / matrices: (n_traj, ndim, n_tg) host-layout device buffer -> F[ndim][n_tg][ld] */
+int qgs_pack_tangent(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_rows, double *d_modes, void *stream);
 /* R[n_records][ndim][ld]  ->  (n_traj, ndim, n_records) */
 int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records,
                        const double *d_rec_modes, double *d_rec_rows, void *stream);

@@ -51,6 +51,7 @@ SIGNATURES = {
     'qgs_host_unregister': (_int, [_vp]),
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_pack_tangent': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_records': (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_tendencies_device': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_rk_integrate_device': (_int, [_vp, _i64, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp, _vp]),
@@ -189,30 +190,44 @@ class _ResultPool(object):
     MIN_BYTES = 8 << 20
 
     def __init__(self):
+        import threading
         self._free = {}
         self._held = 0
         self._cap = int(os.environ.get('QGS_HOST_POOL_BYTES', str(4 << 30)))
+        self._lock = threading.Lock()          # the shards of a device group may ask for blocks from their own threads
 
     def empty(self, shape):
         n = int(np.prod(shape))
         if n * 8 < self.MIN_BYTES or self._cap <= 0:
             return np.empty(shape)
         size = -(-n * 8 // (2 << 20)) * (2 << 20) // 8          # whole 2 MiB blocks, in doubles
-        lst = self._free.get(size)
-        if lst:
-            store = lst.pop()
-            self._held -= store.nbytes
-        else:
+        store = None
+        with self._lock:
+            lst = self._free.get(size)
+            if lst:
+                store = lst.pop()
+                self._held -= store.nbytes
+        if store is None:
             store = _Store(size)
         return np.asarray(_PooledBlock(self, store, shape))
 
     def _give_back(self, store):
-        if self._held + store.nbytes <= self._cap:
-            self._free.setdefault(store.size, []).append(store)
-            self._held += store.nbytes
+        with self._lock:
+            if self._held + store.nbytes <= self._cap:
+                self._free.setdefault(store.size, []).append(store)
+                self._held += store.nbytes
 
 
 _RESULTS = _ResultPool()
+
+
+def to_host(d_tensor):
+    """A device tensor (torch) as a NumPy array in a block of the page-locked result pool: one DMA copy at the PCIe rate instead
+    of a copy into fresh pageable memory (1.9 GB: 35 ms instead of ~0.3 s)."""
+    import torch
+    out = _RESULTS.empty(tuple(d_tensor.shape))
+    torch.from_numpy(out).copy_(d_tensor, non_blocking=False)
+    return out
 
 
 def _tensor_rank(coo, jcoo=None):
@@ -372,6 +387,9 @@ class HipModel(object):
 
     def unpack_states(self, n_traj, ld, d_modes, d_rows, stream=0):
         _check(lib().qgs_unpack_states(self._h, n_traj, ld, d_modes, d_rows, stream or None))
+
+    def pack_tangent(self, n_traj, ld, n_tg, d_rows, d_modes, stream=0):
+        _check(lib().qgs_pack_tangent(self._h, n_traj, ld, int(n_tg), d_rows, d_modes, stream or None))
 
     def unpack_records(self, n_traj, ld, n_inner, nrec, d_in, d_out, stream=0):
         _check(lib().qgs_unpack_records(self._h, n_traj, ld, n_inner, nrec, d_in, d_out, stream or None))

@@ -1295,6 +1295,16 @@ int qgs_unpack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_
     return 0;
 }
 
+int qgs_pack_tangent(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_rows, double *d_modes, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_tg < 1 || (int64_t)m->ndim * n_tg > (int64_t)65535 * 64 || !d_rows || !d_modes) return fail("bad n_tg / null pointer");
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_pack_tangent(m->ndim, n_tg, n_traj, ld, d_rows, d_modes, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records, const double *d_in,
                        double *d_out, void *stream)
 {

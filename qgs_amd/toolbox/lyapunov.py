@@ -164,8 +164,13 @@ class LyapunovsEstimator(object):
 
         # orthonormal start basis: QR of the drawn matrices with the same batched Householder kernel as in the loop
         # (np.linalg.qr on the host took 30 us per member: 0.5 s at 16 384)
+        # (the drawn matrices go up as they are, (n, n_dim, n_vec), and are brought into the device layout F[mode][vector][member]
+        # by the pack kernel: the host-side transpose of 170 MB at config-4 size took longer than the whole spin-up)
         q = torch.zeros((ndim, nv, ld), dtype=f64, device=dev)
-        q[:, :, :n] = torch.from_numpy(np.ascontiguousarray(a0.transpose(1, 2, 0))).to(dev)
+        a0_rows = torch.from_numpy(np.ascontiguousarray(a0)).to(dev)
+        m.pack_tangent(n, ld, nv, a0_rows.data_ptr(), q.data_ptr(), stream)
+        torch.cuda.current_stream(dev).synchronize()
+        del a0_rows
         # diag(R) of that first QR: with an empty spin-up the reference's `r = qr[1]` is still this one
         # (lyapunov.py:524, 603), so the first recorded exponents come from it
         rdiag0 = torch.ones((nv, ld), dtype=f64, device=dev)
@@ -252,7 +257,9 @@ class LyapunovsEstimator(object):
         recorded_exp = np.zeros((n, nv, self.n_records))
         for iw, rd, d in exp_sources:
             recorded_exp[:, :, iw] = (np.log(np.abs(rd[:, :n].cpu().numpy())) / d).T
-        return out_traj.cpu().numpy(), out_vec.cpu().numpy(), recorded_exp
+        from qgs_amd import _lib
+        torch.cuda.current_stream(dev).synchronize()
+        return _lib.to_host(out_traj), _lib.to_host(out_vec), recorded_exp
 
     def get_lyapunovs(self):
         """``(time, traj, exponents, vectors)``: traj (n_traj, n_dim, n_records), exponents (n_traj, n_vec, n_records),

@@ -9,7 +9,7 @@ from qgs_amd.functions.tendencies import create_tendencies
 from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
 p = model_configs.params_m36(); f, Df = create_tendencies(p)
 est = LyapunovsEstimator(num_threads=1); est.set_func(f, Df)
-for n in (1, 64, 1024):
+for n in ((1, 64, 1024) if len(sys.argv) < 2 else tuple(int(q) for q in sys.argv[1].split(","))):
     ic = np.random.RandomState(0).rand(n, 36) * 0.01
     for rep in range(2):
         np.random.seed(0)
