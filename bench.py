@@ -290,6 +290,15 @@ def event_ms(torch, fn, n, warm=1):
     return float(np.median(ts)), ts
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/hbm_traffic.json), or None."""
+    try:
+        with open(os.path.join(HERE, 'profiles', 'hbm_traffic.json')) as f:
+            return json.load(f).get(kernel, {}).get('hbm_bytes_per_launch')
+    except (OSError, ValueError):
+        return None
+
+
 def extra_configs(torch, dev, model, ndim, nnz, jnnz):
     from qgs_amd import _lib
     out = {}
@@ -318,6 +327,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
         'traj_steps_per_s': n * steps / (ms * 1e-3),
         'roofline': {'bound': 'hbm', 'achieved': rec_bytes / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': rec_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     'traffic': measured_traffic(kname_rec),
                      'note': 'record bytes actually written / kernel time; the kernel also does the fp64 work of the steps',
                      'fp64_valu_frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}}
     del rec
@@ -383,7 +393,8 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
         'workload': 'BASELINE configs[4] on one GPU: MAOOAM-36, 1 048 576 members, 1000 RK4 steps, write_steps=0, one launch',
         'kernel': model.last_kernel_info()['name'], 'ms': ms, 'traj_steps_per_s': n * steps / (ms * 1e-3),
         'roofline': {'bound': 'fp64_valu', 'achieved': flops36 * n * steps / (ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS}}
+                     'unit': 'TFLOP/s', 'frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                     'traffic': measured_traffic('qgs_spec_rk_s4@1048576')}}
     del ic, rec
 
     # -- config 4: tangent model, 16 384 members x 36 columns, 10 sub-steps per call, 100 calls; QR separately -------
@@ -429,6 +440,8 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
                      'flops_per_traj_step': flops_tgls,
                      'note': 'dense-matrix flop count of SURVEY 8(a) a8 (the kernel evaluates the sparse J w directly and '
                              'executes fewer)',
+                     'traffic': (measured_traffic(kname['name']) or 0) + (measured_traffic('qgs_spec_rkstagesp_s4') or 0) or None,
+                     'algorithmic_bytes_per_call': 2 * 8 * (ndim + ndim * n_tg) * n * steps,
                      'executed': executed,
                      'executed_fp64_frac': (rate * executed['flops_per_traj_step'] / 1e12 / FP64_VALU_PEAK_TFLOPS) if executed else None,
                      'hbm_algorithmic_frac': rate * 2 * 8 * (ndim + ndim * n_tg) / 1e9 / HBM_PEAK_GBS}}
@@ -452,6 +465,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
         'mode_updates_per_s': rate * nd3,
         'roofline': {'bound': 'fp64_valu', 'achieved': rate * flops228 / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': rate * flops228 / 1e12 / FP64_VALU_PEAK_TFLOPS, 'flops_per_traj_step': flops228,
+                     'traffic': measured_traffic('qgs_spec_rklds16'), 'algorithmic_bytes_per_launch': 2 * 8 * nd3 * n * steps,
                      'hbm_algorithmic_frac': rate * 2 * 8 * nd3 / 1e9 / HBM_PEAK_GBS}}
     m3.close()
     return out
