@@ -873,8 +873,9 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     if (direction == -1) std::reverse(dt.begin(), dt.end());
     if (dt != m->h_time) {
         if (m->d_time.ensure(sizeof(double) * (size_t)n_time)) return -1;
+        // no synchronisation: the source is pageable memory (staged by the runtime before the call returns) and is kept alive
+        // in h_time anyway; the copy is ordered before the kernels that read d_time on `st`
         HIPCHK(hipMemcpyAsync(m->d_time.p, dt.data(), sizeof(double) * (size_t)n_time, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
         m->h_time.swap(dt);
     }
     std::vector<double> tab;
@@ -885,7 +886,6 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     if (tab != m->h_tab) {
         if (m->d_tab.ensure(sizeof(double) * tab.size())) return -1;
         HIPCHK(hipMemcpyAsync(m->d_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
         m->h_tab.swap(tab);
     }
     *d_time = m->d_time.f64();
