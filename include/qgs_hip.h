@@ -94,6 +94,13 @@ int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac);
 /* Number of records the steppers produce.  qgs/integrators/integrate.py:190-196 */
 int64_t qgs_n_records(const double *time, int64_t n_time, int64_t write_steps);
 
+/* How the host-layout integrations cut a run into record windows of W records (pure host arithmetic; exported so that the plan can
+ * be checked without a GPU): window k holds the directed records [out[0], out[1]) -- record iw is written at the top of step
+ * iw * write_steps, the last one after the final step (integrate.py:210-221) --, runs the steps [out[2], out[3]), includes the
+ * final record iff out[4], and its first record is stored at index out[5] of the (direction-corrected) record axis.
+ * Returns the number of windows (> 0), < 0 on bad arguments. */
+int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, int backward, int64_t W, int64_t k, int64_t *out);
+
 /* _integrate_runge_kutta_jit(f, time, ic, time_direction, write_steps, b, c, a)
  * qgs/integrators/integrate.py:182-223.  `time` is the undirected grid (the function reverses it
  * for time_direction == -1 exactly like :199-202) and `traj` comes back direction-corrected (:223).

@@ -32,6 +32,7 @@ SIGNATURES = {
     'qgs_tendencies': (_int, [_vp, _i64, _f64p, _f64p]),
     'qgs_jacobian': (_int, [_vp, _i64, _f64p, _f64p]),
     'qgs_n_records': (_i64, [_f64p, _i64, _i64]),
+    'qgs_record_window': (_int, [_i64, _i64, _i64, _int, _i64, _i64, ctypes.POINTER(_i64)]),
     'qgs_rk_integrate': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p]),
     'qgs_rk_tgls_integrate': (_int, [_vp, _i64, _i64, _f64p, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p,
                                      _int, _dbl, _f64p, _f64p]),

@@ -1991,6 +1991,20 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     return 0;
 }
 
+int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, int backward, int64_t W, int64_t k, int64_t *out)
+{
+    if (!out || n_records < 1 || n_steps < 0 || write_steps < 0 || W < 1 || k < 0) return fail("bad arguments");
+    WindowPlan p;
+    p.n_records = n_records; p.n_steps = n_steps; p.write_steps = write_steps; p.backward = backward ? 1 : 0;
+    p.W = std::min(W, n_records);
+    p.n_windows = (n_records + p.W - 1) / p.W;
+    if (k >= p.n_windows) return fail("window index out of range");
+    int wf;
+    p.window(k, &out[0], &out[1], &out[2], &out[3], &wf, &out[5]);
+    out[4] = wf;
+    return (int)std::min<int64_t>(p.n_windows, 0x7fffffff);
+}
+
 int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
                      int time_direction, int64_t write_steps, int s, const double *b, const double *c, const double *a,
                      double *traj)

@@ -34,3 +34,40 @@ def test_shard_bounds_match_the_group_rule():
     assert shard_bounds(1048576, 8) == [(r * 131072, (r + 1) * 131072) for r in range(8)]
     assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_bounds(3, 5) == [(0, 1), (1, 2), (2, 3), (3, 3), (3, 3)]
+
+
+def test_record_window_plan_covers_every_record_once():
+    """The window plan of the host-layout integrations (qgs_record_window: host arithmetic, no GPU): for any run length,
+    cadence, direction and window size the windows tile the directed records and the steps without gaps or overlaps, every
+    record written at the top of a step lies in the window that runs that step, the final record in the last window only, and
+    the stored index ranges tile the record axis (mirrored for backward runs)."""
+    import ctypes
+    from qgs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(3)
+    cases = [(0, 0, 1), (0, 1, 1), (9, 3, 3), (10, 3, 4), (100, 1, 13), (100, 0, 5), (7, 10, 1), (50, 7, 2)]
+    cases += [(int(rng.randint(0, 300)), int(rng.randint(0, 12)), int(rng.randint(1, 40))) for _ in range(200)]
+    for n_steps, ws, W in cases:
+        time = np.arange(n_steps + 1, dtype=np.float64)
+        n_rec = _lib.n_records(time, ws)
+        n_top = 0 if ws == 0 else -(-n_steps // ws)                      # records written at the top of a step: steps 0, ws, 2 ws, ... < n_steps
+        assert n_rec == n_top + 1
+        for backward in (0, 1):
+            out = (ctypes.c_int64 * 6)()
+            n_win = L.qgs_record_window(n_rec, n_steps, ws, backward, W, 0, out)
+            assert n_win == -(-n_rec // min(W, n_rec))
+            next_lo, next_step, stored = 0, 0, []
+            for k in range(n_win):
+                assert L.qgs_record_window(n_rec, n_steps, ws, backward, W, k, out) == n_win
+                lo, hi, sb, se, wf, lo_s = (int(q) for q in out)
+                assert lo == next_lo and lo < hi <= n_rec and hi - lo <= W
+                assert sb == next_step and sb <= se <= n_steps
+                assert wf == (1 if k == n_win - 1 else 0) and (not wf or (hi == n_rec and se == n_steps))
+                tops = [st // ws for st in range(sb, se) if ws > 0 and st % ws == 0]
+                assert all(lo <= iw < hi for iw in tops), (n_steps, ws, W, k, tops, lo, hi)
+                assert sorted(tops + ([n_rec - 1] if wf else [])) == list(range(lo, hi)), (n_steps, ws, W, k)
+                assert lo_s == (n_rec - hi if backward else lo)
+                stored += list(range(lo_s, lo_s + hi - lo))
+                next_lo, next_step = hi, se
+            assert next_lo == n_rec and next_step == n_steps and sorted(stored) == list(range(n_rec))
+    assert L.qgs_record_window(0, 1, 1, 0, 1, 0, out) < 0 and _lib.last_error()
