@@ -412,6 +412,38 @@ def gen_lyapunov(name):
     print('[lyap %s] wrote %s (%.1f KB)' % (name, path, os.path.getsize(path) / 1024.), flush=True)
 
 
+def gen_lyapunov_t228():
+    """Benettin goldens at MAOOAM 6x6 (ndim 228): the reference's loops on ONE trajectory over four re-orthonormalisation
+    intervals of two sub-steps -- small enough for CPython (every tangent stage evaluates the 55 522-entry Jacobian tensor in a
+    Python loop), large enough to pin the LDS-resident tangent kernels and the 228 x 228 QR of the full spectrum."""
+    from qgs.toolbox.lyapunov import _compute_backward_lyap_jit, _compute_forward_lyap_jit
+    t_start = time.time()
+    cfg = CONFIGS['t228']
+    p = cfg['make']()
+    f, Df = create_tendencies(p)
+    ndim = p.ndim
+    out = {'ndim': np.int64(ndim)}
+    ic = np.random.RandomState(4242).rand(1, ndim) * cfg['ic_scale']
+    out['ic'] = ic
+    t0, tw, t, dt, mdt = 0., 0.2, 0.4, 0.1, 0.05
+    pretime = np.concatenate((np.arange(t0, tw, dt), np.full((1,), tw)))
+    timeg = np.concatenate((np.arange(tw, t, dt), np.full((1,), t)))
+    out['pretime'], out['time'], out['mdt'] = pretime, timeg, np.float64(mdt)
+    cases = []
+    for tag, forward, ws, n_vec in [('b_w1_v5', False, 1, 5), ('f_w1_v3', True, 1, 3), ('b_w0_full', False, 0, ndim)]:
+        np.random.seed(1234)
+        fn = _compute_forward_lyap_jit if forward else _compute_backward_lyap_jit
+        rt, re, rv = fn(f, Df, pretime, timeg, mdt, ic, n_vec, ws, False, 1., RK4['b'], RK4['c'], RK4['a'])
+        out['%s_traj' % tag], out['%s_exp' % tag], out['%s_vec' % tag] = rt, re, rv
+        cases.append(dict(tag=tag, forward=forward, ws=ws, n_vec=int(n_vec), adjoint=False, inverse=False, seed=1234))
+        print('[lyap t228] %s done at %.0f s' % (tag, time.time() - t_start), flush=True)
+    out['meta_json'] = np.frombuffer(json.dumps({'cases': cases, 't0': t0, 'tw': tw, 't': t, 'dt': dt, 'mdt': mdt}).encode(),
+                                     dtype=np.uint8)
+    path = os.path.join(HERE, 'lyap_t228.npz')
+    np.savez_compressed(path, **out)
+    print('[lyap t228] wrote %s (%.1f KB) in %.0f s' % (path, os.path.getsize(path) / 1024., time.time() - t_start), flush=True)
+
+
 # Lorenz-84 as written in the reference's own usage example (qgs/integrators/integrator.py:1230-1256, 1285-1287): a user-written
 # system with its Jacobian and a boundary term for the tangent model.  tests/callables_l84.py holds the same three functions.
 L84 = dict(a=0.25, F=16., G=3., b=6.)
@@ -549,6 +581,8 @@ if __name__ == '__main__':
         if nm == 'lyap':
             gen_lyapunov('rp20')
             gen_lyapunov('m36')
+        elif nm == 'lyap_t228':
+            gen_lyapunov_t228()
         elif nm.startswith('lyap_'):
             gen_lyapunov(nm[5:])
         elif nm == 'callables':

@@ -90,3 +90,29 @@ def test_full_lyapunov_spectrum_at_ndim228():
         assert np.abs(q.T @ q - np.eye(g.ndim)).max() < 1e-11
     est.terminate()
     f.operands.release()
+
+
+def test_lyapunov_estimator_at_ndim228_vs_reference():
+    """MAOOAM 6x6 against the reference's own Benettin loops (tests/golden/lyap_t228.npz, make_golden.py gen_lyapunov_t228: one
+    trajectory, four intervals of two sub-steps): 5 backward vectors, 3 forward vectors, and the full 228-vector spectrum --
+    the LDS-resident tangent kernels and the 228 x 228 global-memory QR with the same random start matrices as the reference."""
+    from conftest import load_golden
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
+    z = np.load(os.path.join(GOLDEN_DIR, 'lyap_t228.npz'))
+    meta = json.loads(bytes(z['meta_json']).decode())
+    g = load_golden('t228')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    est = LyapunovsEstimator(num_threads=1)
+    est.set_func(f, Df)
+    for cs in meta['cases']:
+        np.random.seed(cs['seed'])
+        est.compute_lyapunovs(meta['t0'], meta['tw'], meta['t'], meta['dt'], meta['mdt'], ic=z['ic'], write_steps=cs['ws'],
+                              n_vec=cs['n_vec'], forward=cs['forward'], adjoint=cs['adjoint'], inverse=cs['inverse'])
+        tt, traj, exps, vecs = est.get_lyapunovs()
+        tag = cs['tag']
+        assert rel_err(traj, np.squeeze(z[tag + '_traj'])) < 1e-12, tag
+        assert rel_err(vecs, np.squeeze(z[tag + '_vec'])) < 1e-9, tag
+        assert np.abs(exps - np.squeeze(z[tag + '_exp'])).max() < 1e-8 * max(1.0, np.abs(z[tag + '_exp']).max()), tag
+    est.terminate()
+    f.operands.release()
