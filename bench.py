@@ -471,6 +471,12 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz):
     return out
 
 
+def default_members(n_gpus):
+    """Ensemble members per GPU when --members is not given: BASELINE configs[4] (1 048 576 members over 8 GPUs) at 8 GPUs,
+    configs[1] (65 536 members on one GPU) per GPU otherwise."""
+    return 131072 if n_gpus == 8 else 65536
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -488,9 +494,8 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error('--gpus must be >= 1')
-    members_default = args.members is None
-    if members_default:
-        args.members = 131072 if args.gpus == 8 else 65536
+    if args.members is None:
+        args.members = default_members(args.gpus)
 
     under_launcher = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
     if not under_launcher and args.gpus > 1:

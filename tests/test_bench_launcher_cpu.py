@@ -112,3 +112,14 @@ def test_helper_that_cannot_run_falls_back_to_the_in_process_compiler(tmp_path):
     p = subprocess.run([sys.executable, '-c', _PREBUILD], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900,
                        env=dict(os.environ, QGS_HIP_CACHE_DIR=str(c), QGS_HIP_HELPER=str(fake)))
     assert p.returncode != 0 and b'error: nope' in p.stderr and not os.path.isdir(str(c)) or _hsaco(c) == []
+
+
+def test_bench_default_workloads_follow_the_baseline_configs():
+    """`bench.py --gpus 8` runs BASELINE configs[4] (131 072 members per GPU = 1 048 576), every other N configs[1] per GPU; the
+    launcher counts GPUs without loading HIP (none in this container)."""
+    sys.path.insert(0, REPO)
+    import bench
+    assert [bench.default_members(n) for n in (1, 2, 4, 8)] == [65536, 65536, 65536, 131072]
+    assert 8 * bench.default_members(8) == 1048576
+    assert bench.visible_gpus() == 0
+    assert 'hip' not in ' '.join(m for m in sys.modules if 'amdhip' in m)
