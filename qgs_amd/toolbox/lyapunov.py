@@ -146,12 +146,16 @@ class LyapunovsEstimator(object):
         """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
         returns (traj, vectors, exponents) in the reference's layouts."""
         import torch
+        with torch.cuda.device(torch.device('cuda', m.device)):       # this thread's current device for the duration of the call only
+            return self._compute_shard_on_current_device(m, ic, a0, mdt)
+
+    def _compute_shard_on_current_device(self, m, ic, a0, mdt):
+        import torch
         forward, adjoint, write_steps = self._forward == 1, self._adjoint, self.write_steps
         ndim, nv, n = self.n_dim, self.n_vec, ic.shape[0]
         ld = (n + 63) // 64 * 64
         dev = torch.device('cuda', m.device)
         f64 = torch.float64
-        torch.cuda.set_device(dev)                      # per thread: allocations and the current stream of THIS shard's GPU
         stream = torch.cuda.current_stream(dev).cuda_stream
 
         # base trajectory, every step recorded: R[step][mode][member]            (lyapunov.py:558 / :474)
