@@ -1,7 +1,9 @@
 // codegen.cpp -- see codegen.h.  Emits HIP C++ source; everything is straight-line fp64 code built from the
 // tensor, so the compiled kernels contain no tensor index loads at all: the coefficients arrive through the
-// scalar unit (per-kernel __constant__ tables walked with s_load_dwordx16, or s_mov literals on request) and
-// every VALU slot is a v_mul_f64 / v_fma_f64.
+// scalar unit (per-kernel __constant__ tables walked with s_load_dwordx16) and every VALU slot is a
+// v_mul_f64 / v_fma_f64.  The tables are declared without initialisers: their contents are returned next to the source
+// (GeneratedKernel::tables) and stored into the loaded module, so the source -- and the code object -- depend on the
+// structure of the tensor only, not on its values.
 #include "codegen.h"
 
 #include <algorithm>
@@ -11,6 +13,8 @@
 #include <functional>
 #include <map>
 #include <sstream>
+#include <stdexcept>
+#include <unordered_map>
 
 namespace qgs {
 
@@ -32,10 +36,12 @@ struct KTable {
     size_t pad_to = 0;      // group-64 mode: the run-ahead loads may touch this many entries
 };
 thread_local KTable *g_ktab = nullptr;
+thread_local std::vector<CoefTable> *g_tables = nullptr;     // tables of the kernel being generated (generate_kernel)
 
 std::string lit(double v)
 {
-    if (!g_ktab) return hexlit(v);
+    // no literal coefficients: a value in the source would tie the code object to one parameter set
+    if (!g_ktab) throw std::logic_error("codegen: coefficient outside a coefficient table");
     return "@K" + hexlit(v) + "@";        // resolved to kt[n] in final text order by resolve_ktab()
 }
 
@@ -107,7 +113,8 @@ std::string resolve_ktab(const std::string &text, KTable &t, bool dedupe = false
                 res += (std::signbit(t.vals[n]) == std::signbit(v)) ? ref : "(-" + ref + ")";
             } else {
                 n = next_ref(v, &ok);
-                res += ok ? "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]" : hexlit(v);
+                if (!ok) throw std::logic_error("codegen: the stages of a kernel emit different coefficient sequences");
+                res += "kq" + std::to_string(n / 8) + "[" + std::to_string(n % 8) + "]";
             }
             if (first_group < 0) first_group = (long)(n / 16);
             lp = b + 1;
@@ -150,12 +157,19 @@ std::string interleave(const std::vector<std::vector<std::string>> &lists)
     return out;
 }
 
+// The table is declared without an initialiser (a HIP __constant__ variable is `externally_initialized`: the compiler
+// assumes nothing about its contents); the values go to the caller, who stores them into the loaded module.
 void emit_ktable(std::ostringstream &o, const std::string &name, const KTable &t)
 {
     const size_t padded = std::max<size_t>(std::max<size_t>(8, t.pad_to), (t.vals.size() + 7) / 8 * 8);      // whole 8-double blocks
-    o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << padded << "] = {";
-    for (size_t n = 0; n < padded; ++n) o << (n ? ", " : "") << (n < t.vals.size() ? hexlit(t.vals[n]) : std::string("0.0"));
-    o << "};\n";
+    o << "__constant__ __attribute__((aligned(64))) f64 " << name << "[" << padded << "];   // " << t.vals.size()
+      << " coefficients, filled after the module is loaded\n";
+    if (!g_tables) throw std::logic_error("codegen: coefficient table outside generate_kernel");
+    CoefTable ct;
+    ct.symbol = name;
+    ct.values = t.vals;
+    ct.values.resize(padded, 0.0);
+    g_tables->push_back(std::move(ct));
 }
 
 struct Bil { int j, k; double c; };
@@ -409,24 +423,37 @@ __device__ __forceinline__ f64 qgs_bitsel(unsigned long long mask, f64 a, f64 b)
 }
 )";
 
-void emit_tend_kernel(std::ostringstream &o, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
+void emit_tend_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
                       const std::vector<std::pair<int, int>> &der)
 {
+    std::ostringstream o;
+    KTable table;
     o << "\n// f(t,x) for an ensemble: x, dx are X[mode][member] with leading dimension ld\n";
     o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_tend(const f64* __restrict__ x, f64* __restrict__ dx, i64 n_traj, i64 ld)\n{\n";
     o << "    const i64 m = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n    if (m >= n_traj) return;\n";
     for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
     emit_derived(o, "    ", ndim, der, names("x"));
+    // brace-less rows: the coefficient group vectors of the table pipeline stay in scope (the kernel is bound by its
+    // 2 * ndim memory accesses per member, not by where its coefficients come from)
+    g_ktab = &table;
+    o << "    kf64* kt = (kf64*)qgs_spec_tend_kt; asm volatile(\"\" : \"+s\"(kt));\n";
+    std::ostringstream so;
     for (int i = 1; i <= ndim; ++i) {
-        o << "    {\n";
-        emit_tend_row(o, "        ", rows[i], "r", names("x"), opt, i);
-        o << "        dx[" << (i - 1) << " * ld + m] = r;\n    }\n";
+        const std::string rn = "r" + std::to_string(i);
+        emit_tend_row(so, "    ", rows[i], rn, names("x"), opt, i);
+        so << "    dx[" << (i - 1) << " * ld + m] = " << rn << ";\n";
     }
+    o << resolve_ktab(so.str(), table);
+    g_ktab = nullptr;
     o << "}\n";
+    emit_ktable(out, "qgs_spec_tend_kt", table);
+    out << o.str();
 }
 
-void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &jac, const std::vector<std::pair<int, int>> &der)
+void emit_jac_kernel(std::ostringstream &out, int ndim, const std::vector<Term> &jac, const std::vector<std::pair<int, int>> &der)
 {
+    std::ostringstream o;
+    KTable table;
     // J[i][j] = sum_k Tj_ijk x_k  (sparse_mul2, sparse_mul.py:40-45); only structural entries are
     // stored, the caller zero-fills the output.  Output layout: Jm[(i-1)*ndim + (j-1)][member].
     std::map<std::pair<int, int>, std::vector<Lin>> ent;
@@ -438,18 +465,25 @@ void emit_jac_kernel(std::ostringstream &o, int ndim, const std::vector<Term> &j
     for (int d = 1; d <= ndim; ++d) o << "    const f64 x" << d << " = x[" << (d - 1) << " * ld + m];\n";
     emit_derived(o, "    ", ndim, der, names("x"));
     const NameFn X = names("x");
+    g_ktab = &table;
+    o << "    kf64* kt = (kf64*)qgs_spec_jac_kt; asm volatile(\"\" : \"+s\"(kt));\n";
+    std::ostringstream so;
+    int en = 0;
     for (auto &kv : ent) {
-        o << "    {\n";
-        std::ostringstream &oo = o;
-        Acc acc(oo, "e", "        ");
+        const std::string name = "e" + std::to_string(en++);
+        Acc acc(so, name, "    ");
         double c0 = 0.0; bool has = false;
         for (const Lin &l : kv.second) if (l.k == 0) { c0 += l.c; has = true; }
         if (has) acc.set_const(c0);
         for (const Lin &l : kv.second) if (l.k != 0) acc.add(lit(l.c), X(l.k));
         acc.finish();
-        o << "        jm[(i64)" << ((kv.first.first - 1) * ndim + (kv.first.second - 1)) << " * ld + m] = e;\n    }\n";
+        so << "    jm[(i64)" << ((kv.first.first - 1) * ndim + (kv.first.second - 1)) << " * ld + m] = " << name << ";\n";
     }
+    o << resolve_ktab(so.str(), table);
+    g_ktab = nullptr;
     o << "}\n";
+    emit_ktable(out, "qgs_spec_jac_kt", table);
+    out << o.str();
 }
 
 // Fused S-stage explicit RK stepper for sub-diagonal tableaus, one member per lane, all state in
@@ -1486,9 +1520,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         for (const KTable &t : tables) entries += t.vals.size();
         out << "// statement order " << opt.lds_order << ": " << entries << " coefficient table entries after de-duplication\n";
     }
-    // general-tableau flavour: CodeGenPrepare takes 3.3 min on this kernel at ndim 228 and changes nothing in the result
-    // (same registers, same scratch); qgs_hip_api.hip reads the line below and passes the flags to hiprtc
-    if (dense) out << "// qgs-compile-flags: -mllvm -disable-cgp\n";
+    // (general-tableau flavour: built with -mllvm -disable-cgp, see kernel_compile_flags)
     for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
 }
@@ -1635,9 +1667,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
     o << "#undef QGS_LOAD_XS\n}\n";
     out << "// per stage and 64 (member, column) pairs: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
-    // as for the general-tableau stepper: half of the 40 s this kernel takes to compile at ndim 228 is CodeGenPrepare, and the
-    // kernel runs the same without it (24.4 vs 24.5 ms for 16 384 members x 8 columns x 10 steps)
-    out << "// qgs-compile-flags: -mllvm -disable-cgp\n";
+    // (built with -mllvm -disable-cgp, see kernel_compile_flags)
     for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
 }
@@ -1648,7 +1678,7 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 // column c in registers, the pivot column of step j is broadcast from lane j with v_readlane (j is a compile-time
 // constant, so is every row index: no selects, no LDS, no barriers), after which every lane has the reflector and forms
 // norm / beta / tau itself.  Same conventions as the LDS kernel of generic_kernels.hip (LAPACK dgeqr2 + dorg2r).
-std::string generate_qr_kernel(int n_rows, int n_cols)
+GeneratedKernel generate_qr_kernel(int n_rows, int n_cols)
 {
     // Householder QR (dgeqr2 + dorg2r, the algorithm behind np.linalg.qr), one wavefront per matrix, lane = column, the column
     // in registers.  The pivot column of step j is broadcast from lane j with two v_readlane per entry and stays in SGPRs:
@@ -1721,7 +1751,9 @@ std::string generate_qr_kernel(int n_rows, int n_cols)
     o << "    if (col) {\n";
     for (int i = 0; i < R; ++i) o << "        ap[(i64)" << i * C << " * ld] = q" << i << ";\n";
     o << "    }\n}\n";
-    return o.str();
+    GeneratedKernel g;
+    g.source = o.str();
+    return g;
 }
 
 bool tableau_is_subdiagonal(int s, const double *a)
@@ -1730,6 +1762,15 @@ bool tableau_is_subdiagonal(int s, const double *a)
         for (int j = 0; j < s; ++j)
             if (a[i * s + j] != 0.0 && j != i - 1) return false;
     return true;
+}
+
+bool kernel_uses_jacobian(Kernel k)
+{
+    switch (k) {
+    case Kernel::Jac: case Kernel::Tgl: case Kernel::TglPair: case Kernel::TglX: case Kernel::TglDense: case Kernel::TglLds:
+    case Kernel::AdjLds: return true;
+    default: return false;
+    }
 }
 
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
@@ -1759,9 +1800,34 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
 // One kernel per translation unit: kernels compiled together share the register allocator's context and
 // perturb each other (the plain stepper went from 276 to 324 VGPRs and 4.6 -> 4.7 ms when a 4-way split
 // sibling was added to its module), so every kernel is generated, compiled and cached on its own.
-std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
-                            const CodegenOptions &opt, const Derived &der)
+// CodeGenPrepare: 3.3 of the 3.5 min the general-tableau LDS-resident stepper takes to compile at ndim 228, half of the 40 s of
+// the LDS-resident tangent kernels, and the kernels come out the same without it (same registers, same scratch; 24.4 vs
+// 24.5 ms for 16 384 members x 8 columns x 10 steps).
+std::vector<std::string> kernel_compile_flags(Kernel k)
 {
+    if (k == Kernel::RkLdsDense || k == Kernel::TglLds || k == Kernel::AdjLds) return {"-mllvm", "-disable-cgp"};
+    return {};
+}
+
+std::string options_signature(const CodegenOptions &o)
+{
+    std::ostringstream s;
+    s << "w" << o.min_waves_per_simd << ",il" << o.interleave << ",til" << o.tgl_interleave << ",pv" << o.tgl_park_v << ",tp" << o.tgl_pair
+      << ",td" << o.tgl_coeff_dedupe << ",sx" << o.tgl_share_x << ",sr" << o.rk_spread_rec << ",rs" << o.row_split << ",lw" << o.lds_waves
+      << ",lm" << o.lds_tgl_members << ",lc" << o.lds_cap << ",lg" << o.lds_group << ",ld" << o.lds_coeff_dedupe << ",ly" << o.lds_yload_ahead
+      << ",lo" << o.lds_order;
+    return s.str();
+}
+
+GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
+                                const CodegenOptions &opt, const Derived &der)
+{
+    GeneratedKernel gen;
+    struct TablesGuard {
+        std::vector<CoefTable> *old;
+        explicit TablesGuard(std::vector<CoefTable> *t) : old(g_tables) { g_tables = t; }
+        ~TablesGuard() { g_tables = old; g_ktab = nullptr; }
+    } tables_guard(&gen.tables);
     std::ostringstream o;
     o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
     o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
@@ -1796,7 +1862,8 @@ std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std
     case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt, der.j); break;
     case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt, der.j); break;
     }
-    return o.str();
+    gen.source = o.str();
+    return gen;
 }
 
 std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const std::vector<int> &stages, const CodegenOptions &opt_in)
@@ -1824,8 +1891,75 @@ std::string generate_source(int ndim, const std::vector<Term> &tensor, const std
 {
     std::string all;
     for (auto &ks : kernel_list(ndim, !jac_tensor.empty(), stages, opt))
-        all += generate_kernel(ndim, tensor, jac_tensor, ks.first, ks.second, opt, der) + "\n";
+        all += generate_kernel(ndim, tensor, jac_tensor, ks.first, ks.second, opt, der).source + "\n";
     return all;
+}
+
+// ---- canonical form (codegen.h) ---------------------------------------------------------------------------------------------
+namespace {
+
+struct CoordKey {
+    int i, j, k;
+    bool operator==(const CoordKey &o) const { return i == o.i && j == o.j && k == o.k; }
+};
+struct CoordHash {
+    size_t operator()(const CoordKey &c) const
+    {
+        uint64_t h = (uint64_t)(uint32_t)c.i * 0x9e3779b97f4a7c15ull;
+        h = (h ^ (uint64_t)(uint32_t)c.j) * 0xc2b2ae3d27d4eb4full;
+        h = (h ^ (uint64_t)(uint32_t)c.k) * 0x165667b19e3779f9ull;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+uint64_t magnitude_bits(double v)
+{
+    const double a = std::fabs(v);
+    uint64_t u;
+    std::memcpy(&u, &a, sizeof u);
+    return u;                                   // the bit pattern, so that NaN payloads and 0.0 are classes like any other
+}
+
+std::vector<Term> merge_duplicates(const std::vector<Term> &in)
+{
+    std::vector<Term> out;
+    std::unordered_map<CoordKey, size_t, CoordHash> where;
+    where.reserve(in.size() * 2);
+    for (const Term &t : in) {
+        auto it = where.find(CoordKey{t.i, t.j, t.k});
+        if (it == where.end()) { where.emplace(CoordKey{t.i, t.j, t.k}, out.size()); out.push_back(t); }
+        else out[it->second].v += t.v;
+    }
+    return out;
+}
+
+}  // namespace
+
+void canonicalize(const std::vector<Term> &terms, Canonical &c)
+{
+    c.terms = merge_duplicates(terms);
+    c.magnitude.assign(1, 0.0);
+    std::unordered_map<uint64_t, int> id;
+    id.emplace(magnitude_bits(0.0), 0);
+    for (Term &t : c.terms) {
+        auto it = id.find(magnitude_bits(t.v));
+        if (it == id.end()) {
+            it = id.emplace(magnitude_bits(t.v), (int)c.magnitude.size()).first;
+            c.magnitude.push_back(std::fabs(t.v));
+        }
+        t.v = std::copysign((double)it->second, t.v);
+    }
+}
+
+void Canonical::decode(const std::vector<double> &table, std::vector<double> &out) const
+{
+    out.resize(table.size());
+    for (size_t n = 0; n < table.size(); ++n) {
+        const double a = std::fabs(table[n]);
+        const size_t id = (size_t)a;
+        if (!(a == (double)id) || id >= magnitude.size()) throw std::logic_error("codegen: table entry is not a magnitude-class id");
+        out[n] = std::copysign(magnitude[id], table[n]);
+    }
 }
 
 // Greedy common-subexpression reduction of a set of monomials: while some monomial is longer than `target`, the pair

@@ -23,6 +23,14 @@ struct Term {          // one COO entry (i, j, k, value); index 0 is the constan
 // Always on (the alternatives were measured slower and removed in round 3): equal-|coefficient| bilinear terms of a row are
 // factored, c * (m1 +- m2 ...); coefficients come from a __constant__ table walked by s_load_dwordx16 in a software pipeline
 // of 16-coefficient groups (literal s_mov pairs: 7.4 instead of 4.6 ms for the stepper; compiler-placed loads: 5.75 ms).
+//
+// Coefficient VALUES are never part of the generated source (round 4): every coefficient is an entry of a `__constant__`
+// table that the source declares without an initialiser; the generator returns the table contents next to the source and
+// the library stores them into the loaded module (hipModuleGetGlobal).  What the source does depend on is the STRUCTURE of
+// the tensor: the sparsity pattern, which coefficients of a row share a magnitude (they are factored), and their signs.
+// The library therefore generates from the *canonical form* of a tensor (canonicalize() below), in which every coefficient
+// is replaced by +-(id of its magnitude class): two parameter sets of one model -- the reference's run-time operands
+// `coo` / `val` of sparse_mul3, qgs/functions/sparse_mul.py:48-81 -- give the same source, hence the same code object.
 struct CodegenOptions {
     int min_waves_per_simd = 1;
     int interleave = 2;        // rows whose statements are interleaved in the row-split stepper (ILP)
@@ -86,11 +94,39 @@ bool tableau_is_subdiagonal(int s, const double *a);
 // `stages` lists the stage counts S to instantiate (sub-diagonal tableaus only).
 // generate_source concatenates every kernel (inspection / offline builds); the library compiles one kernel per
 // translation unit (generate_kernel), see codegen.cpp.
+// One `__constant__` coefficient table of a generated kernel: `symbol[values.size()]`, declared uninitialised in the source.
+struct CoefTable {
+    std::string symbol;
+    std::vector<double> values;          // whole 8-double blocks (zero padded)
+};
+struct GeneratedKernel {
+    std::string source;
+    std::vector<CoefTable> tables;       // in the values the tensors were given in (canonical tensors: magnitude-class ids)
+};
+
+// Canonical form of a tensor for the generator.  Entries with equal coordinates are merged (summed in their incoming order);
+// then every value v becomes copysign(id(|v|), v) where id numbers the distinct magnitudes 1, 2, ... in order of first
+// appearance (0.0 keeps id 0).  `magnitude[id]` restores the value: decode() maps a table of a generated kernel back to the
+// coefficients of THIS tensor.  The tendencies tensor and the Jacobian tensor are canonicalised separately: a kernel reads
+// one of them (kernel_uses_jacobian), and its cache entry depends on that one only.
+struct Canonical {
+    std::vector<Term> terms;
+    std::vector<double> magnitude;       // magnitude[0] = 0.0
+    void decode(const std::vector<double> &table, std::vector<double> &out) const;
+};
+void canonicalize(const std::vector<Term> &terms, Canonical &out);
+
 enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense,
                     RkStagesPair, TglPair };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
-std::string generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
-                            const CodegenOptions &opt, const Derived &der = Derived());
+bool kernel_uses_jacobian(Kernel k);     // its coefficients come from the Jacobian tensor (else: from the tendencies tensor)
+GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
+                                const CodegenOptions &opt, const Derived &der = Derived());
+// extra compiler flags a kernel kind is built with (part of the cache key; e.g. "-mllvm -disable-cgp" for the LDS-resident
+// tangent kernels, whose compilation is otherwise dominated by a pass that changes nothing in the result)
+std::vector<std::string> kernel_compile_flags(Kernel k);
+// every generator option as text (part of the cache key)
+std::string options_signature(const CodegenOptions &opt);
 std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const std::vector<int> &stages, const CodegenOptions &opt);
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der = Derived());
@@ -98,7 +134,7 @@ std::string generate_source(int ndim, const std::vector<Term> &tensor, const std
 // Batched Householder QR fully unrolled for one matrix shape (n_rows, n_cols <= 64): kernel `qgs_spec_qr_<rows>x<cols>`
 // (a, rdiag, n_traj, ld), one wavefront per matrix, columns in registers.  Replaces np.linalg.qr in the Benettin loops
 // (qgs/toolbox/lyapunov.py:540-547, 599-628).
-std::string generate_qr_kernel(int n_rows, int n_cols);
+GeneratedKernel generate_qr_kernel(int n_rows, int n_cols);
 
 // Rough count of fp64 VALU instructions of one tendency evaluation in the generated code
 // (used for the roofline note in the bench output and DESIGN.md).

@@ -1,6 +1,7 @@
 // codegen_dump -- developer tool: print the specialised kernel source for a tensor given as text
 // (lines "T i j k value" for the tendencies tensor and "J i j k value" for the Jacobian tensor; rank-5 tensors:
-// "T5 i j k l m value" / "J5 i j k l m value").
+// "T5 i j k l m value" / "J5 i j k l m value").  The source is generated from the canonical form of the tensor, as the
+// library does (codegen.h canonicalize): it holds no coefficient values; `tables` also prints the decoded coefficient tables.
 #include "codegen.h"
 #include <cstdio>
 #include <cstdlib>
@@ -27,13 +28,23 @@ int main(int argc, char **argv)
     }
     std::fclose(f);
     qgs::Derived der;
+    std::vector<double> magnitude;
     qgs::reduce_polynomial(ndim, rank, (int64_t)val[0].size(), coo[0].data(), val[0].data(), false, T, der.t);
     qgs::reduce_polynomial(ndim, rank, (int64_t)val[1].size(), coo[1].data(), val[1].data(), true, J, der.j);
+    {
+        qgs::Canonical ct, cj;                         // what the library generates from
+        qgs::canonicalize(T, ct);
+        qgs::canonicalize(J, cj);
+        T = ct.terms;
+        J = cj.terms;
+        magnitude = ct.magnitude;
+    }
     qgs::CodegenOptions opt;
     std::vector<int> stages = {4};
-    bool all = false;
+    bool all = false, tables = false;
     for (int a = 3; a < argc; ++a) {
         if (!std::strcmp(argv[a], "all")) all = true;
+        if (!std::strcmp(argv[a], "tables")) tables = true;
         if (!std::strncmp(argv[a], "waves=", 6)) opt.min_waves_per_simd = std::atoi(argv[a] + 6);
         if (!std::strncmp(argv[a], "stages=", 7)) stages = {std::atoi(argv[a] + 7)};
         if (!std::strncmp(argv[a], "split=", 6)) opt.row_split = std::atoi(argv[a] + 6);
@@ -49,9 +60,22 @@ int main(int argc, char **argv)
         // every other emitter too (the sanitizer job of tests/test_codegen_sanitizers.py): general-tableau, LDS-resident and QR kernels
         using K = qgs::Kernel;
         if (ndim <= 64)
-            for (K k : {K::RkDense, K::TglDense}) std::fputs(qgs::generate_kernel(ndim, T, J, k, stages[0], opt, der).c_str(), stdout);
-        for (K k : {K::RkLds, K::TendLds, K::RkLdsDense, K::TglLds, K::AdjLds}) std::fputs(qgs::generate_kernel(ndim, T, J, k, 0, opt, der).c_str(), stdout);
-        std::fputs(qgs::generate_qr_kernel(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5).c_str(), stdout);
+            for (K k : {K::RkDense, K::TglDense}) std::fputs(qgs::generate_kernel(ndim, T, J, k, stages[0], opt, der).source.c_str(), stdout);
+        for (K k : {K::RkLds, K::TendLds, K::RkLdsDense, K::TglLds, K::AdjLds}) std::fputs(qgs::generate_kernel(ndim, T, J, k, 0, opt, der).source.c_str(), stdout);
+        std::fputs(qgs::generate_qr_kernel(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5).source.c_str(), stdout);
+    }
+    if (tables) {
+        // the coefficient tables of the fused stepper, decoded back to this tensor's values
+        qgs::Canonical canon;
+        canon.magnitude = magnitude;
+        const qgs::GeneratedKernel g = qgs::generate_kernel(ndim, T, J, ndim <= 64 ? qgs::Kernel::Rk : qgs::Kernel::RkLds, ndim <= 64 ? stages[0] : 0, opt, der);
+        if (ndim > 64) std::fputs(g.source.c_str(), stdout);      // (ndim <= 64: printed above with the other kernels)
+        for (const qgs::CoefTable &t : g.tables) {
+            std::vector<double> v;
+            canon.decode(t.values, v);
+            std::printf("// table %s: %zu entries\n", t.symbol.c_str(), v.size());
+            for (size_t n = 0; n < v.size(); ++n) std::printf("//   [%zu] %a\n", n, v[n]);
+        }
     }
     return 0;
 }

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hiprtc.h>
 
+#include <dirent.h>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <limits.h>
@@ -25,7 +26,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -72,6 +75,48 @@ uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull)
     for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
     return h;
 }
+
+// 128 bits from two differently mixed 64-bit lanes over 8-byte words (names and integrity checks of the kernel cache; not
+// cryptographic: it guards against collisions of the 64-bit file name, truncated files and bit rot, not against an adversary)
+struct Hash128 {
+    uint64_t a = 0, b = 0;
+    bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; }
+    std::string hex() const
+    {
+        char buf[40];
+        std::snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)a, (unsigned long long)b);
+        return buf;
+    }
+};
+struct Hasher {
+    uint64_t a = 1469598103934665603ull, b = 0x9e3779b97f4a7c15ull;
+    void word(uint64_t w)
+    {
+        a = (a ^ w) * 1099511628211ull;
+        a ^= a >> 31;
+        b = ((b << 29) | (b >> 35)) ^ (w * 0xc2b2ae3d27d4eb4full);
+        b *= 0x165667b19e3779f9ull;
+        b ^= b >> 33;
+    }
+    void add(const void *p, size_t n)
+    {
+        const unsigned char *q = (const unsigned char *)p;
+        word((uint64_t)n);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, q + i, 8); word(w); }
+        if (i < n) { uint64_t w = 0; std::memcpy(&w, q + i, n - i); word(w); }
+    }
+    void add(const std::string &s) { add(s.data(), s.size()); }
+    Hash128 done() const
+    {
+        Hasher h = *this;
+        h.word(0x51ed270b1f2c3d4eull);
+        Hash128 r;
+        r.a = h.a ^ (h.b >> 17);
+        r.b = h.b ^ (h.a << 23);
+        return r;
+    }
+};
 
 std::string lib_dir()
 {
@@ -123,21 +168,6 @@ std::vector<std::string> extra_flags()
     }
 #endif
     return default_extra_flags();
-}
-
-// Flags a generated source asks for itself: a line "// qgs-compile-flags: <flags>" (codegen.cpp; the general-tableau
-// LDS-resident stepper spends 3.3 of its 3.5 min of compilation in CodeGenPrepare at ndim 228 and produces the same code
-// without that pass).
-std::vector<std::string> flags_for(const std::string &src)
-{
-    std::vector<std::string> extra = extra_flags();
-    const char *tag = "// qgs-compile-flags:";
-    const size_t p = src.find(tag);
-    if (p != std::string::npos) {
-        std::istringstream is(src.substr(p + std::strlen(tag), src.find('\n', p) - p - std::strlen(tag)));
-        for (std::string tok; is >> tok;) extra.push_back(tok);
-    }
-    return extra;
 }
 
 // ---- which compiler builds the specialised kernels -------------------------------------------------------------------
@@ -220,7 +250,7 @@ std::string inproc_compiler_id()
 
 // Which compiler this process uses, decided once: the helper only when it exists AND answers `--version` (its answer, e.g.
 // "hiprtc9.0-libhiprtc.so.7.2.70200", is the compiler identity in the cache key); otherwise the in-process hiprtc under its
-// own identity.  A helper that stops working later (see compile_source) switches the process to the in-process compiler for
+// own identity.  A helper that stops working later (see obtain_blob) switches the process to the in-process compiler for
 // good -- `helper` and `id` always change together.
 struct CompilerChoice {
     bool helper = false;
@@ -268,29 +298,151 @@ void disable_helper(const std::string &why)
         c.id = inproc_compiler_id();
     }
 }
-std::string compiler_id() { return compiler_choice().id; }
 
-std::string cache_path(const std::string &src, const std::string &arch, const std::vector<std::string> &extra, const std::string &id)
+// ---- kernel cache --------------------------------------------------------------------------------------------------------------
+// A cache entry is what one (kernel kind, tensor STRUCTURE, generator, compiler, flags) compiles to: the code object plus the
+// layout of its coefficient tables in canonical form (magnitude-class ids, codegen.h Canonical).  Coefficient values are not
+// part of it: every model fills the tables of its own loaded module with its own values, so a parameter sweep over one model
+// shares one set of entries -- as the reference compiles sparse_mul3 once whatever `val` holds (sparse_mul.py:48-81).
+//
+// File <first 64 key bits>.hsaco = code object | tables | 64-byte footer.  The code object comes first, so the file still reads
+// as an ELF (llvm-objdump works on it); the footer carries the full 128-bit key, both lengths and a 128-bit hash of the
+// payload: a file that is truncated, damaged or belongs to a colliding key is not a hit, it is recompiled and replaced.
+struct KernelBlob {
+    std::vector<char> code;
+    std::vector<qgs::CoefTable> tables;
+};
+
+#ifndef QGS_CODEGEN_HASH
+#define QGS_CODEGEN_HASH "unversioned"      // the Makefile passes a hash of codegen.cpp + codegen.h: a changed generator never hits old entries
+#endif
+const char CACHE_MAGIC[8] = {'Q', 'G', 'S', 'K', 'C', '0', '0', '1'};
+
+std::string serialise_tables(const std::vector<qgs::CoefTable> &tables)
 {
-    std::string opts_key = arch + "|O3|c++17|v2|" + id;
-    for (const auto &x : extra) opts_key += "|" + x;
-    char name[64];
-    std::snprintf(name, sizeof name, "%016llx", (unsigned long long)fnv1a(src, fnv1a(opts_key)));
+    std::string out;
+    auto put64 = [&](uint64_t v) { out.append((const char *)&v, 8); };
+    put64(tables.size());
+    for (const auto &t : tables) {
+        put64(t.symbol.size());
+        out += t.symbol;
+        put64(t.values.size());
+        out.append((const char *)t.values.data(), t.values.size() * sizeof(double));
+    }
+    return out;
+}
+
+bool parse_tables(const char *p, size_t n, std::vector<qgs::CoefTable> &tables)
+{
+    size_t pos = 0;
+    auto get64 = [&](uint64_t *v) { if (pos + 8 > n) return false; std::memcpy(v, p + pos, 8); pos += 8; return true; };
+    uint64_t nt;
+    if (!get64(&nt) || nt > 4096) return false;
+    tables.clear();
+    for (uint64_t i = 0; i < nt; ++i) {
+        uint64_t len, cnt;
+        if (!get64(&len) || len > 256 || pos + len > n) return false;
+        qgs::CoefTable t;
+        t.symbol.assign(p + pos, (size_t)len);
+        pos += (size_t)len;
+        if (!get64(&cnt) || cnt > (n - pos) / sizeof(double)) return false;
+        t.values.resize((size_t)cnt);
+        std::memcpy(t.values.data(), p + pos, (size_t)cnt * sizeof(double));
+        pos += (size_t)cnt * sizeof(double);
+        tables.push_back(std::move(t));
+    }
+    return pos == n;
+}
+
+std::string cache_entry_path(const Hash128 &key)
+{
+    char name[32];
+    std::snprintf(name, sizeof name, "%016llx", (unsigned long long)key.a);
     return cache_dir() + "/" + name + ".hsaco";
 }
 
-bool read_file(const std::string &path, std::vector<char> &out)
+// a verified hit, or false (missing, foreign, truncated or damaged entry)
+bool read_cache_entry(const std::string &path, const Hash128 &key, KernelBlob &blob)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
-    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
-    return !out.empty();
+    std::vector<char> all((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (all.size() < 64) return false;
+    const char *ft = all.data() + all.size() - 64;
+    uint64_t w[7];
+    std::memcpy(w, ft + 8, sizeof w);
+    if (std::memcmp(ft, CACHE_MAGIC, 8) != 0 || w[0] != key.a || w[1] != key.b) return false;
+    const uint64_t code_len = w[2], tab_len = w[3];
+    if (code_len == 0 || code_len > all.size() || tab_len > all.size() || code_len + tab_len + 64 != all.size()) return false;
+    Hasher h;
+    h.add(all.data(), (size_t)(code_len + tab_len));
+    const Hash128 sum = h.done();
+    if (sum.a != w[4] || sum.b != w[5]) return false;
+    if (!parse_tables(all.data() + code_len, (size_t)tab_len, blob.tables)) return false;
+    blob.code.assign(all.begin(), all.begin() + (std::ptrdiff_t)code_len);
+    (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);          // last use, for the eviction order (fails quietly on a read-only cache)
+    return true;
 }
 
-bool source_is_cached(const std::string &src, const std::string &arch)
+// The cache directory is bounded: QGS_HIP_CACHE_MAX_MB (default 2048; 0 = unbounded).  After a publish that takes it over the
+// bound the least recently used entries (hits refresh the modification time) are removed down to 80 % of it.
+void enforce_cache_limit(const std::string &dir, const std::string &keep)
 {
-    std::ifstream f(cache_path(src, arch, flags_for(src), compiler_id()), std::ios::binary);
-    return (bool)f;
+    double limit_mb = 2048.0;
+    if (const char *e = std::getenv("QGS_HIP_CACHE_MAX_MB")) limit_mb = std::atof(e);
+    if (!(limit_mb > 0.0)) return;
+    const double limit = limit_mb * 1048576.0;
+    DIR *d = opendir(dir.c_str());
+    if (!d) return;
+    struct Ent { double mtime; double size; std::string path; };
+    std::vector<Ent> ents;
+    double total = 0.0;
+    while (struct dirent *de = readdir(d)) {
+        const std::string name(de->d_name);
+        if (name.size() < 7 || name.compare(name.size() - 6, 6, ".hsaco") != 0) continue;
+        const std::string path = dir + "/" + name;
+        struct stat sb;
+        if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
+        ents.push_back({(double)sb.st_mtim.tv_sec + 1e-9 * (double)sb.st_mtim.tv_nsec, (double)sb.st_size, path});
+        total += (double)sb.st_size;
+    }
+    closedir(d);
+    if (total <= limit) return;
+    std::sort(ents.begin(), ents.end(), [](const Ent &x, const Ent &y) { return x.mtime < y.mtime; });
+    for (const Ent &e : ents) {
+        if (total <= 0.8 * limit) break;
+        if (e.path == keep) continue;
+        if (std::remove(e.path.c_str()) == 0) total -= e.size;
+    }
+}
+
+// Best effort: put the entry into the kernel cache (write next to the final name, then rename = atomic publish).  A
+// cache directory that is read-only (shared install) just means the next process compiles again.
+void publish_to_cache(const std::string &path, const Hash128 &key, const KernelBlob &blob)
+{
+    const std::string tab = serialise_tables(blob.tables);
+    Hasher h;
+    std::string payload(blob.code.begin(), blob.code.end());
+    payload += tab;
+    h.add(payload.data(), payload.size());
+    const Hash128 sum = h.done();
+    char footer[64];
+    std::memset(footer, 0, sizeof footer);
+    std::memcpy(footer, CACHE_MAGIC, 8);
+    const uint64_t w[7] = {key.a, key.b, (uint64_t)blob.code.size(), (uint64_t)tab.size(), sum.a, sum.b, 0};
+    std::memcpy(footer + 8, w, sizeof w);
+    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
+    {
+        std::ofstream f(tmp, std::ios::binary);
+        if (!f) return;
+        f.write(payload.data(), (std::streamsize)payload.size());
+        f.write(footer, sizeof footer);
+        f.close();
+        if (!f) { std::remove(tmp.c_str()); return; }
+    }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) { std::remove(tmp.c_str()); return; }
+    const size_t k = path.find_last_of('/');
+    enforce_cache_limit(k == std::string::npos ? std::string(".") : path.substr(0, k), path);
 }
 
 int compile_in_process(const std::string &src, const std::string &arch, const std::vector<std::string> &extra, std::vector<char> &code)
@@ -336,19 +488,12 @@ std::string make_temp(const std::string &suffix_hint)
     return std::string(buf.data());
 }
 
-// Best effort: put the code object into the kernel cache (write next to the final name, then rename = atomic publish).  A
-// cache directory that is read-only (shared install) just means the next process compiles again.
-void publish_to_cache(const std::string &path, const std::vector<char> &code)
+bool read_file(const std::string &path, std::vector<char> &out)
 {
-    const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
-    {
-        std::ofstream f(tmp, std::ios::binary);
-        if (!f) return;
-        f.write(code.data(), (std::streamsize)code.size());
-        f.close();
-        if (!f) { std::remove(tmp.c_str()); return; }
-    }
-    if (std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    out.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+    return !out.empty();
 }
 
 // Several processes that miss the same cache entry at the same time (8 ranks creating the same model on a cold cache)
@@ -372,55 +517,116 @@ struct CacheLock {
     }
 };
 
-int compile_source(const std::string &src, const std::string &arch, std::vector<char> &code, bool *from_cache)
+// source -> code object with the helper process.  0: done; 1: the helper is not usable (any more), *why says so; -1: a real
+// compile error (g_err holds the compiler's log)
+int compile_with_helper(const std::string &src, const std::string &arch, const std::vector<std::string> &extra, std::vector<char> &code,
+                        std::string *why)
 {
-    const std::vector<std::string> extra = flags_for(src);
-    CompilerChoice cc = compiler_choice();
-    std::string path = cache_path(src, arch, extra, cc.id);
-    if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }
-    CacheLock lock(path);
-    if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }      // somebody else compiled it meanwhile
-    if (from_cache) *from_cache = false;
-#ifdef QGS_HIP_DEV_KNOBS
-    if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // keep the generated source
-        std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
+    // source and object travel through private temp files under $TMPDIR, not through the cache directory
+    const std::string srcfile = make_temp("src"), objfile = make_temp("obj");
+    if (srcfile.empty() || objfile.empty()) *why = "cannot create temp files under " + scratch_dir();
+    if (why->empty()) {
+        std::ofstream f(srcfile, std::ios::binary);
         f << src;
+        f.close();
+        if (!f) *why = "cannot write " + srcfile;
     }
+    int rc = -1;
+    std::string out;
+    if (why->empty()) {
+        std::vector<std::string> args = {helper_path(), arch, srcfile, objfile};
+        args.insert(args.end(), extra.begin(), extra.end());
+        rc = run_helper(args, &out);
+        if (rc < 0) *why = "helper did not run to completion: " + out.substr(0, 400);
+    }
+    const bool got = (rc == 0) && read_file(objfile, code);
+    if (rc == 0 && !got) *why = "helper produced no code object";
+    if (!srcfile.empty()) std::remove(srcfile.c_str());
+    if (!objfile.empty()) std::remove(objfile.c_str());
+    if (rc == 1) { fail("kernel compilation failed (" + helper_path() + "):\n" + out.substr(0, 4000)); return -1; }    // a real compile error
+    return got ? 0 : 1;
+}
+
+// entries this process has already read or built: a second model of the same structure (the next point of a parameter sweep,
+// the other shards of a device group) costs neither a file read nor a generator run
+std::mutex g_memo_mutex;
+std::map<std::string, std::shared_ptr<const KernelBlob>> g_memo;
+
+// The blob of the kernel identified by `what` (everything that decides the code object except compiler and flags), through
+// memo -> disk cache -> generate + compile + publish.  `gen` is only called on a miss.  mode: Use (whatever serves the blob
+// fastest), Lookup (never compile: 1 when the entry exists nowhere), Publish (pre-build: the entry must also be on disk when
+// the call returns -- a memo hit whose file is gone, e.g. evicted or another cache directory, is written again).
+enum class BlobMode { Use, Lookup, Publish };
+int obtain_blob(const std::string &what, const std::string &arch, const std::vector<std::string> &kernel_flags,
+                const std::function<qgs::GeneratedKernel()> &gen, std::shared_ptr<const KernelBlob> *out, bool *from_cache,
+                BlobMode mode = BlobMode::Use)
+{
+    std::vector<std::string> extra = extra_flags();
+    extra.insert(extra.end(), kernel_flags.begin(), kernel_flags.end());
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const CompilerChoice cc = compiler_choice();
+        std::string key_text = "qgs-kernel-cache-v3|" QGS_CODEGEN_HASH "|" + arch + "|O3|c++17|" + cc.id;
+        for (const auto &x : extra) key_text += "|" + x;
+        key_text += "|" + what;
+        Hasher hk;
+        hk.add(key_text);
+        const Hash128 key = hk.done();
+        const std::string memo_key = key.hex();
+        const std::string path = cache_entry_path(key);
+        {
+            std::shared_ptr<const KernelBlob> hit;
+            {
+                std::lock_guard<std::mutex> lock(g_memo_mutex);
+                auto it = g_memo.find(memo_key);
+                if (it != g_memo.end()) hit = it->second;
+            }
+            if (hit) {
+                if (mode == BlobMode::Publish && access(path.c_str(), R_OK) != 0) publish_to_cache(path, key, *hit);
+                *out = hit;
+                if (from_cache) *from_cache = true;
+                return 0;
+            }
+        }
+        auto remember = [&](std::shared_ptr<KernelBlob> b) {
+            std::lock_guard<std::mutex> lock(g_memo_mutex);
+            if (g_memo.size() >= 1024) g_memo.clear();
+            g_memo[memo_key] = b;
+            *out = b;
+        };
+        auto blob = std::make_shared<KernelBlob>();
+        if (read_cache_entry(path, key, *blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }
+        if (mode == BlobMode::Lookup) return 1;
+        CacheLock lock(path);
+        if (read_cache_entry(path, key, *blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }   // somebody else compiled it meanwhile
+        if (from_cache) *from_cache = false;
+        qgs::GeneratedKernel g;
+        try {
+            g = gen();
+        } catch (const std::exception &e) {
+            return fail(std::string("kernel generator: ") + e.what());
+        }
+#ifdef QGS_HIP_DEV_KNOBS
+        if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // keep the generated source
+            std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
+            f << g.source;
+        }
 #endif
-    if (cc.helper) {
-        // source and object travel through private temp files under $TMPDIR, not through the cache directory
-        std::string why;
-        const std::string srcfile = make_temp("src"), objfile = make_temp("obj");
-        if (srcfile.empty() || objfile.empty()) why = "cannot create temp files under " + scratch_dir();
-        if (why.empty()) {
-            std::ofstream f(srcfile, std::ios::binary);
-            f << src;
-            f.close();
-            if (!f) why = "cannot write " + srcfile;
-        }
-        int rc = -1;
-        std::string out;
-        if (why.empty()) {
-            std::vector<std::string> args = {helper_path(), arch, srcfile, objfile};
-            args.insert(args.end(), extra.begin(), extra.end());
-            rc = run_helper(args, &out);
-            if (rc < 0) why = "helper did not run to completion: " + out.substr(0, 400);
-        }
-        const bool got = (rc == 0) && read_file(objfile, code);
-        if (rc == 0 && !got) why = "helper produced no code object";
-        if (!srcfile.empty()) std::remove(srcfile.c_str());
-        if (!objfile.empty()) std::remove(objfile.c_str());
-        if (rc == 1) return fail("kernel compilation failed (" + helper_path() + "):\n" + out.substr(0, 4000));    // a real compile error
-        if (got) { publish_to_cache(path, code); return 0; }
-        // the helper is not usable (any more): this process compiles in-process from here on, under that compiler's identity
-        disable_helper(why);
-        cc = compiler_choice();
-        path = cache_path(src, arch, extra, cc.id);
-        if (read_file(path, code)) { if (from_cache) *from_cache = true; return 0; }
+        if (cc.helper) {
+            std::string why;
+            const int rc = compile_with_helper(g.source, arch, extra, blob->code, &why);
+            if (rc < 0) return -1;
+            if (rc == 1) {
+                // the helper is not usable (any more): this process compiles in-process from here on, under that compiler's identity
+                disable_helper(why);
+                continue;
+            }
+        } else if (compile_in_process(g.source, arch, extra, blob->code)) return -1;
+        blob->tables = std::move(g.tables);
+        publish_to_cache(path, key, *blob);
+        remember(blob);
+        return 0;
     }
-    if (compile_in_process(src, arch, extra, code)) return -1;
-    publish_to_cache(path, code);
-    return 0;
+    return fail("no usable kernel compiler");
 }
 
 struct HostCsr {          // row-grouped tensor on the host, see generic_kernels.h DevTensor
@@ -528,6 +734,10 @@ struct qgs_model {
     std::string arch;
     std::vector<qgs::Term> T, J;  // terms of the specialised kernels; rank 5: over the derived-monomial index space (codegen.h)
     qgs::Derived der;
+    // what the kernel generator sees: the canonical forms of T and J (magnitude-class ids instead of values, codegen.h), and the
+    // hashes of those structures -- the model's part of the kernel-cache keys (a kernel reads one of the two tensors)
+    qgs::Canonical canon_t, canon_j;
+    Hash128 hash_t, hash_j;
     int64_t nnz_in = 0, jnnz_in = 0;
     DevCsr dT, dJ_by_i, dJ_by_j;
     // rank 5: the reduced tensors (two factors per term over variables + derived monomials) and the derived chains, for
@@ -578,7 +788,7 @@ struct qgs_model {
     // compiled specialised kernels, one module per kernel (keyed by the kernel name)
     std::map<std::string, hipModule_t> modules;
     std::map<std::string, hipFunction_t> functions;
-    std::string source_all;
+    std::vector<std::pair<qgs::Kernel, int>> loaded_kernels;      // (kind, stage count) of the specialised kernels loaded so far
     // staged time grid / tableau
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
@@ -810,6 +1020,50 @@ void free_csr(DevCsr &d)
     d = DevCsr();
 }
 
+// identity of kernel `k` of this model's structure in the kernel cache (obtain_blob adds compiler, flags, architecture)
+std::string kernel_key(const qgs_model *m, qgs::Kernel k, int S)
+{
+    return qgs::kernel_name(k, S, m->cg) + "|" + qgs::options_signature(m->cg) + "|ndim=" + std::to_string(m->ndim) + "|" +
+           (qgs::kernel_uses_jacobian(k) ? "J" + m->hash_j.hex() : "T" + m->hash_t.hex());
+}
+
+int model_blob(const qgs_model *m, qgs::Kernel k, int S, std::shared_ptr<const KernelBlob> *out, bool *from_cache, BlobMode mode = BlobMode::Use)
+{
+    return obtain_blob(kernel_key(m, k, S), m->arch, qgs::kernel_compile_flags(k),
+                       [&] { return qgs::generate_kernel(m->ndim, m->canon_t.terms, m->canon_j.terms, k, S, m->cg, m->der); }, out, from_cache,
+                       mode);
+}
+
+// Load a blob on the current device and store THIS model's coefficients into the module's tables.
+int load_blob(qgs_model *m, const std::string &fname, const KernelBlob &blob, const qgs::Canonical &canon, hipFunction_t *fn)
+{
+    hipModule_t mod;
+    HIPCHK(hipModuleLoadData(&mod, blob.code.data()));
+    m->modules[fname] = mod;
+    std::vector<double> values;
+    for (const qgs::CoefTable &t : blob.tables) {
+        hipDeviceptr_t dptr = nullptr;
+        size_t bytes = 0;
+        hipError_t e = hipModuleGetGlobal(&dptr, &bytes, mod, t.symbol.c_str());
+        if (e != hipSuccess) return fail("coefficient table " + t.symbol + " not found in its module: " + hipGetErrorString(e));
+        if (bytes != t.values.size() * sizeof(double))
+            return fail("coefficient table " + t.symbol + ": the module has " + std::to_string(bytes) + " bytes, the generator " +
+                        std::to_string(t.values.size() * sizeof(double)));
+        try {
+            canon.decode(t.values, values);
+        } catch (const std::exception &ex) {
+            return fail(std::string("coefficient table ") + t.symbol + ": " + ex.what());
+        }
+        HIPCHK(hipMemcpyHtoD(dptr, values.data(), bytes));
+    }
+    hipFunction_t f;
+    hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
+    if (e != hipSuccess) return fail("kernel " + fname + " not found in its module: " + hipGetErrorString(e));
+    m->functions[fname] = f;
+    *fn = f;
+    return 0;
+}
+
 // Make sure kernel `k` (for S stages) is generated, compiled (or fetched from the cache) and loaded.
 int get_function(qgs_model *m, qgs::Kernel k, int S, hipFunction_t *fn, std::string *name_out = nullptr)
 {
@@ -817,19 +1071,11 @@ int get_function(qgs_model *m, qgs::Kernel k, int S, hipFunction_t *fn, std::str
     if (name_out) *name_out = fname;
     auto it = m->functions.find(fname);
     if (it != m->functions.end()) { *fn = it->second; return 0; }
-    const std::string src = qgs::generate_kernel(m->ndim, m->T, m->J, k, S, m->cg, m->der);
-    std::vector<char> code;
+    std::shared_ptr<const KernelBlob> blob;
     bool cached = false;
-    if (compile_source(src, m->arch, code, &cached)) return -1;
-    hipModule_t mod;
-    HIPCHK(hipModuleLoadData(&mod, code.data()));
-    m->modules[fname] = mod;
-    m->source_all += src;
-    hipFunction_t f;
-    hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
-    if (e != hipSuccess) return fail("kernel " + fname + " not found in its module: " + hipGetErrorString(e));
-    m->functions[fname] = f;
-    *fn = f;
+    if (model_blob(m, k, S, &blob, &cached)) return -1;
+    if (load_blob(m, fname, *blob, qgs::kernel_uses_jacobian(k) ? m->canon_j : m->canon_t, fn)) return -1;
+    m->loaded_kernels.push_back({k, S});
     return 0;
 }
 
@@ -976,8 +1222,10 @@ bool lds_kernel_wanted(const qgs_model *m, qgs::Kernel k, double work)
     const std::string name = qgs::kernel_name(k, 0, m->cg);
     if (m->functions.count(name)) return true;                                              // already loaded
     auto it = m->lds_on_disk.find(name);
-    if (it == m->lds_on_disk.end())
-        it = m->lds_on_disk.emplace(name, source_is_cached(qgs::generate_kernel(m->ndim, m->T, m->J, k, 0, m->cg, m->der), m->arch)).first;
+    if (it == m->lds_on_disk.end()) {
+        std::shared_ptr<const KernelBlob> blob;
+        it = m->lds_on_disk.emplace(name, model_blob(m, k, 0, &blob, nullptr, BlobMode::Lookup) == 0).first;      // looks, never compiles
+    }
     if (it->second) return true;                                                            // built earlier (qgs_prebuild / a previous run)
     return work >= 2e12;                                                                    // ~10 s of the generic kernels
 }
@@ -1130,6 +1378,22 @@ static int load_tensors(qgs_model *m, int rank, int64_t nnz, const int32_t *coo,
     if (!read(jnnz, jcoo, jval, jr, true)) return fail("jacobian coordinate out of range");
     qgs::reduce_polynomial(ndim, rank, nnz, coo, val, false, m->T, m->der.t);
     qgs::reduce_polynomial(ndim, rank, jnnz, jcoo, jval, true, m->J, m->der.j);
+    qgs::canonicalize(m->T, m->canon_t);
+    qgs::canonicalize(m->J, m->canon_j);
+    auto structure_hash = [&](const qgs::Canonical &c, const std::vector<std::pair<int, int>> &der) {
+        Hasher h;
+        const int64_t head[4] = {ndim, rank, (int64_t)c.terms.size(), (int64_t)der.size()};
+        h.add(head, sizeof head);
+        for (const qgs::Term &t : c.terms) {
+            const int32_t q[3] = {t.i, t.j, t.k};
+            h.add(q, sizeof q);
+            h.add(&t.v, sizeof t.v);
+        }
+        for (const auto &pr : der) { const int32_t q[2] = {pr.first, pr.second}; h.add(q, sizeof q); }
+        return h.done();
+    };
+    m->hash_t = structure_hash(m->canon_t, m->der.t);
+    m->hash_j = structure_hash(m->canon_j, m->der.j);
     m->rank = rank;
     m->nnz_in = nnz;
     m->jnnz_in = jnnz;
@@ -1265,8 +1529,16 @@ int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen, int *vg
 int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen)
 {
     if (!m) return -1;
-    std::string src = m->source_all;
-    if (src.empty() && m->spec_possible) src = qgs::generate_kernel(m->ndim, m->T, m->J, qgs::Kernel::Tend, 0, m->cg, m->der);
+    // generated again on request (cache hits never run the generator): the value-free source of every specialised kernel loaded so far
+    std::string src;
+    try {
+        for (const auto &ks : m->loaded_kernels)
+            src += qgs::generate_kernel(m->ndim, m->canon_t.terms, m->canon_j.terms, ks.first, ks.second, m->cg, m->der).source;
+        if (src.empty() && m->spec_possible)
+            src = qgs::generate_kernel(m->ndim, m->canon_t.terms, m->canon_j.terms, qgs::Kernel::Tend, 0, m->cg, m->der).source;
+    } catch (const std::exception &) {
+        return -1;
+    }
     if (buf && buflen > 0) {
         const size_t n = std::min<size_t>(src.size(), (size_t)buflen - 1);
         std::memcpy(buf, src.data(), n);
@@ -1658,15 +1930,10 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         auto it = m->functions.find(fname);
         if (it != m->functions.end()) f = it->second;
         else {
-            std::vector<char> code;
+            std::shared_ptr<const KernelBlob> blob;
             bool cached = false;
-            if (compile_source(qgs::generate_qr_kernel(n_rows, n_cols), m->arch, code, &cached)) return -1;
-            hipModule_t mod;
-            HIPCHK(hipModuleLoadData(&mod, code.data()));
-            m->modules[fname] = mod;
-            hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
-            if (e != hipSuccess) return fail("kernel " + fname + " not found in its module: " + hipGetErrorString(e));
-            m->functions[fname] = f;
+            if (obtain_blob(fname, m->arch, {}, [&] { return qgs::generate_qr_kernel(n_rows, n_cols); }, &blob, &cached)) return -1;
+            if (load_blob(m, fname, *blob, m->canon_t, &f)) return -1;          // (no tables)
         }
         long long nt = n_traj, l = ld;
         void *args[] = {(void *)&d_a, (void *)&d_rdiag, &nt, &l};
@@ -2329,19 +2596,22 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     if (rank == 5) m.cg.row_split = 1;
     std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
     classify_model(&m);
-    if (m.lds_spec_possible) {
-        std::vector<char> code;
+    auto build = [&](qgs::Kernel k, int S) {
+        if (!prebuild_mine()) return 0;
+        std::shared_ptr<const KernelBlob> blob;
         bool cached;
-        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
-        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::TendLds, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+        return model_blob(&m, k, S, &blob, &cached, BlobMode::Publish);
+    };
+    if (m.lds_spec_possible) {
+        if (build(qgs::Kernel::RkLds, 0) || build(qgs::Kernel::TendLds, 0)) return -1;
         for (int S : stages)
             if (S >= 3) {                                   // some 3+-stage scheme requested: also the general-tableau flavour
-                if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, qgs::Kernel::RkLdsDense, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+                if (build(qgs::Kernel::RkLdsDense, 0)) return -1;
                 break;
             }
         if (!m.J.empty() && !m.spec_jac_possible && lds_tgl_bytes(&m) <= (size_t)QGS_LDS_STATE_BYTES)
             for (qgs::Kernel k : {qgs::Kernel::TglLds, qgs::Kernel::AdjLds})
-                if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, k, 0, m.cg, m.der), m.arch, code, &cached)) return -1;
+                if (build(k, 0)) return -1;
     }
     if (!m.spec_possible || m.prefer_lds) return 0;       // prefer_lds: the register-resident kernels would only spill (and take minutes to compile)
     const bool jac_spec = !m.J.empty() && m.spec_jac_possible;
@@ -2353,21 +2623,19 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
             list.push_back({qgs::Kernel::RkDense, S});
             if (jac_spec) list.push_back({qgs::Kernel::TglDense, S});
         }
-    for (auto &ks : list) {
-        std::vector<char> code;
-        bool cached;
-        if (prebuild_mine() && compile_source(qgs::generate_kernel(m.ndim, m.T, m.J, ks.first, ks.second, m.cg, m.der), m.arch, code, &cached)) return -1;
-    }
+    for (auto &ks : list)
+        if (build(ks.first, ks.second)) return -1;
     return 0;
 }
 
 int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
 {
     if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 64");
-    std::vector<char> code;
-    bool cached;
     if (!prebuild_mine()) return 0;
-    return compile_source(qgs::generate_qr_kernel(n_rows, n_cols), (arch && *arch) ? arch : target_arch(-1), code, &cached);
+    std::shared_ptr<const KernelBlob> blob;
+    bool cached;
+    return obtain_blob("qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols), (arch && *arch) ? arch : target_arch(-1), {},
+                       [&] { return qgs::generate_qr_kernel(n_rows, n_cols); }, &blob, &cached, BlobMode::Publish);
 }
 
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
