@@ -184,6 +184,14 @@ int qgs_pack_tangent(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, con
 /* R[n_records][ndim][ld]  ->  (n_traj, ndim, n_records) */
 int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records,
                        const double *d_rec_modes, double *d_rec_rows, void *stream);
+/* One WINDOW of mode-major records into the record block of the whole run: d_window holds n_window consecutive records
+ * R[w][n_inner][ld]; dst is the (n_traj, n_inner, n_records) block in the reference's layout (the host array the reference's
+ * loops fill record by record, qgs/toolbox/lyapunov.py:232-358, qgs/integrators/integrate.py:196-223) and receives records
+ * [first_record, first_record + n_window).  dst may be device memory or page-locked host memory (qgs_host_register: written
+ * by the kernel's own stores) or pageable host memory (staged on the device, then copied).  Enqueued on `stream`: the
+ * window may be overwritten by work enqueued behind it. */
+int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
+                      int64_t first_record, const double *d_window, double *dst, void *stream);
 
 int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x, double *d_dx, void *stream);
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     'qgs_unpack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_pack_tangent': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_records': (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_unpack_window': (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_tendencies_device': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_rk_integrate_device': (_int, [_vp, _i64, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp, _vp]),
     'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
@@ -396,6 +397,12 @@ class HipModel(object):
 
     def unpack_records(self, n_traj, ld, n_inner, nrec, d_in, d_out, stream=0):
         _check(lib().qgs_unpack_records(self._h, n_traj, ld, n_inner, nrec, d_in, d_out, stream or None))
+
+    def unpack_window(self, n_traj, ld, n_inner, n_window, nrec, first_record, d_window, dst, stream=0):
+        """Records [first_record, first_record + n_window) of a (n_traj, n_inner, nrec) block `dst` (device pointer, or host
+        pointer -- page-locked or pageable) from a mode-major window of records on the device."""
+        _check(lib().qgs_unpack_window(self._h, n_traj, ld, int(n_inner), int(n_window), int(nrec), int(first_record), d_window, dst,
+                                       stream or None))
 
     def tendencies_device(self, n_traj, ld, d_x, d_dx, stream=0):
         _check(lib().qgs_tendencies_device(self._h, n_traj, ld, d_x, d_dx, stream or None))

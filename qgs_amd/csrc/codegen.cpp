@@ -1830,8 +1830,14 @@ GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const
     } tables_guard(&gen.tables);
     std::ostringstream o;
     o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
-    o << "// ndim = " << ndim << ", nnz = " << tensor.size() << ", jac nnz = " << jac_tensor.size() << "\n";
-    if (!der.empty()) o << "// derived monomials: " << der.t.size() << " (tendencies), " << der.j.size() << " (Jacobian)\n";
+    // (only what this kernel is generated from: a kernel of the tendencies tensor is the same text whatever the Jacobian tensor is)
+    if (kernel_uses_jacobian(k)) {
+        o << "// ndim = " << ndim << ", Jacobian tensor: " << jac_tensor.size() << " entries\n";
+        if (!der.j.empty()) o << "// derived monomials: " << der.j.size() << "\n";
+    } else {
+        o << "// ndim = " << ndim << ", tendencies tensor: " << tensor.size() << " entries\n";
+        if (!der.t.empty()) o << "// derived monomials: " << der.t.size() << "\n";
+    }
     const std::vector<Row> rows = build_rows(ndim, tensor);
     struct BaseGuard { int old; BaseGuard(int b) : old(g_ext_base) { g_ext_base = b; } ~BaseGuard() { g_ext_base = old; } } guard(ndim);
     switch (k) {

@@ -2,12 +2,43 @@
 #include "generic_kernels.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace qgs {
 
 namespace {
 
 constexpr int WAVE = 64;
+
+// Largest dynamic-LDS size a kernel has been configured for (hipFuncAttributeMaxDynamicSharedMemorySize), per device and
+// guarded: models of one process live on several GPUs and are driven by one host thread each (qgs_group, Lyapunov shards).
+struct DynLdsLimit {
+    static constexpr int MAX_DEVICES = 64;
+    size_t configured[MAX_DEVICES];
+    std::mutex mutex;
+    explicit DynLdsLimit(size_t initial = 0) { for (size_t &c : configured) c = initial; }
+    static int device()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+        return d;
+    }
+    // beyond MAX_DEVICES devices nothing is remembered: the attribute is set on every launch that needs more than the default
+    bool needs(size_t lds)
+    {
+        const int d = device();
+        if (d >= MAX_DEVICES) return lds > 64 * 1024;
+        std::lock_guard<std::mutex> lock(mutex);
+        return lds > configured[d];
+    }
+    void set(size_t lds)
+    {
+        const int d = device();
+        if (d >= MAX_DEVICES) return;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (lds > configured[d]) configured[d] = lds;
+    }
+};
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
@@ -395,11 +426,13 @@ hipError_t launch_tiled(const TiledTensor &T, const RkArgs &p, const double *y_i
                         const double *dtime, const double *tab, hipStream_t st)
 {
     const size_t lds = (size_t)(p.ndim + 1) * 512;
-    static size_t configured = 0;
-    if (lds > configured) {
+    // The raised dynamic-LDS limit is remembered per device (a process may hold models on several GPUs: device groups, the
+    // shards of the Lyapunov estimator, each driven by its own thread) -- the attribute is set on the current device.
+    static DynLdsLimit configured;
+    if (configured.needs(lds)) {
         hipError_t e = hipFuncSetAttribute((const void *)gen_rk_tiled_kernel<RPW, TPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        configured = lds;
+        configured.set(lds);
     }
     hipLaunchKernelGGL((gen_rk_tiled_kernel<RPW, TPI>), dim3(blocks_for(p.n_traj, WAVE)), dim3(64 * TILED_NW), lds, st, T, p, y_in, y_out,
                        rec, stages, dtime, tab);
@@ -1182,10 +1215,10 @@ void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st)
 {
     const size_t lds = sizeof(double) * (size_t)n_rows * QR_STRIDE;
-    static size_t configured = 64 * 1024;
-    if (lds > configured) {
+    static DynLdsLimit configured(64 * 1024);          // per device, see launch_tiled
+    if (configured.needs(lds)) {
         if (hipFuncSetAttribute((const void *)batched_qr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            configured = lds;
+            configured.set(lds);
     }
     hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag);
 }

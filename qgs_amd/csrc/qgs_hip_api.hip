@@ -300,23 +300,31 @@ void disable_helper(const std::string &why)
 }
 
 // ---- kernel cache --------------------------------------------------------------------------------------------------------------
-// A cache entry is what one (kernel kind, tensor STRUCTURE, generator, compiler, flags) compiles to: the code object plus the
-// layout of its coefficient tables in canonical form (magnitude-class ids, codegen.h Canonical).  Coefficient values are not
-// part of it: every model fills the tables of its own loaded module with its own values, so a parameter sweep over one model
-// shares one set of entries -- as the reference compiles sparse_mul3 once whatever `val` holds (sparse_mul.py:48-81).
+// Coefficient values are never part of a cache entry: every model fills the tables of its own loaded module with its own
+// values, so a parameter sweep over one model shares its entries -- as the reference compiles sparse_mul3 once whatever `val`
+// holds (sparse_mul.py:48-81).  Two kinds of entries, both named by the first 64 bits of a 128-bit key:
 //
-// File <first 64 key bits>.hsaco = code object | tables | 64-byte footer.  The code object comes first, so the file still reads
-// as an ELF (llvm-objdump works on it); the footer carries the full 128-bit key, both lengths and a 128-bit hash of the
-// payload: a file that is truncated, damaged or belongs to a colliding key is not a hit, it is recompiled and replaced.
+//   <structure key>.qgst   what one (kernel kind, tensor STRUCTURE, generator options) needs besides code: the layout of its
+//                          coefficient tables in canonical form (magnitude-class ids, codegen.h Canonical) and the key of its
+//                          code object.  The structure key is computed from the canonical tensor alone: a hit costs no
+//                          generator run (0.9 s per kernel at ndim 228).
+//   <code key>.hsaco       the code object of one generated SOURCE (+ compiler, flags, architecture).  Different structures
+//                          often generate the same source -- a coincidence of two magnitudes only changes the source when
+//                          the generator exploits it (same row, same de-duplication window) -- and then share the object.
+//
+// Files: payload | 64-byte footer (magic, own 128-bit key, payload length, 128-bit payload hash, and for a structure entry the
+// code key).  A code entry starts with the ELF, so llvm-objdump reads it as it is.  A file that is truncated, damaged or
+// belongs to a colliding key is not a hit: it is rebuilt and replaced.
 struct KernelBlob {
-    std::vector<char> code;
+    std::shared_ptr<const std::vector<char>> code;
     std::vector<qgs::CoefTable> tables;
 };
 
 #ifndef QGS_CODEGEN_HASH
 #define QGS_CODEGEN_HASH "unversioned"      // the Makefile passes a hash of codegen.cpp + codegen.h: a changed generator never hits old entries
 #endif
-const char CACHE_MAGIC[8] = {'Q', 'G', 'S', 'K', 'C', '0', '0', '1'};
+const char CODE_MAGIC[8] = {'Q', 'G', 'S', 'K', 'C', '0', '0', '2'};
+const char STRUCT_MAGIC[8] = {'Q', 'G', 'S', 'K', 'T', '0', '0', '2'};
 
 std::string serialise_tables(const std::vector<qgs::CoefTable> &tables)
 {
@@ -354,15 +362,15 @@ bool parse_tables(const char *p, size_t n, std::vector<qgs::CoefTable> &tables)
     return pos == n;
 }
 
-std::string cache_entry_path(const Hash128 &key)
+std::string cache_entry_path(const Hash128 &key, const char *ext)
 {
     char name[32];
     std::snprintf(name, sizeof name, "%016llx", (unsigned long long)key.a);
-    return cache_dir() + "/" + name + ".hsaco";
+    return cache_dir() + "/" + name + ext;
 }
 
-// a verified hit, or false (missing, foreign, truncated or damaged entry)
-bool read_cache_entry(const std::string &path, const Hash128 &key, KernelBlob &blob)
+// payload of a verified entry (magic, key, length and payload hash all match), or false; *link: the second key of the footer
+bool read_cache_file(const std::string &path, const char *magic, const Hash128 &key, std::vector<char> &payload, Hash128 *link)
 {
     std::ifstream f(path, std::ios::binary);
     if (!f) return false;
@@ -371,15 +379,15 @@ bool read_cache_entry(const std::string &path, const Hash128 &key, KernelBlob &b
     const char *ft = all.data() + all.size() - 64;
     uint64_t w[7];
     std::memcpy(w, ft + 8, sizeof w);
-    if (std::memcmp(ft, CACHE_MAGIC, 8) != 0 || w[0] != key.a || w[1] != key.b) return false;
-    const uint64_t code_len = w[2], tab_len = w[3];
-    if (code_len == 0 || code_len > all.size() || tab_len > all.size() || code_len + tab_len + 64 != all.size()) return false;
+    if (std::memcmp(ft, magic, 8) != 0 || w[0] != key.a || w[1] != key.b) return false;
+    if (w[2] + 64 != all.size()) return false;
     Hasher h;
-    h.add(all.data(), (size_t)(code_len + tab_len));
+    h.add(all.data(), (size_t)w[2]);
     const Hash128 sum = h.done();
-    if (sum.a != w[4] || sum.b != w[5]) return false;
-    if (!parse_tables(all.data() + code_len, (size_t)tab_len, blob.tables)) return false;
-    blob.code.assign(all.begin(), all.begin() + (std::ptrdiff_t)code_len);
+    if (sum.a != w[3] || sum.b != w[4]) return false;
+    if (link) { link->a = w[5]; link->b = w[6]; }
+    all.resize((size_t)w[2]);
+    payload.swap(all);
     (void)utimensat(AT_FDCWD, path.c_str(), nullptr, 0);          // last use, for the eviction order (fails quietly on a read-only cache)
     return true;
 }
@@ -397,9 +405,10 @@ void enforce_cache_limit(const std::string &dir, const std::string &keep)
     struct Ent { double mtime; double size; std::string path; };
     std::vector<Ent> ents;
     double total = 0.0;
+    auto ends_with = [](const std::string &s, const char *e) { const size_t n = std::strlen(e); return s.size() > n && s.compare(s.size() - n, n, e) == 0; };
     while (struct dirent *de = readdir(d)) {
         const std::string name(de->d_name);
-        if (name.size() < 7 || name.compare(name.size() - 6, 6, ".hsaco") != 0) continue;
+        if (!ends_with(name, ".hsaco") && !ends_with(name, ".qgst")) continue;
         const std::string path = dir + "/" + name;
         struct stat sb;
         if (stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode)) continue;
@@ -416,26 +425,23 @@ void enforce_cache_limit(const std::string &dir, const std::string &keep)
     }
 }
 
-// Best effort: put the entry into the kernel cache (write next to the final name, then rename = atomic publish).  A
-// cache directory that is read-only (shared install) just means the next process compiles again.
-void publish_to_cache(const std::string &path, const Hash128 &key, const KernelBlob &blob)
+// Best effort: put an entry into the kernel cache (write next to the final name, then rename = atomic publish).  A
+// cache directory that is read-only (shared install) just means the next process builds it again.
+void publish_cache_file(const std::string &path, const char *magic, const Hash128 &key, const char *payload, size_t n, const Hash128 &link)
 {
-    const std::string tab = serialise_tables(blob.tables);
     Hasher h;
-    std::string payload(blob.code.begin(), blob.code.end());
-    payload += tab;
-    h.add(payload.data(), payload.size());
+    h.add(payload, n);
     const Hash128 sum = h.done();
     char footer[64];
     std::memset(footer, 0, sizeof footer);
-    std::memcpy(footer, CACHE_MAGIC, 8);
-    const uint64_t w[7] = {key.a, key.b, (uint64_t)blob.code.size(), (uint64_t)tab.size(), sum.a, sum.b, 0};
+    std::memcpy(footer, magic, 8);
+    const uint64_t w[7] = {key.a, key.b, (uint64_t)n, sum.a, sum.b, link.a, link.b};
     std::memcpy(footer + 8, w, sizeof w);
     const std::string tmp = path + ".tmp" + std::to_string((long)getpid());
     {
         std::ofstream f(tmp, std::ios::binary);
         if (!f) return;
-        f.write(payload.data(), (std::streamsize)payload.size());
+        f.write(payload, (std::streamsize)n);
         f.write(footer, sizeof footer);
         f.close();
         if (!f) { std::remove(tmp.c_str()); return; }
@@ -550,12 +556,27 @@ int compile_with_helper(const std::string &src, const std::string &arch, const s
 // entries this process has already read or built: a second model of the same structure (the next point of a parameter sweep,
 // the other shards of a device group) costs neither a file read nor a generator run
 std::mutex g_memo_mutex;
-std::map<std::string, std::shared_ptr<const KernelBlob>> g_memo;
+std::map<std::string, std::shared_ptr<const KernelBlob>> g_memo;                 // structure key -> blob
+std::map<std::string, std::shared_ptr<const std::vector<char>>> g_code_memo;     // code key -> code object
 
-// The blob of the kernel identified by `what` (everything that decides the code object except compiler and flags), through
-// memo -> disk cache -> generate + compile + publish.  `gen` is only called on a miss.  mode: Use (whatever serves the blob
-// fastest), Lookup (never compile: 1 when the entry exists nowhere), Publish (pre-build: the entry must also be on disk when
-// the call returns -- a memo hit whose file is gone, e.g. evicted or another cache directory, is written again).
+std::shared_ptr<const std::vector<char>> code_memo_get(const std::string &k)
+{
+    std::lock_guard<std::mutex> lock(g_memo_mutex);
+    auto it = g_code_memo.find(k);
+    return it == g_code_memo.end() ? nullptr : it->second;
+}
+void code_memo_put(const std::string &k, std::shared_ptr<const std::vector<char>> c)
+{
+    std::lock_guard<std::mutex> lock(g_memo_mutex);
+    if (g_code_memo.size() >= 1024) g_code_memo.clear();
+    g_code_memo[k] = c;
+}
+
+// The blob of the kernel identified by `what` (everything that decides the generated source: kernel kind, generator options,
+// canonical tensor), through memo -> structure entry + code entry on disk -> generate (+ compile) + publish.  `gen` is only
+// called when the structure is new to the cache.  mode: Use (whatever serves the blob fastest), Lookup (never generate or
+// compile: 1 when the entry exists nowhere), Publish (pre-build: both entries must also be on disk when the call returns -- a
+// memo hit whose files are gone, e.g. evicted or another cache directory, is written again).
 enum class BlobMode { Use, Lookup, Publish };
 int obtain_blob(const std::string &what, const std::string &arch, const std::vector<std::string> &kernel_flags,
                 const std::function<qgs::GeneratedKernel()> &gen, std::shared_ptr<const KernelBlob> *out, bool *from_cache,
@@ -565,14 +586,24 @@ int obtain_blob(const std::string &what, const std::string &arch, const std::vec
     extra.insert(extra.end(), kernel_flags.begin(), kernel_flags.end());
     for (int attempt = 0; attempt < 2; ++attempt) {
         const CompilerChoice cc = compiler_choice();
-        std::string key_text = "qgs-kernel-cache-v3|" QGS_CODEGEN_HASH "|" + arch + "|O3|c++17|" + cc.id;
-        for (const auto &x : extra) key_text += "|" + x;
-        key_text += "|" + what;
+        std::string common = "qgs-kernel-cache-v4|" QGS_CODEGEN_HASH "|" + arch + "|O3|c++17|" + cc.id;
+        for (const auto &x : extra) common += "|" + x;
         Hasher hk;
-        hk.add(key_text);
-        const Hash128 key = hk.done();
-        const std::string memo_key = key.hex();
-        const std::string path = cache_entry_path(key);
+        hk.add(common);
+        hk.add(what);
+        const Hash128 skey = hk.done();
+        const std::string memo_key = skey.hex();
+        const std::string spath = cache_entry_path(skey, ".qgst");
+        auto code_key_of = [&](const std::string &source) {
+            Hasher h;
+            h.add(common);
+            h.add(source);
+            return h.done();
+        };
+        auto publish_struct = [&](const KernelBlob &b, const Hash128 &ckey) {
+            const std::string tab = serialise_tables(b.tables);
+            publish_cache_file(spath, STRUCT_MAGIC, skey, tab.data(), tab.size(), ckey);
+        };
         {
             std::shared_ptr<const KernelBlob> hit;
             {
@@ -580,49 +611,79 @@ int obtain_blob(const std::string &what, const std::string &arch, const std::vec
                 auto it = g_memo.find(memo_key);
                 if (it != g_memo.end()) hit = it->second;
             }
-            if (hit) {
-                if (mode == BlobMode::Publish && access(path.c_str(), R_OK) != 0) publish_to_cache(path, key, *hit);
-                *out = hit;
-                if (from_cache) *from_cache = true;
-                return 0;
-            }
+            if (hit && mode == BlobMode::Publish && access(spath.c_str(), R_OK) != 0) hit = nullptr;     // rebuilt (below) into this directory
+            if (hit) { *out = hit; if (from_cache) *from_cache = true; return 0; }
         }
         auto remember = [&](std::shared_ptr<KernelBlob> b) {
             std::lock_guard<std::mutex> lock(g_memo_mutex);
-            if (g_memo.size() >= 1024) g_memo.clear();
+            if (g_memo.size() >= 4096) g_memo.clear();
             g_memo[memo_key] = b;
             *out = b;
         };
+        // structure entry -> code entry
+        auto try_disk = [&](std::shared_ptr<KernelBlob> blob) {
+            std::vector<char> tab;
+            Hash128 ckey;
+            if (!read_cache_file(spath, STRUCT_MAGIC, skey, tab, &ckey)) return false;
+            if (!parse_tables(tab.data(), tab.size(), blob->tables)) return false;
+            blob->code = code_memo_get(ckey.hex());
+            if (!blob->code) {
+                auto code = std::make_shared<std::vector<char>>();
+                if (!read_cache_file(cache_entry_path(ckey, ".hsaco"), CODE_MAGIC, ckey, *code, nullptr)) return false;
+                blob->code = code;
+                code_memo_put(ckey.hex(), code);
+            } else if (mode == BlobMode::Publish && access(cache_entry_path(ckey, ".hsaco").c_str(), R_OK) != 0) {
+                publish_cache_file(cache_entry_path(ckey, ".hsaco"), CODE_MAGIC, ckey, blob->code->data(), blob->code->size(), Hash128());
+            }
+            return true;
+        };
         auto blob = std::make_shared<KernelBlob>();
-        if (read_cache_entry(path, key, *blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }
+        if (try_disk(blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }
         if (mode == BlobMode::Lookup) return 1;
-        CacheLock lock(path);
-        if (read_cache_entry(path, key, *blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }   // somebody else compiled it meanwhile
-        if (from_cache) *from_cache = false;
+        CacheLock slock(spath);
+        if (try_disk(blob)) { remember(blob); if (from_cache) *from_cache = true; return 0; }   // somebody else built it meanwhile
         qgs::GeneratedKernel g;
         try {
             g = gen();
         } catch (const std::exception &e) {
             return fail(std::string("kernel generator: ") + e.what());
         }
-#ifdef QGS_HIP_DEV_KNOBS
-        if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // keep the generated source
-            std::ofstream f(std::string(d) + "/" + path.substr(path.find_last_of('/') + 1) + ".hip");
-            f << g.source;
-        }
-#endif
-        if (cc.helper) {
-            std::string why;
-            const int rc = compile_with_helper(g.source, arch, extra, blob->code, &why);
-            if (rc < 0) return -1;
-            if (rc == 1) {
-                // the helper is not usable (any more): this process compiles in-process from here on, under that compiler's identity
-                disable_helper(why);
-                continue;
-            }
-        } else if (compile_in_process(g.source, arch, extra, blob->code)) return -1;
         blob->tables = std::move(g.tables);
-        publish_to_cache(path, key, *blob);
+        // the code object of this source: memo -> disk -> compile
+        const Hash128 ckey = code_key_of(g.source);
+        const std::string cpath = cache_entry_path(ckey, ".hsaco");
+        blob->code = code_memo_get(ckey.hex());
+        if (blob->code && mode == BlobMode::Publish && access(cpath.c_str(), R_OK) != 0)
+            publish_cache_file(cpath, CODE_MAGIC, ckey, blob->code->data(), blob->code->size(), Hash128());
+        if (!blob->code) {
+            CacheLock clock(cpath);
+            auto code = std::make_shared<std::vector<char>>();
+            if (read_cache_file(cpath, CODE_MAGIC, ckey, *code, nullptr)) {
+                if (from_cache) *from_cache = true;
+            } else {
+                if (from_cache) *from_cache = false;
+#ifdef QGS_HIP_DEV_KNOBS
+                if (const char *d = std::getenv("QGS_HIP_DUMP_SRC")) {          // keep the generated source
+                    std::ofstream f(std::string(d) + "/" + cpath.substr(cpath.find_last_of('/') + 1) + ".hip");
+                    f << g.source;
+                }
+#endif
+                if (cc.helper) {
+                    std::string why;
+                    const int rc = compile_with_helper(g.source, arch, extra, *code, &why);
+                    if (rc < 0) return -1;
+                    if (rc == 1) {
+                        // the helper is not usable (any more): this process compiles in-process from here on, under that compiler's identity
+                        disable_helper(why);
+                        continue;
+                    }
+                } else if (compile_in_process(g.source, arch, extra, *code)) return -1;
+                publish_cache_file(cpath, CODE_MAGIC, ckey, code->data(), code->size(), Hash128());
+            }
+            blob->code = code;
+            code_memo_put(ckey.hex(), code);
+        } else if (from_cache) *from_cache = true;
+        publish_struct(*blob, ckey);
         remember(blob);
         return 0;
     }
@@ -686,6 +747,49 @@ struct Buffer {           // grow-only device scratch
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     double *f64() const { return (double *)p; }
+};
+
+// Small host-to-device uploads that must not stall the caller (the directed time grid and the tableau of every integration
+// call; the Benettin loop makes one such call per re-orthonormalisation interval): the source is copied into a slot of a ring
+// of page-locked blocks and leaves from there, so the copy is truly asynchronous, its source stays valid whatever the caller
+// does with its own memory, and the host only ever waits for the upload made N uploads ago.
+struct UploadRing {
+    static const int N = 16;
+    void *slot[N];
+    size_t cap[N];
+    hipEvent_t ev[N];
+    bool used[N];
+    unsigned next = 0;
+    int last = -1;
+    UploadRing() { for (int i = 0; i < N; ++i) { slot[i] = nullptr; cap[i] = 0; ev[i] = nullptr; used[i] = false; } }
+    int stage(const void *src, size_t bytes, void *dst_dev, hipStream_t st)
+    {
+        const int i = (int)(next++ % N);
+        if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        if (used[i]) HIPCHK(hipEventSynchronize(ev[i]));
+        if (cap[i] < bytes) {
+            if (slot[i]) (void)hipHostFree(slot[i]);
+            slot[i] = nullptr;
+            cap[i] = 0;
+            const size_t want = std::max<size_t>(bytes, 4096);
+            HIPCHK(hipHostMalloc(&slot[i], want, hipHostMallocDefault));
+            cap[i] = want;
+        }
+        std::memcpy(slot[i], src, bytes);
+        HIPCHK(hipMemcpyAsync(dst_dev, slot[i], bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(ev[i], st));
+        used[i] = true;
+        last = i;
+        return 0;
+    }
+    void release()
+    {
+        for (int i = 0; i < N; ++i) {
+            if (ev[i]) { if (used[i]) (void)hipEventSynchronize(ev[i]); (void)hipEventDestroy(ev[i]); }
+            if (slot[i]) (void)hipHostFree(slot[i]);
+            slot[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false;
+        }
+    }
 };
 
 struct KernelInfo {
@@ -789,11 +893,14 @@ struct qgs_model {
     std::map<std::string, hipModule_t> modules;
     std::map<std::string, hipFunction_t> functions;
     std::vector<std::pair<qgs::Kernel, int>> loaded_kernels;      // (kind, stage count) of the specialised kernels loaded so far
-    // staged time grid / tableau
+    // staged time grid / tableau (uploads go through a ring of page-locked blocks; a stream other than the one of the last
+    // upload waits for that upload's event before it reuses the staged tables)
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
+    UploadRing uploads;
+    hipStream_t tab_stream = nullptr;
     // scratch
-    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit, b_carry, b_win[2], b_fwin[2];
+    Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit, b_carry, b_win[2], b_fwin[2], b_drain;
     // host-layout pipeline: compute stream, copy stream, "window k computed" / "window k drained" events (created on first use)
     hipStream_t st_comp = nullptr, st_copy = nullptr;
     hipEvent_t ev_comp[2] = {nullptr, nullptr}, ev_copy[2] = {nullptr, nullptr};
@@ -1038,7 +1145,7 @@ int model_blob(const qgs_model *m, qgs::Kernel k, int S, std::shared_ptr<const K
 int load_blob(qgs_model *m, const std::string &fname, const KernelBlob &blob, const qgs::Canonical &canon, hipFunction_t *fn)
 {
     hipModule_t mod;
-    HIPCHK(hipModuleLoadData(&mod, blob.code.data()));
+    HIPCHK(hipModuleLoadData(&mod, blob.code->data()));
     m->modules[fname] = mod;
     std::vector<double> values;
     for (const qgs::CoefTable &t : blob.tables) {
@@ -1117,22 +1224,26 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
 {
     std::vector<double> dt(time, time + n_time);
     if (direction == -1) std::reverse(dt.begin(), dt.end());
-    if (dt != m->h_time) {
-        if (m->d_time.ensure(sizeof(double) * (size_t)n_time)) return -1;
-        // no synchronisation: the source is pageable memory (staged by the runtime before the call returns) and is kept alive
-        // in h_time anyway; the copy is ordered before the kernels that read d_time on `st`
-        HIPCHK(hipMemcpyAsync(m->d_time.p, dt.data(), sizeof(double) * (size_t)n_time, hipMemcpyHostToDevice, st));
-        m->h_time.swap(dt);
-    }
     std::vector<double> tab;
     tab.insert(tab.end(), b, b + s);
     for (int i = 1; i < s; ++i) tab.push_back(a[i * s + (i - 1)]);
     tab.insert(tab.end(), b, b + s);
     tab.insert(tab.end(), a, a + (size_t)s * s);
-    if (tab != m->h_tab) {
+    const bool new_time = dt != m->h_time, new_tab = tab != m->h_tab;
+    if (new_time) {
+        if (m->d_time.ensure(sizeof(double) * (size_t)n_time)) return -1;
+        if (m->uploads.stage(dt.data(), sizeof(double) * (size_t)n_time, m->d_time.p, st)) return -1;
+        m->h_time.swap(dt);
+    }
+    if (new_tab) {
         if (m->d_tab.ensure(sizeof(double) * tab.size())) return -1;
-        HIPCHK(hipMemcpyAsync(m->d_tab.p, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, st));
+        if (m->uploads.stage(tab.data(), sizeof(double) * tab.size(), m->d_tab.p, st)) return -1;
         m->h_tab.swap(tab);
+    }
+    if (new_time || new_tab) m->tab_stream = st;
+    else if (m->uploads.last >= 0 && st != m->tab_stream) {
+        // cached tables, another stream than the one that staged them: its kernels must not start before that copy has landed
+        HIPCHK(hipStreamWaitEvent(st, m->uploads.ev[m->uploads.last], 0));
     }
     *d_time = m->d_time.f64();
     *d_tab_spec = m->d_tab.f64();
@@ -1471,12 +1582,13 @@ int qgs_model_destroy(qgs_model *m)
         if (q) (void)hipFree(q);
     for (Buffer *b : {&m->d_time, &m->d_tab, &m->work, &m->stages, &m->b_in_rows, &m->b_in_modes, &m->b_rec_modes,
                       &m->b_rec_rows, &m->b_tg_rows, &m->b_tg_modes, &m->b_fm_modes, &m->b_fm_rows, &m->b_state2, &m->b_tg2, &m->b_ywork, &m->b_vwork, &m->b_mom_part, &m->b_mom_out, &m->b_unit,
-                      &m->b_carry, &m->b_win[0], &m->b_win[1], &m->b_fwin[0], &m->b_fwin[1]})
+                      &m->b_carry, &m->b_win[0], &m->b_win[1], &m->b_fwin[0], &m->b_fwin[1], &m->b_drain})
         b->release();
     for (int i = 0; i < 2; ++i) {
         if (m->ev_comp[i]) (void)hipEventDestroy(m->ev_comp[i]);
         if (m->ev_copy[i]) (void)hipEventDestroy(m->ev_copy[i]);
     }
+    m->uploads.release();
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
@@ -1809,10 +1921,12 @@ static int tgls_launch(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, c
         // 256 MB Infinity Cache every column can afford to read it (one-wavefront kernel 3-8 % ahead: 1.11 vs 1.21 ms at
         // 16 384 members, 189 MB); beyond that the re-reads go to HBM and sharing wins 1.5x (65 536 members, 755 MB:
         // 4.4 vs 6.4 ms).  Rank-5 models keep the plain kernel (their derived monomials already fill the register file).
+        // The size that decides is the stage record of a FULL chunk of the run, not of this range: a run cut into record windows
+        // (whose last chunks are shorter) takes the same kernels in every range and stays bitwise the run in one piece.
         const int C = m->cg.tgl_share_x;
         const bool share_x = tg_spec && C > 1 && n_tg >= 2 && (size_t)m->ndim * 1024 <= (size_t)64 * 1024 &&
                              (n_tg + C - 1) / C <= 65535 && m->der.j.empty() &&
-                             stage_bytes_per_step * (size_t)(end - begin) >= m->tune.tgl_share_min_bytes && !m->tune.tgl_plain;
+                             stage_bytes_per_step * (size_t)chunk >= m->tune.tgl_share_min_bytes && !m->tune.tgl_plain;
         const bool st_wave = use_wave(m, n_traj, s, a);
         const bool st_lds_first = !st_wave && m->prefer_lds && use_lds_spec(m, n_traj, n_steps, s, a);
         const bool st_spec = !st_wave && !st_lds_first && !dense && spec;
@@ -2270,6 +2384,17 @@ int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, i
     p.window(k, &out[0], &out[1], &out[2], &out[3], &wf, &out[5]);
     out[4] = wf;
     return (int)std::min<int64_t>(p.n_windows, 0x7fffffff);
+}
+
+int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
+                      int64_t first_record, const double *d_window, double *dst, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_inner < 1 || n_inner > (int64_t)65535 * 64 || n_window < 1 || n_records < 1 || first_record < 0 ||
+        first_record + n_window > n_records || !d_window || !dst) return fail("bad window arguments");
+    HIPCHK(hipSetDevice(m->device));
+    double *alias = device_alias(m, dst);
+    return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream);
 }
 
 int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,

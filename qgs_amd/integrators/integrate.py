@@ -59,11 +59,33 @@ def on_device(func):
 AUTO_ALL_DEVICES_MIN_TRAJ = 2 * 65536
 
 
+def in_multi_process_job():
+    """True when this process is one rank of a one-process-per-GPU job (a launcher set WORLD_SIZE / LOCAL_RANK / RANK, or a
+    torch.distributed process group is up): its GPU is the one the launcher gave it, the other GPUs belong to the other ranks."""
+    import os
+    import sys
+    for var in ('LOCAL_RANK', 'RANK'):
+        if os.environ.get(var, '') != '':
+            return True
+    try:
+        if int(os.environ.get('WORLD_SIZE', '1') or '1') > 1:
+            return True
+    except ValueError:
+        return True
+    dist = sys.modules.get('torch.distributed')          # never imports torch for the question
+    try:
+        return bool(dist is not None and dist.is_available() and dist.is_initialized())
+    except Exception:
+        return False
+
+
 def resolve_device(device, n_traj=None):
     """The `device` argument of the integrators: a GPU index, a list of indices, 'all', or None = the device the tendencies
-    were created for -- unless the ensemble has at least AUTO_ALL_DEVICES_MIN_TRAJ members and the node has several GPUs, in
-    which case None means all of them (the reference's default is every core of the machine, integrator.py:79-82)."""
-    if device is None and n_traj is not None and n_traj >= AUTO_ALL_DEVICES_MIN_TRAJ:
+    were created for -- unless the ensemble has at least AUTO_ALL_DEVICES_MIN_TRAJ members, the node has several GPUs and this
+    process has them to itself, in which case None means all of them (the reference's default is every core of the machine,
+    integrator.py:79-82).  A rank of a multi-process job never spreads by itself: there `None` keeps meaning the tendencies'
+    own device, and all GPUs must be asked for explicitly (device='all')."""
+    if device is None and n_traj is not None and n_traj >= AUTO_ALL_DEVICES_MIN_TRAJ and not in_multi_process_job():
         from qgs_amd import _lib
         if len(_lib.visible_devices()) > 1:
             return 'all'

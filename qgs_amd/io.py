@@ -53,16 +53,18 @@ def save_trajectory_txt(filename, time, traj, **savetxt_kwargs):
 
 
 def _assembly_version():
-    """Hash of the source files that turn a parameter set into tensors: a fix to the inner products or the tensor assembly must
-    not keep serving tensors cached by the old code."""
-    import qgs_amd.inner_products.analytic as ipa
-    import qgs_amd.inner_products.symbolic as ips
-    import qgs_amd.tensors.qgtensor as qgt
-    import qgs_amd.basis.fourier as bf
-    h = hashlib.sha256(b'qgs_amd tensor cache v2')
-    for mod in (ipa, ips, qgt, bf):
-        with open(mod.__file__, 'rb') as f:
-            h.update(f.read())
+    """Hash of the source files that turn a parameter set into the cached arrays: a fix to the inner products, the tensor
+    assembly, the derived parameters or the Jacobian operands must not keep serving tensors cached by the old code.  Every
+    module of the package takes part except the GPU glue (bindings, integrators, toolbox), which never touches the arrays."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256(b'qgs_amd tensor cache v3')
+    for sub in ('basis', 'functions', 'inner_products', 'params', 'tensors'):
+        d = os.path.join(root, sub)
+        for fn in sorted(os.listdir(d)):
+            if fn.endswith('.py'):
+                h.update(fn.encode())
+                with open(os.path.join(d, fn), 'rb') as f:
+                    h.update(f.read())
     return h.hexdigest()[:12]
 
 

@@ -181,7 +181,22 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
         if backend is not None and backend != 'nccl':
             device = torch.device('cpu')
     # ---- host route (test seam) ----
-    integ = integrator_factory(b=b, c=c, a=a)
+    # the rank's own GPU, explicitly: an integrator left at device=None may spread a large block over every visible GPU
+    # (integrate.resolve_device), and those belong to the other ranks
+    local_gpu = None
+    if getattr(f, 'hip_model', None) is not None and ens.distributed and torch.cuda.is_available():
+        local_gpu = torch.cuda.current_device() if device is None or torch.device(device).type != 'cuda' or torch.device(device).index is None \
+            else torch.device(device).index
+    kwargs = {}
+    if local_gpu is not None:
+        import inspect
+        try:
+            params = inspect.signature(integrator_factory).parameters
+            if 'device' in params or any(q.kind == q.VAR_KEYWORD for q in params.values()):
+                kwargs['device'] = local_gpu
+        except (TypeError, ValueError):                   # a factory whose signature cannot be read keeps its own default
+            pass
+    integ = integrator_factory(b=b, c=c, a=a, **kwargs)
     integ.set_func(f)
     if ens.n_local > 0:
         integ.integrate(t0, t, dt, ic=local_ic, forward=forward, write_steps=write_steps)

@@ -4,25 +4,172 @@
 Same API as the reference (`set_func(f, fjac)`, `compute_lyapunovs(t0, tw, t, dt, mdt, ...)`,
 `get_lyapunovs()`), whole ensemble on the GPU:
 
-* the base trajectory is one fused RK launch with every step recorded (device resident);
+* the base trajectory is integrated by the fused RK stepper with every step recorded;
 * per `dt` interval the tangent model is integrated over the `mdt` sub-steps by the TGLS kernels.  The
   reference propagates the identity and multiplies (`prop @ q`, lyapunov.py:546, 624); the tangent model is
   linear, so the `n_vec` columns of `q` are propagated directly (same result to rounding, n_dim/n_vec
   times less work);
 * the re-orthonormalisation `np.linalg.qr` (lyapunov.py:547, 625) is the batched Householder QR kernel
   `qgs_batched_qr_device` (LAPACK sign convention, so the vectors match the reference's);
-* exponents `log|diag R| / dt` are formed on the host at the end from the stored diagonals.
+* exponents `log|diag R| / dt` are formed on the host at the end from the recorded diagonals.
+
+What the device holds is bounded (round 4).  The reference keeps one trajectory's records at a time in host memory
+(lyapunov.py:232-358, 555-632): the size of a run is limited by the host, not by a device.  Here, within the budget of
+QGS_HIP_RECORD_WINDOW_MB (default 8192, the budget of the windowed integrations of qgs_hip_api.hip):
+
+* the base trajectory is held one WINDOW of steps at a time (`_BaseTrajectory`): backward vectors consume it in time order
+  and integrate it window by window; forward vectors consume it against time and recompute each window from a stored
+  checkpoint (its first state), with the same kernel and the same time grid values, hence bitwise the same states;
+* the recorded vectors / states / diag(R) go into one of two windows of records (`_RecordWindows`); a full window leaves
+  for the host block on a copy stream (`qgs_unpack_window`: the kernel's own stores into the page-locked result block, in
+  the reference's layout) while the next intervals run into the other window.
+A run whose records fit the budget is one window of each: the same code path.  The result blocks themselves are host
+memory, allocated for the whole ensemble before anything runs; a run that does not fit the host says so ("host memory").
 
 The random initial basis is drawn exactly like the reference does (one `np.random.random((n_dim, n_vec))`
 per trajectory, in trajectory order), so seeded runs are reproducible against it.
-PyTorch is used for device buffers only.
+PyTorch is used for device buffers, streams and events only.
 """
 import multiprocessing
+import os
 
 import numpy as np
 
 from qgs_amd.integrators import integrate as _fn
 from qgs_amd.functions.util import reverse
+
+
+def _window_budget_bytes():
+    """Device memory the estimator spends on its windows (same knob and default as the windowed integrations)."""
+    try:
+        mb = float(os.environ.get('QGS_HIP_RECORD_WINDOW_MB', '8192'))
+    except ValueError:
+        mb = 8192.0
+    return int(max(1.0, mb * 1048576.0))
+
+
+def _host_memory_available():
+    try:
+        with open('/proc/meminfo') as f:
+            for line in f:
+                if line.startswith('MemAvailable:'):
+                    return int(line.split()[1]) * 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
+class _BaseTrajectory(object):
+    """States of the base trajectory on the device, a window of steps at a time.
+
+    `state(i)` returns the (n_dim, ld) device view of the state at grid index i; the indices must come in monotone order
+    (ascending, or descending with `descending=True`).  Window k holds the states [k W, min((k + 1) W, G - 1)]; it is the
+    record of one `rk_integrate_device` launch over that piece of the grid with write_steps = 1, started from the last state
+    of window k - 1.  A run cut into ranges is bitwise the run in one piece (the steppers take dt from the grid values).
+    Descending: a first sweep integrates window after window and keeps the first state of each (checkpoints); the windows
+    are then recomputed from their checkpoints in reverse order -- the last one is still resident after the sweep."""
+
+    def __init__(self, torch, m, n, ld, grid, ic_modes, budget, descending, tableau, stream):
+        self.torch, self.m, self.n, self.ld, self.grid, self.stream = torch, m, n, ld, grid, stream
+        self.b, self.c, self.a = tableau
+        ndim = ic_modes.shape[0]
+        steps = len(grid) - 1
+        state_bytes = ndim * ld * 8
+        self.W = int(max(1, min(max(1, steps), budget // state_bytes - 1)))
+        self.n_windows = max(1, -(-steps // self.W))
+        self.buf = torch.empty((min(self.W, steps) + 1, ndim, ld), dtype=torch.float64, device=ic_modes.device)
+        self.starts = [ic_modes]                 # first state of window k (descending: all of them; ascending: the current one)
+        self.k = -1
+        self.descending = descending
+        self._load(0, ic_modes)
+        if descending:
+            for k in range(1, self.n_windows):
+                start = self.buf[self.W].clone()
+                self.starts.append(start)
+                self._load(k, start)
+
+    def _bounds(self, k):
+        return k * self.W, min((k + 1) * self.W, len(self.grid) - 1)
+
+    def _load(self, k, start):
+        lo, hi = self._bounds(k)
+        if hi > lo:
+            self.m.rk_integrate_device(self.n, self.ld, start.data_ptr(), self.grid[lo:hi + 1], 1, 1, self.b, self.c, self.a,
+                                       self.buf.data_ptr(), self.stream)
+        else:                                    # a grid of one point: the state is the initial condition
+            self.buf[0].copy_(start)
+        self.k = k
+
+    def state(self, i):
+        lo, hi = self._bounds(self.k)
+        if i < lo or i > hi:
+            k = self.k + (-1 if i < lo else 1)
+            if self.descending:
+                self._load(k, self.starts[k])
+            else:
+                start = self.buf[hi - lo].clone()             # the last state of the window that is about to be overwritten
+                self._load(k, start)
+            lo, hi = self._bounds(k)
+            if i < lo or i > hi:
+                raise RuntimeError('base trajectory states must be consumed in monotone order')
+        return self.buf[i - lo]
+
+
+class _RecordWindows(object):
+    """The records of a run (vectors, states, diag(R)) on their way to the host blocks, a window of records at a time.
+
+    `slot(iw)` returns the device views record iw is to be written into (on the compute stream); record indices must come in
+    monotone order.  When a record falls outside the current window, that window is handed to the copy stream
+    (`qgs_unpack_window`: mode-major window -> records [first, first + count) of the host blocks in the reference's layout) and
+    the other buffer becomes current -- after its own previous drain has completed."""
+
+    def __init__(self, torch, m, n, ld, inner, hosts, n_records, budget, dev):
+        self.torch, self.m, self.n, self.ld, self.inner, self.hosts, self.n_records = torch, m, n, ld, inner, hosts, n_records
+        per_record = sum(inner) * ld * 8
+        self.W = int(max(1, min(n_records, budget // (2 * per_record))))
+        self.n_windows = -(-n_records // self.W)
+        nbuf = 1 if self.n_windows == 1 else 2
+        self.bufs = [[torch.empty((self.W, q, ld), dtype=torch.float64, device=dev) for q in inner] for _ in range(nbuf)]
+        self.done = [None] * nbuf                             # event: the buffer's last drain has completed
+        self.compute = torch.cuda.current_stream(dev)
+        self.copy = torch.cuda.Stream(dev) if nbuf > 1 else self.compute
+        self.j, self.which, self.used = None, 0, None
+        self.flushed = 0
+
+    def slot(self, iw):
+        j = iw // self.W
+        if j != self.j:
+            if self.j is not None:
+                self._flush()
+                self.which = (self.which + 1) % len(self.bufs)
+            if self.done[self.which] is not None:
+                self.compute.wait_event(self.done[self.which])
+            self.j, self.used = j, None
+        self.used = (iw, iw) if self.used is None else (min(self.used[0], iw), max(self.used[1], iw))
+        return [t[iw - j * self.W] for t in self.bufs[self.which]]
+
+    def _flush(self):
+        if self.used is None:
+            return
+        torch = self.torch
+        first, count = self.used[0], self.used[1] - self.used[0] + 1
+        if self.copy is not self.compute:
+            ready = torch.cuda.Event()
+            ready.record(self.compute)
+            self.copy.wait_event(ready)
+        for t, q, host in zip(self.bufs[self.which], self.inner, self.hosts):
+            self.m.unpack_window(self.n, self.ld, q, count, self.n_records, first, t[first - self.j * self.W].data_ptr(),
+                                 host.ctypes.data, self.copy.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.copy)
+        self.done[self.which] = ev
+        self.used = None
+        self.flushed += 1
+
+    def finish(self):
+        self._flush()
+        self.copy.synchronize()
+        self.compute.synchronize()
 
 
 class LyapunovsEstimator(object):
@@ -55,6 +202,7 @@ class LyapunovsEstimator(object):
         self.func = None
         self.func_jac = None
         self._model = None
+        self.last_windows = None          # (base-trajectory windows, record windows) of the last run, per shard
 
     def terminate(self):
         self._model = None
@@ -112,6 +260,23 @@ class LyapunovsEstimator(object):
             tot = rec_grid[::write_steps]
             self.n_records = len(tot) + (1 if tot[-1] != rec_grid[-1] else 0)
 
+        # the result blocks of the WHOLE ensemble, in host memory and in the reference's layouts; every shard fills its slice.
+        # Their size is what bounds a run -- checked before anything is allocated or computed.
+        from qgs_amd import _lib
+        nt, nd, nv, nr = self.n_traj, self.n_dim, self.n_vec, self.n_records
+        need = 8 * nt * nr * (nd * nv + nd + nv)
+        avail = _host_memory_available()
+        if avail is not None and need > 0.9 * avail:
+            raise MemoryError('host memory: the records of this run (%d members x %d records x (%d x %d vectors + state + exponents)) '
+                              'need %.1f GB, %.1f GB are available -- raise write_steps, or lower n_vec or the number of members'
+                              % (nt, nr, nd, nv, need / 1e9, avail / 1e9))
+        try:
+            out_traj = _lib._RESULTS.empty((nt, nd, nr))
+            out_vec = _lib._RESULTS.empty((nt, nd, nv, nr))
+            out_exp = _lib._RESULTS.empty((nt, nv, nr))
+        except MemoryError:
+            raise MemoryError('host memory: could not allocate %.1f GB for the records of this run' % (need / 1e9))
+
         # random start bases: the matrices are drawn like the reference's (one draw per trajectory, in order:
         # `np.random.random((ndim, nv))` consumes the generator exactly as n such calls in a row do) -- for the WHOLE ensemble
         # before it is split over devices
@@ -119,37 +284,38 @@ class LyapunovsEstimator(object):
         model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
         shards = getattr(model, 'models', None)
         if shards is None:
-            self._recorded_traj, self._recorded_vec, self._recorded_exp = self._compute_shard(model, self.ic, a0, mdt)
-            return
-        # several GPUs: contiguous member shards, one host thread each (the work of a shard is a chain of kernel launches)
-        import threading
-        parts, errors = [None] * len(shards), []
+            self.last_windows = [self._compute_shard(model, self.ic, a0, mdt, (out_traj, out_vec, out_exp))]
+        else:
+            # several GPUs: contiguous member shards, one host thread each (the work of a shard is a chain of kernel launches)
+            import threading
+            windows, errors = [None] * len(shards), []
 
-        def run(i):
-            try:
-                a, cnt = model.shard(self.n_traj, i)
-                if cnt > 0:
-                    parts[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt)
-            except Exception as e:                       # re-raised on the calling thread
-                errors.append(e)
-        threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shards))]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
-        parts = [q for q in parts if q is not None]
-        self._recorded_traj, self._recorded_vec, self._recorded_exp = (np.concatenate([q[k] for q in parts], axis=0) for k in range(3))
+            def run(i):
+                try:
+                    a, cnt = model.shard(self.n_traj, i)
+                    if cnt > 0:
+                        windows[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt,
+                                                         (out_traj[a:a + cnt], out_vec[a:a + cnt], out_exp[a:a + cnt]))
+                except Exception as e:                       # re-raised on the calling thread
+                    errors.append(e)
+            threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shards))]
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            if errors:
+                raise errors[0]
+            self.last_windows = [w for w in windows if w is not None]
+        self._recorded_traj, self._recorded_vec, self._recorded_exp = out_traj, out_vec, out_exp
 
-    def _compute_shard(self, m, ic, a0, mdt):
+    def _compute_shard(self, m, ic, a0, mdt, outs):
         """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
-        returns (traj, vectors, exponents) in the reference's layouts."""
+        fills the slices `outs` = (traj, vectors, exponents) of the result blocks (reference layouts)."""
         import torch
         with torch.cuda.device(torch.device('cuda', m.device)):       # this thread's current device for the duration of the call only
-            return self._compute_shard_on_current_device(m, ic, a0, mdt)
+            return self._compute_shard_on_current_device(m, ic, a0, mdt, outs)
 
-    def _compute_shard_on_current_device(self, m, ic, a0, mdt):
+    def _compute_shard_on_current_device(self, m, ic, a0, mdt, outs):
         import torch
         forward, adjoint, write_steps = self._forward == 1, self._adjoint, self.write_steps
         ndim, nv, n = self.n_dim, self.n_vec, ic.shape[0]
@@ -157,13 +323,14 @@ class LyapunovsEstimator(object):
         dev = torch.device('cuda', m.device)
         f64 = torch.float64
         stream = torch.cuda.current_stream(dev).cuda_stream
+        out_traj, out_vec, out_exp = outs
+        budget = _window_budget_bytes()
 
-        # base trajectory, every step recorded: R[step][mode][member]            (lyapunov.py:558 / :474)
+        # base trajectory, every step recorded: R[step][mode][member], a window of steps at a time   (lyapunov.py:558 / :474)
         full_grid = np.concatenate((self._pretime[:-1], self._time))
         ic_modes = torch.zeros((ndim, ld), dtype=f64, device=dev)
         ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
-        base = torch.empty((len(full_grid), ndim, ld), dtype=f64, device=dev)
-        m.rk_integrate_device(n, ld, ic_modes.data_ptr(), full_grid, 1, 1, self.b, self.c, self.a, base.data_ptr(), stream)
+        base = _BaseTrajectory(torch, m, n, ld, full_grid, ic_modes, budget // 4, forward, (self.b, self.c, self.a), stream)
         n_pre = len(self._pretime)
 
         # orthonormal start basis: QR of the drawn matrices with the same batched Householder kernel as in the loop
@@ -184,13 +351,14 @@ class LyapunovsEstimator(object):
 
         q_new = torch.empty((1, ndim, nv, ld), dtype=f64, device=dev)
         y_end = torch.empty((1, ndim, ld), dtype=f64, device=dev)
-        rec_vec = torch.zeros((self.n_records, ndim, nv, ld), dtype=f64, device=dev)
-        rec_traj = torch.zeros((self.n_records, ndim, ld), dtype=f64, device=dev)
+        # records on their way to the host: vectors F[record][mode * vector][member], states, diag(R) of the QR before the interval
+        rec = _RecordWindows(torch, m, n, ld, (ndim * nv, ndim, nv), (out_vec, out_traj, out_exp), self.n_records, budget // 2, dev)
+        rec_dt = np.ones(self.n_records)                             # interval length behind each record's exponents
 
         def propagate(y_index, subtime, direction):
             """q <- Q of QR( TL_{subtime}(q) ) along the trajectory started at base[y_index]; returns diag(R)."""
             nonlocal q, q_new
-            m.rk_tgls_integrate_device(n, ld, nv, base[y_index].data_ptr(), q.data_ptr(), subtime, direction, 0,
+            m.rk_tgls_integrate_device(n, ld, nv, base.state(y_index).data_ptr(), q.data_ptr(), subtime, direction, 0,
                                        self.b, self.c, self.a, adjoint, self._inverse, y_end.data_ptr(), q_new.data_ptr(),
                                        stream)
             rdiag = torch.empty((nv, ld), dtype=f64, device=dev)
@@ -198,7 +366,17 @@ class LyapunovsEstimator(object):
             q, q_new = q_new[0], q.unsqueeze(0)
             return rdiag
 
-        exp_sources = []            # (record index, rdiag tensor, dt) resolved on the host at the end
+        def record(iw, y_index, rdiag, d):
+            """record iw <- (q, base[y_index], rdiag); exponents = log|rdiag| / d (None: no interval behind it -> zeros)"""
+            s_vec, s_traj, s_rd = rec.slot(iw)
+            s_traj.copy_(base.state(y_index))
+            s_vec.copy_(q.reshape(ndim * nv, ld))
+            if rdiag is None:
+                s_rd.fill_(1.0)
+            else:
+                s_rd.copy_(rdiag)
+                rec_dt[iw] = d
+
         if not forward:
             # ---- backward Lyapunov vectors (lyapunov.py:564-632) ----
             pre, tim = self._pretime, self._time
@@ -214,16 +392,11 @@ class LyapunovsEstimator(object):
                 tt, d = tim[ti], tim[ti + 1] - tim[ti]
                 last = (rdiag, d)                                                   # m_exp = log|diag r| / dt
                 if write_steps > 0 and ti % write_steps == 0:
-                    exp_sources.append((iw, rdiag, d))
-                    rec_traj[iw].copy_(base[n_pre - 1 + ti])
-                    rec_vec[iw].copy_(q)
+                    record(iw, n_pre - 1 + ti, rdiag, d)
                     iw += 1
                 sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
                 rdiag = propagate(n_pre - 1 + ti, sub, 1)
-            if last is not None:
-                exp_sources.append((self.n_records - 1, last[0], last[1]))
-            rec_traj[self.n_records - 1].copy_(base[len(full_grid) - 1])
-            rec_vec[self.n_records - 1].copy_(q)
+            record(self.n_records - 1, len(full_grid) - 1, last[0] if last else None, last[1] if last else 1.0)
         else:
             # ---- forward Lyapunov vectors (lyapunov.py:480-552): integrate the tangent model backward in time ----
             tim, post = self._pretime, self._time            # the reference's (time, posttime)
@@ -242,28 +415,18 @@ class LyapunovsEstimator(object):
                 y_idx = n_t - 1 - ti                                                 # traj[:, :, -1-ti]
                 last = (rdiag, d)
                 if write_steps > 0 and ti % write_steps == 0:
-                    exp_sources.append((iw, rdiag, d))
-                    rec_traj[iw].copy_(base[y_idx])
-                    rec_vec[iw].copy_(q)
+                    record(iw, y_idx, rdiag, d)
                     iw -= 1
                 sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
                 rdiag = propagate(y_idx, sub, -1)
-            if last is not None:
-                exp_sources.append((0, last[0], last[1]))
-            rec_traj[0].copy_(base[y_idx])
-            rec_vec[0].copy_(q)
+            record(0, y_idx, last[0] if last else None, last[1] if last else 1.0)
 
-        # device layout -> the reference's (n_traj, n_dim[, n_vec], n_records)
-        out_traj = torch.empty((n, ndim, self.n_records), dtype=f64, device=dev)
-        out_vec = torch.empty((n, ndim, nv, self.n_records), dtype=f64, device=dev)
-        m.unpack_records(n, ld, ndim, self.n_records, rec_traj.data_ptr(), out_traj.data_ptr(), stream)
-        m.unpack_records(n, ld, ndim * nv, self.n_records, rec_vec.data_ptr(), out_vec.data_ptr(), stream)
-        recorded_exp = np.zeros((n, nv, self.n_records))
-        for iw, rd, d in exp_sources:
-            recorded_exp[:, :, iw] = (np.log(np.abs(rd[:, :n].cpu().numpy())) / d).T
-        from qgs_amd import _lib
-        torch.cuda.current_stream(dev).synchronize()
-        return _lib.to_host(out_traj), _lib.to_host(out_vec), recorded_exp
+        rec.finish()
+        # exponents from the recorded diagonals, in place on the host block: log|diag R| / dt
+        np.abs(out_exp, out=out_exp)
+        np.log(out_exp, out=out_exp)
+        out_exp /= rec_dt
+        return base.n_windows, rec.n_windows
 
     def get_lyapunovs(self):
         """``(time, traj, exponents, vectors)``: traj (n_traj, n_dim, n_records), exponents (n_traj, n_vec, n_records),

@@ -14,6 +14,24 @@ def test_default_device_is_every_gpu_for_large_ensembles(monkeypatch):
     assert fn.resolve_device(None, 10 ** 7) is None
 
 
+def test_a_rank_of_a_multi_process_job_never_spreads_by_itself(monkeypatch):
+    """One rank per GPU (torchrun, bench.py --gpus N, parallel.integrate_ensemble): the other GPUs belong to the other ranks,
+    so `device=None` keeps meaning the tendencies' own device whatever the ensemble size; 'all' must be asked for."""
+    from qgs_amd.integrators import integrate as fn
+    from qgs_amd import _lib
+    monkeypatch.setattr(_lib, 'visible_devices', lambda: [0, 1, 2, 3, 4, 5, 6, 7])
+    for var in ('LOCAL_RANK', 'RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    assert fn.resolve_device(None, 10 ** 7) == 'all'
+    for var, val in (('LOCAL_RANK', '3'), ('RANK', '0'), ('WORLD_SIZE', '8')):
+        monkeypatch.setenv(var, val)
+        assert fn.in_multi_process_job() and fn.resolve_device(None, 10 ** 7) is None
+        assert fn.resolve_device('all', 10 ** 7) == 'all'
+        monkeypatch.delenv(var)
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    assert not fn.in_multi_process_job() and fn.resolve_device(None, 10 ** 7) == 'all'
+
+
 
 def test_pooled_moments_equal_the_moments_of_the_whole():
     from qgs_amd._lib import pool_moments

@@ -54,28 +54,44 @@ def _prebuild(g, val, jval, cache, stages=(2,), env=None):
         os.environ.update(old)
 
 
+def _structs(d):
+    return sorted(f for f in os.listdir(str(d)) if f.endswith('.qgst'))
+
+
 def test_parameter_sweep_shares_one_set_of_code_objects(tmp_path):
     g = load_golden('rp20')
     t1 = _prebuild(g, g['val'], g['jval'], tmp_path)
-    first = _objs(tmp_path)
-    assert len(first) >= 9
-    mt = {f: os.path.getmtime(os.path.join(str(tmp_path), f)) for f in first}
+    first, first_s = _objs(tmp_path), _structs(tmp_path)
+    assert len(first) >= 9 and len(first_s) == len(first)     # one structure entry (table layout) + one code object per kernel
+    mt = {f: os.path.getmtime(os.path.join(str(tmp_path), f)) for f in first + first_s}
     for k in (1, 2):
         tk = _prebuild(g, remap(g['val'], k), remap(g['jval'], k), tmp_path)
-        assert _objs(tmp_path) == first                       # not one new code object
+        assert _objs(tmp_path) == first and _structs(tmp_path) == first_s     # not one new entry of either kind
         assert tk < 0.2, (tk, t1)                             # and no generator run either (memo / verified file reads only)
-    # a value change that breaks a magnitude coincidence IS a new structure (the factored groups differ): new objects, old ones kept
-    val = g['val'].copy()
-    a = np.abs(val)
-    vals, counts = np.unique(a, return_counts=True)
-    shared = vals[counts > 1]
-    assert len(shared)
-    idx = np.nonzero(a == shared[0])[0]
-    val[idx[0]] *= 1.25
-    _prebuild(g, val, g['jval'], tmp_path)
-    assert set(first) < set(_objs(tmp_path))
     # hits refresh the modification time of an entry (the eviction order is least recently used)
-    assert all(os.path.getmtime(os.path.join(str(tmp_path), f)) >= mt[f] for f in first)
+    assert all(os.path.getmtime(os.path.join(str(tmp_path), f)) >= mt[f] for f in first + first_s)
+    # A value change that breaks a coincidence of two magnitudes is a new STRUCTURE (new table layouts).  It is new CODE only
+    # where the generator had exploited the coincidence: two bilinear terms of one row are factored, c * (x_a x_b +- x_c x_d) ...
+    coo, val = g['coo'], g['val'].copy()
+    a = np.abs(val)
+    bil = (coo[:, 1] > 0) & (coo[:, 2] > 0)
+    same_row = [(i, j) for i in np.nonzero(bil)[0] for j in np.nonzero(bil & (coo[:, 0] == coo[i, 0]) & (a == a[i]))[0] if j > i]
+    assert same_row
+    val[same_row[0][1]] *= 1.25
+    _prebuild(g, val, None, tmp_path, stages=(2,))
+    after = _objs(tmp_path)
+    assert set(first) < set(after) and len(_structs(tmp_path)) > len(first_s)
+    # ... while a coincidence between different rows of the tendencies is nothing the fused stepper knows about: a new table
+    # layout, the same source, the same code object
+    val = g['val'].copy()
+    rows = coo[:, 0]
+    cross = [(i, j) for i in range(len(val)) for j in range(i + 1, len(val)) if a[i] == a[j] and rows[i] != rows[j]
+             and np.sum(a[rows == rows[j]] == a[j]) == 1 and np.sum(a == a[i]) == 2]
+    if cross:
+        val[cross[0][1]] *= 1.25
+        n_s = len(_structs(tmp_path))
+        _prebuild(g, val, None, tmp_path, stages=(2,))
+        assert len(_structs(tmp_path)) > n_s and _objs(tmp_path) == after
 
 
 def test_damaged_or_foreign_cache_entries_are_recompiled(tmp_path):
@@ -87,42 +103,54 @@ def test_damaged_or_foreign_cache_entries_are_recompiled(tmp_path):
             % (REPO, os.path.join(GOLDEN_DIR, 'rp20.npz')))
     env = dict(os.environ, QGS_HIP_CACHE_DIR=str(tmp_path))
     subprocess.run([sys.executable, '-c', code], check=True, timeout=900, env=env)
-    objs = _objs(tmp_path)
-    assert len(objs) >= 3
-    good = {f: open(os.path.join(str(tmp_path), f), 'rb').read() for f in objs}
-    # the footer names the full 128-bit key and the payload's length and hash
-    for f, data in good.items():
-        assert data[:4] == b'\x7fELF' and data[-64:-56] == b'QGSKC001'
+    objs, structs = _objs(tmp_path), _structs(tmp_path)
+    assert len(objs) >= 3 and len(structs) >= 3
+    good = {f: open(os.path.join(str(tmp_path), f), 'rb').read() for f in objs + structs}
+    # the footer names the full 128-bit key and the payload's length and hash; a code entry still reads as an ELF
+    for f in objs:
+        assert good[f][:4] == b'\x7fELF' and good[f][-64:-56] == b'QGSKC002'
+    for f in structs:
+        assert good[f][-64:-56] == b'QGSKT002'
     a, b, c = (os.path.join(str(tmp_path), f) for f in objs[:3])
     open(a, 'wb').write(good[objs[0]][:len(good[objs[0]]) // 2])                  # truncated, still non-empty
     flipped = bytearray(good[objs[1]])
     flipped[len(flipped) // 3] ^= 0x40
     open(b, 'wb').write(bytes(flipped))                                            # one flipped bit in the code object
     open(c, 'wb').write(good[objs[0]])                                             # a valid entry of ANOTHER key under this name
+    flipped = bytearray(good[structs[0]])
+    flipped[10] ^= 0x01
+    open(os.path.join(str(tmp_path), structs[0]), 'wb').write(bytes(flipped))      # a damaged table layout
+    open(os.path.join(str(tmp_path), structs[1]), 'wb').write(good[structs[2]])    # a foreign one
     subprocess.run([sys.executable, '-c', code], check=True, timeout=900, env=env)
-    for f in objs:
+    for f in objs + structs:
         # (code objects of one compiler for one source are reproducible: the replaced entries equal the originals)
         assert open(os.path.join(str(tmp_path), f), 'rb').read() == good[f], f
 
 
 def test_cache_directory_is_bounded(tmp_path):
     g = load_golden('rp20')
+
+    def entries():
+        return _objs(tmp_path) + _structs(tmp_path)
+
+    def size():
+        return sum(os.path.getsize(os.path.join(str(tmp_path), f)) for f in entries())
     _prebuild(g, g['val'], None, tmp_path)
-    total = sum(os.path.getsize(os.path.join(str(tmp_path), f)) for f in _objs(tmp_path))
-    n0 = len(_objs(tmp_path))
-    assert n0 >= 3
-    # a second structure under a bound of ~the size of the first: least recently used entries go, the directory stays under it
-    val = g['val'].copy()
-    val[0] *= 1.25
-    limit_mb = total / 1048576.0
-    _prebuild(g, val, None, tmp_path, env={'QGS_HIP_CACHE_MAX_MB': '%.6f' % limit_mb})
-    left = _objs(tmp_path)
-    assert sum(os.path.getsize(os.path.join(str(tmp_path), f)) for f in left) <= total
-    assert len(left) < 2 * n0
-    # 0 = unbounded: a third structure is added, nothing leaves
-    val[1] *= 1.3
-    _prebuild(g, val, None, tmp_path, env={'QGS_HIP_CACHE_MAX_MB': '0'})
-    assert len(_objs(tmp_path)) == len(left) + n0 and set(left) < set(_objs(tmp_path))
+    total, n0 = size(), len(entries())
+    assert n0 >= 6
+    # a second model (other sparsity pattern: one entry dropped) under a bound of ~the size of the first: least recently used
+    # entries go, the directory stays under the bound
+    keep = np.ones(len(g['val']), dtype=bool)
+    keep[len(keep) // 2] = False
+    g2 = {'ndim': g['ndim'], 'coo': g['coo'][keep], 'jcoo': None}
+    _prebuild(g2, g['val'][keep], None, tmp_path, env={'QGS_HIP_CACHE_MAX_MB': '%.6f' % (total / 1048576.0)})
+    left = entries()
+    assert size() <= total and len(left) < 2 * n0
+    # 0 = unbounded: a third model is added, nothing leaves
+    keep[len(keep) // 3] = False
+    g3 = {'ndim': g['ndim'], 'coo': g['coo'][keep], 'jcoo': None}
+    _prebuild(g3, g['val'][keep], None, tmp_path, env={'QGS_HIP_CACHE_MAX_MB': '0'})
+    assert len(entries()) == len(left) + n0 and set(left) < set(entries())
 
 
 @pytest.fixture(scope='module')
