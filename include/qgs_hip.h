@@ -157,6 +157,20 @@ int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, cons
                                 int s, const double *b, const double *c, const double *a,
                                 int adjoint, double inverse, double *traj, double *fmatrix);
 
+/* The general contraction behind the reference's sparse_mul3 / sparse_mul5 / sparse_mul2 / sparse_mul4 called with ANY vectors
+ * (qgs/functions/sparse_mul.py:13-158: `coo`, `val` and the vectors are all run-time arguments; a[0] need not be 1, the
+ * vectors may differ, the tensor may hold entries in row 0).  coo: (nnz, rank) row-major, rank 3 or 5, every index in
+ * [0, n_slots).  n_out_axes = 1: res[i] = sum val * a[j] * b[k] (* c[l] * d[m])          -- sparse_mul3 / sparse_mul5
+ * n_out_axes = 2: res[i][j] = sum val * a[k] (* b[l] * c[m])                             -- sparse_mul2 / sparse_mul4
+ * `vecs`: the rank - n_out_axes vectors, n_slots doubles each, one after the other; `res`: n_slots (or n_slots^2) doubles,
+ * zero where the tensor has no entry (the reference's `res[0] = 1` of sparse_mul3 / 5 is the caller's).  Entries are summed
+ * per output element in their incoming order with the reference's operation order: bitwise the reference's loops. */
+typedef struct qgs_contraction qgs_contraction;
+int qgs_contraction_create(int device, int n_slots, int rank, int n_out_axes, int64_t nnz, const int32_t *coo, const double *val,
+                           qgs_contraction **out);
+int qgs_contraction_apply(qgs_contraction *c, const double *vecs, double *res);
+int qgs_contraction_destroy(qgs_contraction *c);
+
 /* Page-lock (and later release) a caller-owned host block that receives large results, so that the device-to-host copies
  * of the host-layout entry points run at the pinned PCIe rate (measured 57 instead of 50 GB/s for a 1.9 GB record, and
  * without first-touch page faults inside the copy).  Optional: every entry point also accepts pageable memory.  The Python

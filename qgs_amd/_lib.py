@@ -48,6 +48,9 @@ SIGNATURES = {
     'qgs_group_rk_tgls_integrate': (_int, [_vp, _i64, _i64, _f64p, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p,
                                            _int, _dbl, _f64p, _f64p]),
     'qgs_rk_integrate_rows_device': (_int, [_vp, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp]),
+    'qgs_contraction_create': (_int, [_int, _int, _int, _int, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
+    'qgs_contraction_apply': (_int, [_vp, _f64p, _f64p]),
+    'qgs_contraction_destroy': (_int, [_vp]),
     'qgs_host_register': (_int, [_vp, _i64]),
     'qgs_host_unregister': (_int, [_vp]),
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
@@ -428,6 +431,43 @@ class HipModel(object):
         _check(lib().qgs_rk_tgls_integrate_device(self._h, n_traj, ld, n_tg, d_ic, d_tg_ic, time, len(time),
                                                   int(time_direction), int(write_steps), len(b), b, c, a,
                                                   int(bool(adjoint)), float(inverse), d_rec, d_rec_fm, stream or None))
+
+
+class Contraction(object):
+    """A COO tensor staged on one GPU for the general contraction with explicit vectors (qgs_contraction handle): what the
+    reference's sparse_mul3 / sparse_mul5 (`matrix=False`) and sparse_mul2 / sparse_mul4 (`matrix=True`) compute for ANY
+    arguments (qgs/functions/sparse_mul.py:13-158)."""
+
+    def __init__(self, n_slots, coo, val, matrix=False, device=0):
+        self.n_slots, self.matrix = int(n_slots), bool(matrix)
+        coo, val = _c(coo, np.int32), _c(val)
+        rank = _tensor_rank(coo)
+        self.n_fac = rank - (2 if matrix else 1)
+        h = _vp()
+        _check(lib().qgs_contraction_create(int(device), self.n_slots, rank, 2 if matrix else 1, len(val), _ptr(coo), _ptr(val),
+                                            ctypes.byref(h)))
+        self._h = h
+
+    def apply(self, *vectors):
+        if len(vectors) != self.n_fac:
+            raise ValueError('%d vectors expected' % self.n_fac)
+        vecs = np.ascontiguousarray(np.stack([np.asarray(v, dtype=np.float64) for v in vectors]))
+        if vecs.shape != (self.n_fac, self.n_slots):
+            raise ValueError('the vectors must have length %d' % self.n_slots)
+        res = np.empty((self.n_slots, self.n_slots) if self.matrix else (self.n_slots,))
+        _check(lib().qgs_contraction_apply(self._h, vecs, res))
+        return res
+
+    def close(self):
+        if getattr(self, '_h', None):
+            lib().qgs_contraction_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def visible_devices():

@@ -1941,19 +1941,50 @@ std::vector<Term> merge_duplicates(const std::vector<Term> &in)
 
 }  // namespace
 
+// Magnitudes that differ by at most this many units in the last place are ONE magnitude (the one that appears first): see
+// codegen.h Canonical.
+constexpr int64_t MAGNITUDE_ULP_TOLERANCE = 2;
+
+bool magnitudes_close(double a, double b)
+{
+    if (a == b) return true;
+    if (!(a > 0.0) || !(b > 0.0) || !std::isfinite(a) || !std::isfinite(b)) return false;       // zero stays apart from everything else
+    const int64_t d = (int64_t)magnitude_bits(a) - (int64_t)magnitude_bits(b);
+    return d >= -MAGNITUDE_ULP_TOLERANCE && d <= MAGNITUDE_ULP_TOLERANCE;
+}
+
 void canonicalize(const std::vector<Term> &terms, Canonical &c)
 {
     c.terms = merge_duplicates(terms);
     c.magnitude.assign(1, 0.0);
-    std::unordered_map<uint64_t, int> id;
+    std::unordered_map<uint64_t, int> id;                  // exact magnitude (bit pattern) -> class
+    std::map<double, int> reps;                            // class representatives (finite, > 0), for the neighbourhood search
     id.emplace(magnitude_bits(0.0), 0);
     for (Term &t : c.terms) {
+        const double a = std::fabs(t.v);
         auto it = id.find(magnitude_bits(t.v));
-        if (it == id.end()) {
-            it = id.emplace(magnitude_bits(t.v), (int)c.magnitude.size()).first;
-            c.magnitude.push_back(std::fabs(t.v));
+        int cls = -1;
+        if (it != id.end()) cls = it->second;
+        else if (a > 0.0 && std::isfinite(a)) {
+            // the closest representative within the tolerance (the lower class id on a tie)
+            auto hi = reps.lower_bound(a);
+            int64_t best = MAGNITUDE_ULP_TOLERANCE + 1;
+            for (int side = 0; side < 2; ++side) {
+                auto q = hi;
+                if (side == 0) { if (q == reps.begin()) continue; --q; }
+                else if (q == reps.end()) continue;
+                if (!magnitudes_close(a, q->first)) continue;
+                const int64_t d = std::llabs((int64_t)magnitude_bits(a) - (int64_t)magnitude_bits(q->first));
+                if (d < best || (d == best && q->second < cls)) { best = d; cls = q->second; }
+            }
         }
-        t.v = std::copysign((double)it->second, t.v);
+        if (cls < 0) {
+            cls = (int)c.magnitude.size();
+            c.magnitude.push_back(a);
+            if (a > 0.0 && std::isfinite(a)) reps.emplace(a, cls);
+        }
+        id.emplace(magnitude_bits(t.v), cls);              // (the same bits again: straight to this class)
+        t.v = std::copysign((double)cls, t.v);
     }
 }
 

@@ -67,6 +67,13 @@ void launch_gen_tend_one(const DevTensor &T, int ndim, const double *x, double *
 void launch_gen_jac_one(const OnePairs &P, int ndim, const double *x, double *jm, unsigned *counter, unsigned long long *flag,
                         unsigned long long seq, hipStream_t st);
 
+// General contraction of a COO tensor with explicit vectors (sparse_mul3 / sparse_mul5 / sparse_mul2 / sparse_mul4 called with ANY
+// vectors, qgs/functions/sparse_mul.py:13-158): entries grouped by output element (in their incoming order), n_fac factor
+// indices per entry; out[out_index[t]] = sum_e val[e] * prod_f vecs[f][fidx[e * n_fac + f]] with the reference's operation
+// order ((a*b)*val, no contraction into FMAs): bitwise the reference's loops.  vecs: n_fac vectors of n_slots doubles.
+void launch_contract(int n_out, const int32_t *out_index, const int32_t *ptr, const uint32_t *fidx, const double *val, int n_fac,
+                     const double *vecs, int n_slots, double *out, hipStream_t st);
+
 // Explicit s-stage RK with the full `a` matrix (integrate.py:204-221).
 //   work: (s + 2) * ndim * ld doubles of scratch;  stages: optional S[(step-step_begin)*s+stage][mode][member]
 //   tab_full: device array  b[s], a[s*s]

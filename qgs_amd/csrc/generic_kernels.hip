@@ -963,6 +963,36 @@ void launch_gen_jac_one(const OnePairs &P, int ndim, const double *x, double *jm
                        flag, seq);
 }
 
+// ---- general contraction with explicit vectors (sparse_mul3 / 5 / 2 / 4 with any arguments) ---------------------------------------
+// One thread per non-empty output element, entries in their incoming order, products left to right and then times the
+// value, contraction into FMAs switched off for this kernel: the same sequence of IEEE operations as the reference's loops
+// `res[i] += a[j] * b[k] * val[n]` (sparse_mul.py:76-78).
+__global__ void __launch_bounds__(256) contract_kernel(int n_out, const int32_t *__restrict__ out_index, const int32_t *__restrict__ ptr,
+                                                       const uint32_t *__restrict__ fidx, const double *__restrict__ val, int n_fac,
+                                                       const double *__restrict__ vecs, int n_slots, double *__restrict__ out)
+{
+#pragma clang fp contract(off)       // (HIP's __dmul_rn / __dadd_rn are plain * and +: only this keeps `s + p * val` two roundings)
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_out) return;
+    double s = 0.0;
+    for (int e = ptr[t]; e < ptr[t + 1]; ++e) {
+        const uint32_t *f = fidx + (size_t)e * n_fac;
+        double p = vecs[f[0]];
+        for (int q = 1; q < n_fac; ++q) p = p * vecs[(size_t)q * n_slots + f[q]];
+        p = p * val[e];
+        s = s + p;
+    }
+    out[out_index[t]] = s;
+}
+
+void launch_contract(int n_out, const int32_t *out_index, const int32_t *ptr, const uint32_t *fidx, const double *val, int n_fac,
+                     const double *vecs, int n_slots, double *out, hipStream_t st)
+{
+    if (n_out < 1) return;
+    hipLaunchKernelGGL(contract_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, n_out, out_index, ptr, fidx, val, n_fac, vecs,
+                       n_slots, out);
+}
+
 void launch_gen_rk(const DevTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec, double *stages,
                    double *work, const double *dtime, const double *tab_full, hipStream_t st)
 {

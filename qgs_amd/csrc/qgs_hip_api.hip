@@ -1491,9 +1491,10 @@ static int load_tensors(qgs_model *m, int rank, int64_t nnz, const int32_t *coo,
     qgs::reduce_polynomial(ndim, rank, jnnz, jcoo, jval, true, m->J, m->der.j);
     qgs::canonicalize(m->T, m->canon_t);
     qgs::canonicalize(m->J, m->canon_j);
-    auto structure_hash = [&](const qgs::Canonical &c, const std::vector<std::pair<int, int>> &der) {
+    // structure hash: everything of a canonical form the generated source can depend on
+    auto hash_form = [&](const qgs::Canonical &c, const std::vector<std::pair<int, int>> &der, char tag) {
         Hasher h;
-        const int64_t head[4] = {ndim, rank, (int64_t)c.terms.size(), (int64_t)der.size()};
+        const int64_t head[5] = {ndim, rank, (int64_t)c.terms.size(), (int64_t)der.size(), (int64_t)tag};
         h.add(head, sizeof head);
         for (const qgs::Term &t : c.terms) {
             const int32_t q[3] = {t.i, t.j, t.k};
@@ -1503,8 +1504,8 @@ static int load_tensors(qgs_model *m, int rank, int64_t nnz, const int32_t *coo,
         for (const auto &pr : der) { const int32_t q[2] = {pr.first, pr.second}; h.add(q, sizeof q); }
         return h.done();
     };
-    m->hash_t = structure_hash(m->canon_t, m->der.t);
-    m->hash_j = structure_hash(m->canon_j, m->der.j);
+    m->hash_t = hash_form(m->canon_t, m->der.t, 'T');
+    m->hash_j = hash_form(m->canon_j, m->der.j, 'J');
     m->rank = rank;
     m->nnz_in = nnz;
     m->jnnz_in = jnnz;
@@ -2542,6 +2543,87 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     }
     HIPCHK(hipStreamSynchronize(sc));
     HIPCHK(hipStreamSynchronize(sd));
+    return 0;
+}
+
+// ---- the general contraction: sparse_mul3 / sparse_mul5 / sparse_mul2 / sparse_mul4 with any vectors -----------------------
+}  // extern "C"
+
+struct qgs_contraction {
+    int device = 0, n_slots = 0, n_fac = 0, n_out = 0;
+    int64_t out_len = 0;
+    int32_t *d_out_index = nullptr, *d_ptr = nullptr;
+    uint32_t *d_fidx = nullptr;
+    double *d_val = nullptr, *d_vecs = nullptr, *d_res = nullptr;
+};
+
+extern "C" {
+
+int qgs_contraction_create(int device, int n_slots, int rank, int n_out_axes, int64_t nnz, const int32_t *coo, const double *val,
+                           qgs_contraction **out)
+{
+    if (!out) return fail("out is null");
+    *out = nullptr;
+    if (rank != 3 && rank != 5) return fail("tensor rank must be 3 or 5");
+    if (n_out_axes != 1 && n_out_axes != 2) return fail("the result has 1 (vector) or 2 (matrix) axes");
+    if (n_slots < 1 || n_slots > 46340) return fail("n_slots out of range");
+    if (nnz < 0 || nnz > 0x7fffffff || (nnz > 0 && (!coo || !val))) return fail("bad tensor arguments");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) return fail("no HIP device visible; libqgs_hip has no CPU path");
+    if (device < 0 || device >= n) return fail("device index out of range");
+    for (int64_t e = 0; e < nnz * rank; ++e)
+        if (coo[e] < 0 || coo[e] >= n_slots) return fail("tensor coordinate out of range");
+    HIPCHK(hipSetDevice(device));
+    const int n_fac = rank - n_out_axes;
+    // entries grouped by output element, incoming order kept inside a group (stable counting sort)
+    const int64_t out_len = n_out_axes == 1 ? n_slots : (int64_t)n_slots * n_slots;
+    auto out_of = [&](int64_t e) { const int32_t *q = coo + e * rank; return n_out_axes == 1 ? (int64_t)q[0] : (int64_t)q[0] * n_slots + q[1]; };
+    std::map<int64_t, int32_t> group;                          // output element -> group number, in order of the element
+    for (int64_t e = 0; e < nnz; ++e) group.emplace(out_of(e), 0);
+    std::vector<int32_t> out_index, ptr(1, 0);
+    for (auto &kv : group) { kv.second = (int32_t)out_index.size(); out_index.push_back((int32_t)kv.first); }
+    std::vector<int32_t> count(out_index.size(), 0);
+    for (int64_t e = 0; e < nnz; ++e) count[(size_t)group[out_of(e)]]++;
+    for (int32_t c : count) ptr.push_back(ptr.back() + c);
+    std::vector<int32_t> pos(ptr.begin(), ptr.end() - 1);
+    std::vector<uint32_t> fidx((size_t)nnz * n_fac);
+    std::vector<double> v((size_t)nnz);
+    for (int64_t e = 0; e < nnz; ++e) {
+        const int32_t at = pos[(size_t)group[out_of(e)]]++;
+        for (int f = 0; f < n_fac; ++f) fidx[(size_t)at * n_fac + f] = (uint32_t)coo[e * rank + n_out_axes + f];
+        v[(size_t)at] = val[e];
+    }
+    qgs_contraction *c = new qgs_contraction();
+    c->device = device; c->n_slots = n_slots; c->n_fac = n_fac; c->n_out = (int)out_index.size(); c->out_len = out_len;
+    if (upload_vec(out_index, &c->d_out_index) || upload_vec(ptr, &c->d_ptr) || upload_vec(fidx, &c->d_fidx) || upload_vec(v, &c->d_val) ||
+        hipMalloc((void **)&c->d_vecs, sizeof(double) * (size_t)n_fac * n_slots) != hipSuccess ||
+        hipMalloc((void **)&c->d_res, sizeof(double) * (size_t)out_len) != hipSuccess) {
+        qgs_contraction_destroy(c);
+        return fail("device allocation for the contraction failed");
+    }
+    *out = c;
+    return 0;
+}
+
+int qgs_contraction_apply(qgs_contraction *c, const double *vecs, double *res)
+{
+    if (!c || !vecs || !res) return fail("bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_vecs, vecs, sizeof(double) * (size_t)c->n_fac * c->n_slots, hipMemcpyHostToDevice));
+    HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(double) * (size_t)c->out_len, nullptr));
+    qgs::launch_contract(c->n_out, c->d_out_index, c->d_ptr, c->d_fidx, c->d_val, c->n_fac, c->d_vecs, c->n_slots, c->d_res, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(res, c->d_res, sizeof(double) * (size_t)c->out_len, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int qgs_contraction_destroy(qgs_contraction *c)
+{
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    for (void *q : {(void *)c->d_out_index, (void *)c->d_ptr, (void *)c->d_fidx, (void *)c->d_val, (void *)c->d_vecs, (void *)c->d_res})
+        if (q) (void)hipFree(q);
+    delete c;
     return 0;
 }
 

@@ -250,8 +250,21 @@ def test_sparse_mul_entry_points_match_oracle():
     ref2 = oracle.sparse_mul2(g['jcoo'], g['jval'], xx)
     assert r2.shape == ref2.shape and np.abs(r2 - ref2).max() < 1e-14 * np.abs(ref2).max()
     assert np.abs(ref2[1:, 0]).max() > 0                      # column 0 (linear part) is exercised
-    with pytest.raises(NotImplementedError):
-        sparse_mul3(g['coo'], g['val'], xx, 2. * xx)
+    # any arguments the reference's functions take (sparse_mul.py:48-81: `a`, `b` are just two arrays): different vectors, a
+    # constant slot that is not 1, entries in row 0 -- the general contraction kernel, bitwise the reference's loops
+    rng = np.random.RandomState(3)
+    a, b = rng.randn(g.ndim + 1), rng.randn(g.ndim + 1)
+    coo0 = np.concatenate((g['coo'], np.array([[0, 2, 3], [0, 0, 0], [0, 5, 0]], dtype=g['coo'].dtype)))
+    val0 = np.concatenate((g['val'], [0.25, -1.5, 2.0]))
+    for coo_, val_ in ((g['coo'], g['val']), (coo0, val0)):
+        got = sparse_mul3(coo_, val_, a, b)
+        ref = oracle.sparse_mul3(coo_, val_, a, b)
+        assert got[0] == 1. and np.array_equal(got, ref)
+        assert np.array_equal(sparse_mul3(coo_, val_, 2. * xx, xx), oracle.sparse_mul3(coo_, val_, 2. * xx, xx))
+    jcoo0 = np.concatenate((g['jcoo'], np.array([[0, 2, 3], [0, 0, 1], [4, 0, 0]], dtype=g['jcoo'].dtype)))
+    jval0 = np.concatenate((g['jval'], [0.5, -0.75, 3.0]))
+    for coo_, val_, v in ((g['jcoo'], g['jval'], a), (jcoo0, jval0, a), (jcoo0, jval0, xx)):
+        assert np.array_equal(sparse_mul2(coo_, val_, v), oracle.sparse_mul2(coo_, val_, v))
 
 
 def test_sparse_mul_rank5_entry_points_match_oracle():
@@ -267,8 +280,18 @@ def test_sparse_mul_rank5_entry_points_match_oracle():
     ref4 = oracle.sparse_mul4(g['jcoo'], g['jval'], xx, xx, xx)
     assert r4.shape == ref4.shape and np.abs(r4 - ref4).max() < 1e-14 * np.abs(ref4).max()
     assert np.abs(ref4[1:, 0]).max() > 0                      # column 0 (the j == 0 entries) is exercised
-    with pytest.raises(NotImplementedError):
-        sparse_mul5(g['coo'], g['val'], xx, xx, xx, 2. * xx)
+    # four (three) different vectors, entries in row 0 (sparse_mul.py:84-158 take any arrays): the general contraction kernel
+    rng = np.random.RandomState(4)
+    va, vb, vc, vd = (rng.randn(g.ndim + 1) for _ in range(4))
+    coo0 = np.concatenate((g['coo'], np.array([[0, 2, 3, 0, 1], [0, 0, 0, 0, 0]], dtype=g['coo'].dtype)))
+    val0 = np.concatenate((g['val'], [0.25, -1.5]))
+    for coo_, val_ in ((g['coo'], g['val']), (coo0, val0)):
+        got = sparse_mul5(coo_, val_, va, vb, vc, vd)
+        assert got[0] == 1. and np.array_equal(got, oracle.sparse_mul5(coo_, val_, va, vb, vc, vd))
+    jcoo0 = np.concatenate((g['jcoo'], np.array([[0, 2, 3, 0, 1], [3, 0, 0, 0, 0]], dtype=g['jcoo'].dtype)))
+    jval0 = np.concatenate((g['jval'], [0.5, -0.75]))
+    for coo_, val_ in ((g['jcoo'], g['jval']), (jcoo0, jval0)):
+        assert np.array_equal(sparse_mul4(coo_, val_, va, vb, vc), oracle.sparse_mul4(coo_, val_, va, vb, vc))
 
 
 def test_dynamic_T_model_end_to_end():
