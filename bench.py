@@ -593,35 +593,29 @@ print('COLD ' + json.dumps({'seconds': t2 - t0, 'create_tendencies_s': t1 - t0, 
 
 def cold_start():
     """Seconds from `create_tendencies` to the first 65 536-member x 1000-step result, each in a FRESH process: on an empty
-    kernel cache (everything that run needs is generated and compiled), then with other parameter values of the same
-    tensor structure on the cache the first run left (no compilation: the code objects do not depend on values), and on the
-    cache that ships with the tree."""
+    kernel cache with the compiler's own cache switched off (everything that run needs is generated and really compiled), then
+    with other parameter values on the cache the first run left (no compilation: the code objects do not depend on values),
+    and with the shipped parameter set on the cache that ships with the tree."""
     import tempfile
     out = {}
     with tempfile.TemporaryDirectory(prefix='qgs_cold_') as d:
-        for tag, kd, cache in (('empty_cache', 0.0291, d), ('structure_warm_cache', 0.0292, d), ('shipped_cache', 0.0290, None)):
-            env = dict(os.environ)
-            if cache is not None:
-                env['QGS_HIP_CACHE_DIR'] = cache
-            else:
-                env.pop('QGS_HIP_CACHE_DIR', None)
-                env['QGS_HIP_CACHE_DIR'] = os.path.join(HERE, 'qgs_amd', 'kcache')
+        for tag, kd, cache, comgr in (('empty_cache', 0.0291, d, '0'), ('structure_warm_cache', 0.0296, d, None),
+                                      ('shipped_cache', 0.0290, os.path.join(HERE, 'qgs_amd', 'kcache'), None)):
+            env = dict(os.environ, QGS_HIP_CACHE_DIR=cache)
+            if comgr is not None:
+                env['AMD_COMGR_CACHE'] = comgr            # hiprtc's own on-disk cache (~/.cache/comgr) would hide the compilation
             try:
                 p = subprocess.run([sys.executable, '-c', _COLD_CHILD % {'here': HERE, 'kd': kd}], stdout=subprocess.PIPE,
                                    stderr=subprocess.PIPE, timeout=600, env=env)
                 line = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('COLD ')]
                 out[tag] = json.loads(line[0][5:]) if line else {'error': p.stderr.decode()[-400:]}
+                out[tag]['kd'] = kd
             except (OSError, subprocess.TimeoutExpired, ValueError) as e:
                 out[tag] = {'error': repr(e)}
-    out['note'] = ('fresh process each; process start-up (imports, HIP context) excluded; kd = 0.0291 / 0.0292 with kdp = 0.0290: two '
-                   'parameter sets of one tensor structure (kd = kdp, the shipped set, is another structure: coinciding magnitudes are factored)')
+    out['note'] = ('fresh process each; process start-up (imports, HIP context) excluded; empty_cache: empty kernel cache and '
+                   'AMD_COMGR_CACHE=0, i.e. generation + hiprtc compilation of the packing-free path (one code object: the fused stepper); '
+                   'structure_warm_cache: another kd on that cache (the code object does not depend on parameter values)')
     return out
-
-
-def default_members(n_gpus):
-    """Ensemble members per GPU when --members is not given: BASELINE configs[4] (1 048 576 members over 8 GPUs) at 8 GPUs,
-    configs[1] (65 536 members on one GPU) per GPU otherwise."""
-    return 131072 if n_gpus == 8 else 65536
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -116,3 +116,31 @@ def test_lyapunov_estimator_at_ndim228_vs_reference():
         assert np.abs(exps - np.squeeze(z[tag + '_exp'])).max() < 1e-8 * max(1.0, np.abs(z[tag + '_exp']).max()), tag
     est.terminate()
     f.operands.release()
+
+
+def test_lyapunov_at_ndim228_on_a_device_list():
+    """Two shards, one host thread each, at a size whose batched QR needs more than 64 KB of dynamic LDS (228 x 40: 118 KB, the
+    limit is raised per device and kernel, generic_kernels.hip DynLdsLimit) and whose tangent model runs in the LDS-resident
+    kernels: the sharded run agrees with one model holding both members."""
+    from conftest import load_golden
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
+    g = load_golden('t228')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = np.random.RandomState(2).rand(2, g.ndim) * 0.01
+    res = []
+    for device in (None, [0, 0]):
+        est = LyapunovsEstimator(num_threads=1, device=device)
+        est.set_func(f, Df)
+        np.random.seed(9)
+        est.compute_lyapunovs(0., 0.2, 0.6, 0.1, 0.05, ic=ic, write_steps=1, n_vec=40, forward=False)
+        res.append(est.get_lyapunovs())
+        est.terminate()
+    (t0, traj0, exp0, vec0), (t1, traj1, exp1, vec1) = res
+    assert vec0.shape == (2, g.ndim, 40, 5) == vec1.shape
+    assert np.abs(traj0 - traj1).max() < 1e-13 and np.abs(vec0 - vec1).max() < 1e-10 and np.abs(exp0 - exp1).max() < 1e-9
+    for i in range(2):
+        q = vec1[i, :, :, -1]
+        assert np.abs(q.T @ q - np.eye(40)).max() < 1e-11
+    f.operands.release()
+

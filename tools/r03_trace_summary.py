@@ -8,6 +8,7 @@ import json
 import sys
 
 O = sys.argv[1]
+PREFIX = sys.argv[2] if len(sys.argv) > 2 else 'r03'          # round tag of the two output files
 
 
 def dispatches(sub):
@@ -60,7 +61,7 @@ for sub, jpath, skip in (('trace', 'bench_headline.json', 10), ('trace_configs',
         for k, v in bench.get('configs', {}).items():
             if isinstance(v, dict):
                 print('   ', k, v.get('kernel'), v.get('ms', v.get('ms_per_call')))
-for name, rows in (('r03_bench_kernel_stats.csv', out_rows), ('r03_bench_dispatches.csv', disp_rows)):
+for name, rows in ((PREFIX + '_bench_kernel_stats.csv', out_rows), (PREFIX + '_bench_dispatches.csv', disp_rows)):
     with open(O + '/' + name, 'w', newline='') as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
