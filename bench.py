@@ -618,6 +618,12 @@ def cold_start():
     return out
 
 
+def default_members(n_gpus):
+    """Ensemble members per GPU when --members is not given: BASELINE configs[4] (1 048 576 members over 8 GPUs) at 8 GPUs,
+    configs[1] (65 536 members on one GPU) per GPU otherwise."""
+    return 131072 if n_gpus == 8 else 65536
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the rank body: what every rank does between the barriers, written against an `engine` (the HIP engine below; a host stand-in
 # in tests/test_bench_rank_body_cpu.py runs the same control flow at world size 8 on gloo)
