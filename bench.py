@@ -297,7 +297,7 @@ def event_ms(torch, fn, n, warm=1):
     return float(np.median(ts)), ts
 
 
-TRAFFIC_SOURCE = 'profiles/hbm_traffic.json (rocprofv3 PMC passes of round 3, committed; a constant attached by kernel name, not measured in this run)'
+TRAFFIC_SOURCE = 'profiles/hbm_traffic.json (rocprofv3 PMC passes of round 4, tools/r04_profiles.sh, committed; a constant attached by kernel name, not measured in this run)'
 
 
 def measured_traffic(kernel):
