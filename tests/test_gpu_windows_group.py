@@ -487,6 +487,43 @@ def test_cabi_rejects_bad_arguments_and_stays_usable():
     expect_fail(L.qgs_rk_tgls_integrate(bare._h, 70, 2, ic, tg, t, len(t), 1, 1, 4, B, C, A, 0, 1., out, fm), 'no jacobian')
     expect_fail(L.qgs_jacobian(bare._h, 1, ic, out), 'no jacobian, single state')
     bare.close()
+    # round-4 entry points: record-window unpack (window beyond the record, zero sizes, null pointers) ...
+    host = np.empty((70, nd, 6))
+    hp = host.ctypes.data_as(vp)
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, nd, 3, 6, 4, d_r.data_ptr(), hp, None), 'records 4..6 of 6')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, nd, 0, 6, 0, d_r.data_ptr(), hp, None), 'empty window')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, 0, 2, 6, 0, d_r.data_ptr(), hp, None), 'n_inner 0')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, nd, 2, 6, -1, d_r.data_ptr(), hp, None), 'first record < 0')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 100, nd, 2, 6, 0, d_r.data_ptr(), hp, None), 'ld 100')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, nd, 2, 6, 0, None, hp, None), 'null window')
+    expect_fail(L.qgs_unpack_window(m._h, 70, 128, nd, 2, 6, 0, d_r.data_ptr(), None, None), 'null destination')
+    expect_fail(L.qgs_unpack_window(None, 70, 128, nd, 2, 6, 0, d_r.data_ptr(), hp, None), 'null model')
+    # (a good call: records 2..3 of the pageable block from the first two records of the window buffer)
+    d_r.copy_(torch.arange(d_r.numel(), dtype=torch.float64, device='cuda').reshape(d_r.shape))
+    host[:] = -1.0
+    assert L.qgs_unpack_window(m._h, 70, 128, nd, 2, 6, 2, d_r.data_ptr(), hp, None) == 0
+    torch.cuda.synchronize()
+    want = d_r[:2, :, :70].cpu().numpy().transpose(2, 1, 0)
+    assert np.array_equal(host[:, :, 2:4], want) and np.all(host[:, :, :2] == -1.0) and np.all(host[:, :, 4:] == -1.0)
+    # ... and the general contraction (rank, result axes, slots, coordinates, device, null pointers)
+    hc = vp()
+    c3 = np.array([[0, 1, 2], [3, 0, 3]], dtype=np.int32)
+    v3 = np.array([1.5, -2.0])
+    p3, q3 = c3.ctypes.data_as(vp), v3.ctypes.data_as(vp)
+    expect_fail(L.qgs_contraction_create(0, 4, 4, 1, 2, p3, q3, ctypes.byref(hc)), 'rank 4')
+    expect_fail(L.qgs_contraction_create(0, 4, 3, 3, 2, p3, q3, ctypes.byref(hc)), '3 result axes')
+    expect_fail(L.qgs_contraction_create(0, 0, 3, 1, 2, p3, q3, ctypes.byref(hc)), 'n_slots 0')
+    expect_fail(L.qgs_contraction_create(0, 3, 3, 1, 2, p3, q3, ctypes.byref(hc)), 'coordinate 3 with 3 slots')
+    expect_fail(L.qgs_contraction_create(99, 4, 3, 1, 2, p3, q3, ctypes.byref(hc)), 'device 99')
+    expect_fail(L.qgs_contraction_create(0, 4, 3, 1, 2, None, q3, ctypes.byref(hc)), 'null coo')
+    expect_fail(L.qgs_contraction_create(0, 4, 3, 1, -1, p3, q3, ctypes.byref(hc)), 'nnz < 0')
+    assert not hc.value
+    assert L.qgs_contraction_create(0, 4, 3, 1, 2, p3, q3, ctypes.byref(hc)) == 0
+    vecs, res = np.array([[2., 3., 5., 7.], [11., 13., 17., 19.]]), np.empty(4)
+    expect_fail(L.qgs_contraction_apply(None, vecs, res), 'null contraction')
+    assert L.qgs_contraction_apply(hc, vecs, res) == 0
+    assert np.array_equal(res, [3. * 17. * 1.5, 0., 0., 2. * 19. * -2.0])            # res[0] is the caller's to overwrite
+    assert L.qgs_contraction_destroy(hc) == 0 and L.qgs_contraction_destroy(None) == 0
     # ... and the model is still usable
     assert np.array_equal(m.rk_integrate(t, ic, 1, 1, B, C, A), good)
     m.close()
