@@ -815,7 +815,7 @@ def main():
     ic_host = rng.rand(n_traj, ndim) * 0.01
     engine = HipEngine(torch, dist, dev, model, ndim, n_traj, ic_host, time_grid, (b, c, a), world, rank, use_dist)
 
-    ref_passes = min(args.steps, 50) if world > 1 else 0
+    ref_passes = min(args.steps, 50) if use_dist else 0     # (with --force-dist also at world size 1: the N > 1 code path, exercised on one GPU)
     elapsed, ref_elapsed, gather_ms = rank_body(engine, dist, use_dist, args.steps, args.warmup, reference_passes=ref_passes)
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in engine.kern_events])) if engine.kern_events else float('nan')

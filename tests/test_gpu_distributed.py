@@ -117,13 +117,20 @@ def _bench(*args, timeout=900):
 
 
 def test_bench_with_a_process_group_at_world_size_one():
-    rc, out, err = _bench('--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extra-configs')
+    rc, out, err = _bench('--gpus', '1', '--force-dist', '--steps', '4', '--warmup', '1', '--no-cpu-baseline', '--no-extra-configs',
+                          '--no-cold-start')
     assert rc == 0, err[-3000:]
     lines = [ln for ln in out.splitlines() if ln.startswith('{')]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r['n_gpus'] == 1 and r['steps'] == 2 and r['value'] > 1e9
+    assert r['n_gpus'] == 1 and r['steps'] == 4 and r['value'] > 1e9
     assert r['gather_ms'] is not None and r['gather_ms'] > 0.0
+    # the entries of an N > 1 line: the gather-free per-GPU reference (the denominator of the scaling efficiency) and the total
+    ref = r['single_gpu_reference']
+    assert ref['members_per_gpu'] == 65536 and ref['passes'] == 4 and ref['value'] > 1e9
+    assert 0.5 < ref['value_over_n_times_reference'] < 1.5 and r['config']['members_total'] == 65536
+    # and the timed kernel's own output was checked against the oracle
+    assert r['parity_check']['ok'] and r['parity_check']['kernel'] == r['roofline']['kernel'] and 'parity_failures' not in r
     assert r['roofline']['bound'] == 'fp64_valu' and 0.3 < r['roofline']['frac'] <= 1.0
     assert r['roofline']['kernel'].startswith('qgs_spec_rk')
 
