@@ -47,7 +47,11 @@ int qgs_backend_info(int *n_devices, char *arch_buf, int buflen);
  *   coo/val   : qgs/functions/tendencies.py:92-93   coo = tensor.coords.T (nnz,3), val = tensor.data
  *   jcoo/jval : qgs/functions/tendencies.py:95-96   jacobian_tensor ditto (may be NULL/0: then
  *               qgs_jacobian and qgs_rk_tgls_integrate are unavailable)
- * Replaces the closure capture of create_tendencies (tendencies.py:111-121). */
+ * Replaces the closure capture of create_tendencies (tendencies.py:111-121).
+ * As in the reference (numba compiles sparse_mul3 once; `val` is a run-time operand, sparse_mul.py:48-81) the VALUES are data:
+ * the specialised kernels are generated from, and cached under, the STRUCTURE of the tensor (coordinates, which coefficients
+ * share a magnitude -- to within 2 ulp --, signs); every model stores its own coefficients into the tables of the module it
+ * loads.  Models that differ in parameter values share their code objects. */
 int qgs_model_create(int device, int ndim,
                      int64_t nnz, const int32_t *coo, const double *val,
                      int64_t jnnz, const int32_t *jcoo, const double *jval,
@@ -258,7 +262,8 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
 /* Same for the shape-specialised batched QR kernel of qgs_batched_qr_device (n_cols <= n_rows <= 64). */
 int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch);
 
-/* Generated HIP source of the specialised kernels of this model (debugging / inspection).
+/* Generated HIP source of the specialised kernels of this model (debugging / inspection); value-free: the coefficient
+ * tables are declared without initialisers.
  * Returns the length; copies at most buflen-1 bytes. */
 int64_t qgs_model_kernel_source(const qgs_model *m, char *buf, int64_t buflen);
 
