@@ -1,0 +1,45 @@
+"""GPU box: the Benettin estimator with every interval recorded at config-4 size (16 384 members x 36 vectors) -- a record far
+beyond the device budget of the windows (default 8 GB) that lands in host memory window by window.
+Prints the size of the record, the windows it was cut into, the wall time and the transfer rate; checks orthonormality of a few
+recorded bases.  Usage: lyap_big.py [recorded intervals, default: what fits 35 % of the host's available memory, at most 400]."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, 'tests'))
+import model_configs                                                  # noqa: E402
+from qgs_amd.functions.tendencies import create_tendencies           # noqa: E402
+from qgs_amd.toolbox import lyapunov                                  # noqa: E402
+
+n, nv, ndim = 16384, 36, 36
+per_record = 8 * n * (ndim * nv + ndim + nv)
+avail = lyapunov._host_memory_available() or (64 << 30)
+intervals = int(sys.argv[1]) if len(sys.argv) > 1 else int(min(400, 0.35 * avail / per_record - 1))
+f, Df = create_tendencies(model_configs.params_m36())
+est = lyapunov.LyapunovsEstimator(num_threads=1)
+est.set_func(f, Df)
+ic = np.random.RandomState(0).rand(n, ndim) * 0.01
+np.random.seed(0)
+est.compute_lyapunovs(0., 1., 1.5, 0.1, 0.01, ic=ic[:256], write_steps=1)          # warm-up (kernels, pools)
+out = {'members': n, 'vectors': nv, 'recorded_intervals': intervals, 'record_gb': per_record * (intervals + 1) / 1e9,
+       'host_available_gb': avail / 1e9, 'device_window_budget_mb': lyapunov._window_budget_bytes() / 1048576.0}
+np.random.seed(1)
+t0 = time.perf_counter()
+est.compute_lyapunovs(0., 2., 2. + 0.1 * intervals, 0.1, 0.01, ic=ic, write_steps=1, n_vec=nv)
+el = time.perf_counter() - t0
+tt, traj, exps, vecs = est.get_lyapunovs()
+out.update({'seconds': el, 'windows_base_records': est.last_windows, 'gb_per_s': out['record_gb'] / el,
+            'ms_per_interval': el / (intervals + 20) * 1e3, 'vectors_shape': list(vecs.shape)})
+dev = 0.0
+for i in (0, n // 2, n - 1):
+    for r in (0, intervals // 2, intervals):
+        q = vecs[i, :, :, r]
+        dev = max(dev, float(np.abs(q.T @ q - np.eye(nv)).max()))
+out['max_orthonormality_defect'] = dev
+out['lambda_1_mean'] = float(np.mean(exps[:, 0, :]))
+print(json.dumps(out, indent=1))
