@@ -149,11 +149,19 @@ class _Store(object):
     """One block of host memory of the result pool, page-locked while it lives (qgs_host_register): device-to-host copies
     into it run at the pinned PCIe rate, and the page faults of a fresh allocation are taken once, not inside a copy."""
 
+    #: blocks above this size are not page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB): they stay pageable and are filled
+    #: through staged copies.  Page-locking takes the pages out of the kernel's hands for good; the largest blocks measured
+    #: page-locked are 170 GB (profiles/r04_lyap_big_1000.json) and 189 GB (profiles/r03_big_record_10000.txt), and a 0.85 TB one was being set up when a box of the pool went
+    #: down (DESIGN 3.6) -- nothing of that size is handed to the driver any more.
+    PIN_MAX_BYTES = int(os.environ.get('QGS_HOST_PIN_MAX_BYTES', str(256 << 30)))
+
     def __init__(self, n_doubles):
         self.array = np.empty(n_doubles)
         self.nbytes = self.array.nbytes
         self.size = n_doubles
         self._pinned = False
+        if self.nbytes > self.PIN_MAX_BYTES:
+            return
         try:
             self._pinned = lib().qgs_host_register(self.array.ctypes.data_as(_vp), self.nbytes) == 0
         except Exception:

@@ -2275,6 +2275,10 @@ struct TempPin {
     double *lock(qgs_model *m, double *dst, size_t bytes)
     {
         if (m->tune.d2h_mode == 2) return nullptr;
+        // blocks above QGS_HOST_PIN_MAX_BYTES (default 256 GiB; the largest measured page-locked: 189 GB) stay pageable
+        size_t cap = (size_t)256 << 30;
+        if (const char *e = std::getenv("QGS_HOST_PIN_MAX_BYTES")) cap = (size_t)std::strtoull(e, nullptr, 10);
+        if (bytes > cap) return nullptr;
         if (hipHostRegister(dst, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         p = dst;
         void *dp = nullptr;

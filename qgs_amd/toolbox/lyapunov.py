@@ -48,15 +48,65 @@ def _window_budget_bytes():
     return int(max(1.0, mb * 1048576.0))
 
 
+def _cgroup_memory_room(proc_cgroup='/proc/self/cgroup', sys_root='/sys/fs/cgroup'):
+    """Bytes this process' control groups still allow (limit - usage, the tightest of the groups found), or None when no
+    group sets a limit.  /proc/meminfo describes the machine, not the container: a container limit is only visible here."""
+    rooms = []
+
+    def read(path):
+        try:
+            with open(path) as f:
+                v = f.read().strip()
+            return None if v in ('', 'max') else int(v)
+        except (OSError, ValueError):
+            return None
+    paths = {'': ''}
+    try:
+        with open(proc_cgroup) as f:
+            for line in f:
+                parts = line.strip().split(':', 2)
+                if len(parts) == 3:
+                    if parts[0] == '0' and parts[1] == '':
+                        paths['v2'] = parts[2]
+                    elif 'memory' in parts[1].split(','):
+                        paths['v1'] = parts[2]
+    except OSError:
+        pass
+    candidates = []
+    for root, sub, lim, cur in ((sys_root, paths.get('v2', ''), 'memory.max', 'memory.current'),
+                                (os.path.join(sys_root, 'unified'), paths.get('v2', ''), 'memory.max', 'memory.current'),
+                                (os.path.join(sys_root, 'memory'), paths.get('v1', ''), 'memory.limit_in_bytes', 'memory.usage_in_bytes')):
+        # the group itself and every ancestor up to the mount point (a limit anywhere on the way applies)
+        sub = sub.strip('/')
+        chain = [''] + ['/'.join(sub.split('/')[:k]) for k in range(1, len(sub.split('/')) + 1)] if sub else ['']
+        for c in chain:
+            d = os.path.join(root, c) if c else root
+            candidates.append((os.path.join(d, lim), os.path.join(d, cur)))
+    for lim_path, cur_path in candidates:
+        limit = read(lim_path)
+        if limit is None or limit >= (1 << 60):                   # "max" / the v1 spelling of no limit
+            continue
+        used = read(cur_path) or 0
+        rooms.append(max(0, limit - used))
+    return min(rooms) if rooms else None
+
+
 def _host_memory_available():
+    """Host memory a result can still take: MemAvailable of /proc/meminfo, cut down to what the process' control groups
+    allow; None when neither can be read."""
+    avail = None
     try:
         with open('/proc/meminfo') as f:
             for line in f:
                 if line.startswith('MemAvailable:'):
-                    return int(line.split()[1]) * 1024
+                    avail = int(line.split()[1]) * 1024
+                    break
     except (OSError, ValueError, IndexError):
         pass
-    return None
+    room = _cgroup_memory_room()
+    if room is not None:
+        avail = room if avail is None else min(avail, room)
+    return avail
 
 
 class _BaseTrajectory(object):
@@ -266,7 +316,7 @@ class LyapunovsEstimator(object):
         nt, nd, nv, nr = self.n_traj, self.n_dim, self.n_vec, self.n_records
         need = 8 * nt * nr * (nd * nv + nd + nv)
         avail = _host_memory_available()
-        if avail is not None and need > 0.9 * avail:
+        if avail is not None and need > 0.8 * avail:
             raise MemoryError('host memory: the records of this run (%d members x %d records x (%d x %d vectors + state + exponents)) '
                               'need %.1f GB, %.1f GB are available -- raise write_steps, or lower n_vec or the number of members'
                               % (nt, nr, nd, nv, need / 1e9, avail / 1e9))

@@ -89,3 +89,36 @@ def test_record_window_plan_covers_every_record_once():
                 next_lo, next_step = hi, se
             assert next_lo == n_rec and next_step == n_steps and sorted(stored) == list(range(n_rec))
     assert L.qgs_record_window(0, 1, 1, 0, 1, 0, out) < 0 and _lib.last_error()
+
+
+def test_host_memory_guard_reads_the_container_limits(tmp_path):
+    """What a result may take of the host is MemAvailable cut down to the process' control-group limits (v2 `memory.max`, v1
+    `memory.limit_in_bytes`, on the group itself or any ancestor): /proc/meminfo describes the machine, not the container."""
+    from qgs_amd.toolbox import lyapunov
+    proc = tmp_path / 'cgroup'
+    root = tmp_path / 'sys'
+    # cgroup v2, limit on the parent group
+    (root / 'a' / 'b').mkdir(parents=True)
+    proc.write_text('0::/a/b\n')
+    (root / 'memory.max').write_text('max\n')
+    (root / 'a' / 'memory.max').write_text('%d\n' % (64 << 30))
+    (root / 'a' / 'memory.current').write_text('%d\n' % (4 << 30))
+    (root / 'a' / 'b' / 'memory.max').write_text('max\n')
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 60 << 30
+    # the tighter of two limits on the way
+    (root / 'a' / 'b' / 'memory.max').write_text('%d\n' % (16 << 30))
+    (root / 'a' / 'b' / 'memory.current').write_text('%d\n' % (1 << 30))
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 15 << 30
+    # cgroup v1 memory controller; 2^63-ish = no limit
+    proc.write_text('4:memory:/jobs/x\n0::/\n')
+    (root / 'memory' / 'jobs' / 'x').mkdir(parents=True)
+    (root / 'memory' / 'memory.limit_in_bytes').write_text('9223372036854771712\n')
+    (root / 'memory' / 'jobs' / 'x' / 'memory.limit_in_bytes').write_text('%d\n' % (32 << 30))
+    (root / 'memory' / 'jobs' / 'x' / 'memory.usage_in_bytes').write_text('%d\n' % (2 << 30))
+    (root / 'a' / 'memory.max').write_text('max\n')
+    (root / 'a' / 'b' / 'memory.max').write_text('max\n')
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 30 << 30
+    # no limit anywhere
+    (root / 'memory' / 'jobs' / 'x' / 'memory.limit_in_bytes').write_text('9223372036854771712\n')
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) is None
+    assert lyapunov._host_memory_available() > 0

@@ -20,6 +20,11 @@ n, nv, ndim = 16384, 36, 36
 per_record = 8 * n * (ndim * nv + ndim + nv)
 avail = lyapunov._host_memory_available() or (64 << 30)
 intervals = int(sys.argv[1]) if len(sys.argv) > 1 else int(min(400, 0.35 * avail / per_record - 1))
+if per_record * (intervals + 1) > (200 << 30) and os.environ.get('QGS_LYAP_BIG_ANYWAY') != '1':
+    # 180 GB is the largest record this tool has delivered; the 0.9 TB request (5 000 intervals) took a box of the pool down while
+    # its result block was being set up
+    sys.exit('lyap_big.py: %d intervals = %.0f GB of records; refusing above 200 GB (QGS_LYAP_BIG_ANYWAY=1 overrides)'
+             % (intervals, per_record * (intervals + 1) / 1e9))
 f, Df = create_tendencies(model_configs.params_m36())
 est = lyapunov.LyapunovsEstimator(num_threads=1)
 est.set_func(f, Df)
