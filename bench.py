@@ -501,10 +501,10 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     flops_tgls = 4 * (2 * jnnz) + 4 * 2 * ndim ** 3 + 7 * 2 * ndim * ndim + flops36     # 4.02e5 at ndim 36
     rate = n * steps / (ms_call * 1e-3)
     # what the two kernels of a call EXECUTE: fp64 instructions of their step loops, counted in the ISA (tools/kisa.py ->
-    # profiles/r03_kernel_isa.json; the tangent kernel's loop holds the tangent and the adjoint branch: half of it runs)
+    # profiles/r04_kernel_isa.json; the tangent kernel's loop holds the tangent and the adjoint branch: half of it runs)
     executed = None
     try:
-        with open(os.path.join(HERE, 'profiles', 'r03_kernel_isa.json')) as f:
+        with open(os.path.join(HERE, 'profiles', 'r04_kernel_isa.json')) as f:
             isa = json.load(f)
         tg_i = isa['bench:' + kname['name']]['hot_loop']['fp64'] / 2.0
         st_i = isa['bench:qgs_spec_rkstagesp_s4']['hot_loop']['fp64']
