@@ -112,9 +112,9 @@ struct GeneratedKernel {
 //
 // Magnitudes within 2 units in the last place of each other are ONE magnitude (the first to appear): the inner products of a
 // spectral model reach analytically equal coefficients along different floating-point routes, and whether two such results
-// agree in the last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ... 0.0300: four different
-// patterns of such splits in eleven values -- taken literally, four structures and sets of code objects where the model has
-// one).  The perturbation, <= 4.4e-16 relative on a coefficient, is far below the fp64 tolerances stated for the path.
+// agree in the last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ... 0.0300: three different
+// patterns of such splits in eleven values, a fourth at 0.031 -- taken literally, as many structures and sets of code objects
+// where the model has one).  The perturbation, <= 4.4e-16 relative on a coefficient, is far below the fp64 tolerances stated for the path.
 struct Canonical {
     std::vector<Term> terms;
     std::vector<double> magnitude;       // magnitude[0] = 0.0

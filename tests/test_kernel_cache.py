@@ -127,7 +127,7 @@ def test_parameter_sweep_shares_one_set_of_code_objects(tmp_path):
 
 def test_last_bit_differences_are_one_structure(tmp_path):
     """Analytically equal coefficients reach the tensor along different floating-point routes; whether two of them agree in the
-    last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ... 0.0300: four patterns in eleven values).
+    last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ... 0.0300: three patterns in eleven values).
     Magnitudes within 2 ulp of each other are one magnitude for the generator, so such tensors share their code objects."""
     g = load_golden('rp20')
     val, jval = g['val'], g['jval']
