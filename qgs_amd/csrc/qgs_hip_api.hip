@@ -907,6 +907,7 @@ struct qgs_model {
     // single-state fast path of f / Df: page-locked staging block the kernels read and write directly
     double *h_pin = nullptr, *d_pin = nullptr;
     size_t pin_cap = 0;
+    double *h_bounce = nullptr;                        // page-locked bounce block of the strided copies into pageable host memory
     unsigned *d_one_counter = nullptr;                 // "workgroups finished" word of the single-state kernels
     unsigned long long one_seq = 0;                    // sequence number of the last single-state call (the kernel echoes it into h_pin[0])
     // Jacobian tensor grouped by output element (generic_kernels.h OnePairs), models of up to 1024 variables
@@ -1593,6 +1594,7 @@ int qgs_model_destroy(qgs_model *m)
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
+    if (m->h_bounce) (void)hipHostFree(m->h_bounce);
     for (void *q : {(void *)m->d_one_counter, (void *)m->p_lut, (void *)m->p_ptr, (void *)m->p_idx, (void *)m->p_idx2, (void *)m->p_val})
         if (q) (void)hipFree(q);
     delete m;
@@ -2295,6 +2297,16 @@ struct DrainGuard {
     ~DrainGuard() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
 };
 
+// true for ordinary (pageable, unregistered) host memory
+static bool host_is_pageable(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return at.type != hipMemoryTypeHost && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged;
+}
+
+constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
+
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
 static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
                         const double *d_win, double *alias, double *dst_host, Buffer &staging, hipStream_t st)
@@ -2308,11 +2320,32 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
     if (staging.ensure(sizeof(double) * rows * (size_t)Wk)) return -1;
     qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, Wk, d_win, staging.f64(), st);
     HIPCHK(hipGetLastError());
-    if (Wk == n_records)
+    if (Wk == n_records) {
         HIPCHK(hipMemcpyAsync(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, hipMemcpyDeviceToHost, st));
-    else
+        return 0;
+    }
+    if (!host_is_pageable(dst_host)) {
+        // page-locked destination (QGS_HIP_D2H=copy): one strided DMA copy
         HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
                                 sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
+        return 0;
+    }
+    // Pageable destination, strided rows: through a page-locked bounce block and a CPU scatter.  (A 2-D copy straight into
+    // pageable memory makes the runtime lock "pitch x height" bytes from the first row's address -- first_record * 8 bytes
+    // more than the destination array has behind it; when the array ends where a mapping ends that aborts the process: seen
+    // once in about ten runs of the GPU suite, round 4.)  Blocking, which a copy into pageable memory is anyway.
+    if (!m->h_bounce) {
+        HIPCHK(hipHostMalloc((void **)&m->h_bounce, BOUNCE_BYTES, hipHostMallocDefault));
+    }
+    const size_t per_row = sizeof(double) * (size_t)Wk;
+    const size_t chunk_rows = std::max<size_t>(1, BOUNCE_BYTES / per_row);
+    for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+        const size_t nr = std::min(chunk_rows, rows - r0);
+        HIPCHK(hipMemcpyAsync(m->h_bounce, staging.f64() + r0 * (size_t)Wk, nr * per_row, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t r = 0; r < nr; ++r)
+            std::memcpy(dst_host + lo_s + (r0 + r) * (size_t)n_records, m->h_bounce + r * (size_t)Wk, per_row);
+    }
     return 0;
 }
 
