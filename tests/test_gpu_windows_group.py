@@ -598,3 +598,29 @@ def test_cache_miss_compiles_the_batched_qr(tmp_path):
         assert float([ln for ln in out.splitlines() if ln.startswith('WORST ')][0][6:]) < 1e-13
         counts.append(int([ln for ln in out.splitlines() if ln.startswith('FILES ')][0][6:]))
     assert counts == [2, 2], counts
+
+
+def test_record_windows_into_pageable_blocks_that_end_with_their_mapping():
+    """`qgs_unpack_window` into ordinary (pageable) NumPy blocks at record offsets > 0, for block sizes whose data ends close
+    to the end of its memory mapping.  A strided 2-D copy straight into such a block made the runtime lock more bytes than the
+    block has behind the first row (first_record * 8 too many) and aborted the process once in about ten runs of the GPU suite
+    (round 4); the copy now goes through a page-locked bounce block and a CPU scatter."""
+    import torch
+    from qgs_amd import _lib
+    L = _lib.lib()
+    g, m = _model('m36')
+    nd = g.ndim
+    vp = ctypes.c_void_p
+    rng = np.random.RandomState(0)
+    for n, nrec in ((256, 64), (257, 61), (300, 57), (512, 32), (63, 509), (128, 128), (1000, 17), (64, 1024)):
+        ld = (n + 63) // 64 * 64
+        host = np.full((n, nd, nrec), -1.0)                               # mmap'ed by the allocator at these sizes
+        w = 3
+        win = torch.from_numpy(rng.rand(w, nd, ld)).cuda()
+        for first in (nrec - w, nrec // 2, 1):
+            assert L.qgs_unpack_window(m._h, n, ld, nd, w, nrec, first, win.data_ptr(), host.ctypes.data_as(vp), None) == 0, _lib.last_error()
+            torch.cuda.synchronize()
+            want = win[:, :, :n].cpu().numpy().transpose(2, 1, 0)
+            assert np.array_equal(host[:, :, first:first + w], want)
+        assert np.all(host[:, :, 0] == -1.0)
+    m.close()
