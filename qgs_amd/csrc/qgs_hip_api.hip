@@ -2324,16 +2324,21 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
         HIPCHK(hipMemcpyAsync(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, hipMemcpyDeviceToHost, st));
         return 0;
     }
+#ifdef QGS_PAGEABLE_2D_COPY           // (diagnostic build only: the pre-fix behaviour, to reproduce the abort described below)
+    if (true) {
+#else
     if (!host_is_pageable(dst_host)) {
+#endif
         // page-locked destination (QGS_HIP_D2H=copy): one strided DMA copy
         HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
                                 sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
         return 0;
     }
-    // Pageable destination, strided rows: through a page-locked bounce block and a CPU scatter.  (A 2-D copy straight into
-    // pageable memory makes the runtime lock "pitch x height" bytes from the first row's address -- first_record * 8 bytes
-    // more than the destination array has behind it; when the array ends where a mapping ends that aborts the process: seen
-    // once in about ten runs of the GPU suite, round 4.)  Blocking, which a copy into pageable memory is anyway.
+    // Pageable destination, strided rows: through a page-locked bounce block and a CPU scatter, so that the runtime never has
+    // to pin the caller's pages in place for a strided copy (its footprint, pitch x height from the first row's address, is
+    // first_record * 8 bytes more than the array has behind it).  Such a copy aborted the process once in about ten runs of
+    // the GPU suite in round 4 (no message; 480 isolated repetitions did not reproduce it, tools/diag_pageable_2d.py with a
+    // -DQGS_PAGEABLE_2D_COPY build: the cause is not established).  Blocking, which a copy into pageable memory is anyway.
     if (!m->h_bounce) {
         HIPCHK(hipHostMalloc((void **)&m->h_bounce, BOUNCE_BYTES, hipHostMallocDefault));
     }
