@@ -2245,15 +2245,44 @@ static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_
     return p;
 }
 
-// device-side address of a destination block: the block itself when it is device memory, its mapped alias when it is
-// page-locked host memory (qgs_host_register / hipHostMalloc), null for pageable host memory
-static double *device_alias(qgs_model *m, double *dst, bool *is_device = nullptr)
+// Host blocks THIS library has page-locked and mapped (qgs_host_register, TempPin): the only host memory a kernel may store
+// into.  What hipPointerGetAttributes says about a host address cannot be used for that decision: the runtime pins the pages
+// of pageable hipMemcpy operands on its own and keeps those pins cached -- the source of a host-to-device copy READ-ONLY --
+// and reports any later allocation that reuses such an address as "host" memory with a device pointer.  A result block that
+// landed there was taken for page-locked, the unpack kernel stored into it and the process died with "Memory access fault by
+// GPU ... Write access to a read-only page" (once in about ten runs of the GPU suite; pytest's capture hid the message).
+std::mutex g_registered_mutex;
+std::map<uintptr_t, size_t> g_registered;              // start -> bytes
+
+static void registry_add(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered[(uintptr_t)p] = bytes;
+}
+static void registry_remove(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered.erase((uintptr_t)p);
+}
+static bool registry_covers(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    auto it = g_registered.upper_bound((uintptr_t)p);
+    if (it == g_registered.begin()) return false;
+    --it;
+    return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
+}
+
+// device-side address of a destination block of `bytes` bytes: the block itself when it is device memory, its mapped alias when
+// it lies inside a host block this library has page-locked (qgs_host_register / TempPin), null for any other host memory
+static double *device_alias(qgs_model *m, double *dst, size_t bytes, bool *is_device = nullptr)
 {
     if (is_device) *is_device = false;
     hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, dst) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    if (at.type == hipMemoryTypeDevice) { if (is_device) *is_device = true; return dst; }
-    if (at.type != hipMemoryTypeHost || m->tune.d2h_mode == 2) return nullptr;
+    if (hipPointerGetAttributes(&at, dst) == hipSuccess) {
+        if (at.type == hipMemoryTypeDevice) { if (is_device) *is_device = true; return dst; }
+    } else (void)hipGetLastError();
+    if (m->tune.d2h_mode == 2 || !registry_covers(dst, bytes)) return nullptr;
     void *dp = nullptr;
     if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return (double *)dp;
@@ -2283,11 +2312,12 @@ struct TempPin {
         if (bytes > cap) return nullptr;
         if (hipHostRegister(dst, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         p = dst;
+        registry_add(dst, bytes);
         void *dp = nullptr;
         if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         return (double *)dp;
     }
-    ~TempPin() { if (p) (void)hipHostUnregister(p); }
+    ~TempPin() { if (p) { registry_remove(p); (void)hipHostUnregister(p); } }
 };
 
 // Whatever way a pipelined call ends -- also on an error in the middle of it -- nothing of it may still be in flight when its
@@ -2297,13 +2327,6 @@ struct DrainGuard {
     ~DrainGuard() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
 };
 
-// true for ordinary (pageable, unregistered) host memory
-static bool host_is_pageable(const void *p)
-{
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return true; }
-    return at.type != hipMemoryTypeHost && at.type != hipMemoryTypeDevice && at.type != hipMemoryTypeManaged;
-}
 
 constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
 
@@ -2327,7 +2350,7 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
 #ifdef QGS_PAGEABLE_2D_COPY           // (diagnostic build only: the pre-fix behaviour, to reproduce the abort described below)
     if (true) {
 #else
-    if (!host_is_pageable(dst_host)) {
+    if (registry_covers(dst_host, sizeof(double) * rows * (size_t)n_records)) {
 #endif
         // page-locked destination (QGS_HIP_D2H=copy): one strided DMA copy
         HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
@@ -2382,7 +2405,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     const double *d_time, *d_tab_spec, *d_tab_full;
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
     bool dst_dev = false;
-    double *alias = device_alias(m, traj, &dst_dev);
+    double *alias = device_alias(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records, &dst_dev);
     if (alias && prefer_copy_route(m, dst_dev, n_records, modes_b)) alias = nullptr;
     TempPin pin;
     if (!alias && !dst_dev && !prefer_copy_route(m, false, n_records, modes_b))
@@ -2436,7 +2459,7 @@ int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner,
     if (n_inner < 1 || n_inner > (int64_t)65535 * 64 || n_window < 1 || n_records < 1 || first_record < 0 ||
         first_record + n_window > n_records || !d_window || !dst) return fail("bad window arguments");
     HIPCHK(hipSetDevice(m->device));
-    double *alias = device_alias(m, dst);
+    double *alias = device_alias(m, dst, sizeof(double) * (size_t)n_traj * (size_t)n_inner * (size_t)n_records);
     return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream);
 }
 
@@ -2553,7 +2576,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     const double *d_time, *d_tab_spec, *d_tab_full;
     if (stage_time_tab(m, time, n_time, time_direction, s, b, a, sc, &d_time, &d_tab_spec, &d_tab_full)) return -1;
     bool dev_t = false, dev_f = false;
-    double *alias_t = device_alias(m, traj, &dev_t), *alias_f = device_alias(m, fmatrix, &dev_f);
+    double *alias_t = device_alias(m, traj, rows_b * (size_t)n_records, &dev_t), *alias_f = device_alias(m, fmatrix, tg_rows_b * (size_t)n_records, &dev_f);
     if (prefer_copy_route(m, dev_t || dev_f, n_records, modes_b + tg_modes_b)) alias_t = alias_f = nullptr;
     TempPin pin_t, pin_f;
     if (!dev_t && !dev_f && !prefer_copy_route(m, false, n_records, modes_b + tg_modes_b)) {
@@ -2674,12 +2697,14 @@ int qgs_host_register(void *ptr, int64_t bytes)
     if (!ptr || bytes <= 0) return fail("bad arguments");
     // portable + mapped: every GPU of the node can store into the block (the unpack kernels of all shards write their slices)
     HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+    registry_add(ptr, (size_t)bytes);
     return 0;
 }
 
 int qgs_host_unregister(void *ptr)
 {
     if (!ptr) return fail("bad arguments");
+    registry_remove(ptr);
     HIPCHK(hipHostUnregister(ptr));
     return 0;
 }
@@ -2805,7 +2830,7 @@ int qgs_group_rk_integrate(qgs_group *g, int64_t n_traj, const double *ic, const
     // not each lock their own): every GPU then stores its slice itself
     TempPin pin;
     const size_t bytes = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec;
-    if (bytes >= ((size_t)32 << 20) && !device_alias(g->models[0], traj)) (void)pin.lock(g->models[0], traj, bytes);
+    if (bytes >= ((size_t)32 << 20) && !device_alias(g->models[0], traj, bytes)) (void)pin.lock(g->models[0], traj, bytes);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_integrate(g->models[(size_t)i], n, ic + a0 * nd, time, n_time, time_direction, write_steps, s, b, c, a,
                                 traj + a0 * nd * nrec);
@@ -2822,8 +2847,8 @@ int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, cons
     const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
     TempPin pin_t, pin_f;
     const size_t bytes_t = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec, bytes_f = bytes_t * (size_t)n_tg;
-    if (bytes_t >= ((size_t)32 << 20) && !device_alias(g->models[0], traj)) (void)pin_t.lock(g->models[0], traj, bytes_t);
-    if (bytes_f >= ((size_t)32 << 20) && !device_alias(g->models[0], fmatrix)) (void)pin_f.lock(g->models[0], fmatrix, bytes_f);
+    if (bytes_t >= ((size_t)32 << 20) && !device_alias(g->models[0], traj, bytes_t)) (void)pin_t.lock(g->models[0], traj, bytes_t);
+    if (bytes_f >= ((size_t)32 << 20) && !device_alias(g->models[0], fmatrix, bytes_f)) (void)pin_f.lock(g->models[0], fmatrix, bytes_f);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_tgls_integrate(g->models[(size_t)i], n, n_tg, ic + a0 * nd, tg_ic + a0 * nd * n_tg, time, n_time,
                                      time_direction, write_steps, s, b, c, a, adjoint, inverse, traj + a0 * nd * nrec,
