@@ -602,10 +602,10 @@ def test_cache_miss_compiles_the_batched_qr(tmp_path):
 
 def test_record_windows_into_pageable_blocks_that_end_with_their_mapping():
     """`qgs_unpack_window` into ordinary (pageable) NumPy blocks at record offsets > 0, for block sizes whose data ends close
-    to the end of its memory mapping.  A strided 2-D copy straight into pageable memory (the runtime pins the caller's pages
-    in place; the footprint it computes is first_record * 8 bytes longer than the block) aborted the process once in about ten
-    runs of the GPU suite in round 4 -- not reproduced in isolation, cause not established; the copy now goes through a
-    page-locked bounce block and a CPU scatter, and this test keeps the pattern exercised."""
+    to the end of its memory mapping.  Such blocks are pageable memory whatever hipPointerGetAttributes says about their
+    addresses (the runtime's cached pins of earlier pageable copies make reused addresses look page-locked -- and read-only for
+    the GPU when the pin belonged to a copy source): the library stores into host blocks only when it registered them itself,
+    and strided rows reach pageable blocks through a page-locked bounce block."""
     import torch
     from qgs_amd import _lib
     L = _lib.lib()
