@@ -792,6 +792,66 @@ struct UploadRing {
     }
 };
 
+// Host blocks THIS library has page-locked and mapped (qgs_host_register, TempPin): the only host memory a kernel may store
+// into.  What hipPointerGetAttributes says about a host address cannot be used for that decision: the runtime pins the pages
+// of pageable hipMemcpy operands on its own and keeps those pins cached -- the source of a host-to-device copy READ-ONLY --
+// and reports any later allocation that reuses such an address as "host" memory with a device pointer.  A result block that
+// landed there was taken for page-locked, the unpack kernel stored into it and the process died with "Memory access fault by
+// GPU ... Write access to a read-only page" (once in about ten runs of the GPU suite; pytest's capture hid the message).
+std::mutex g_registered_mutex;
+std::map<uintptr_t, size_t> g_registered;              // start -> bytes
+
+void registry_add(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered[(uintptr_t)p] = bytes;
+}
+void registry_remove(const void *p)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    g_registered.erase((uintptr_t)p);
+}
+bool registry_covers(const void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lock(g_registered_mutex);
+    auto it = g_registered.upper_bound((uintptr_t)p);
+    if (it == g_registered.begin()) return false;
+    --it;
+    return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
+}
+
+// Copies between device memory and the CALLER's host memory.  A block this library page-locked itself is copied asynchronously
+// on `st`.  Any other host memory is pageable as far as the library knows, and for a pageable operand the runtime pins the
+// caller's pages in place -- read-only when they are the source.  Several host threads doing that at once (the shards of a
+// device group: their slices, and small neighbouring arrays of the caller, share pages) let a page end up read-only for the
+// GPU while another thread's device-to-host copy is writing to it: "Memory access fault by GPU ... Write access to a read-only
+// page", three times in about thirty runs of the GPU suite in round 4, never with serialised launches.  Pageable copies are
+// therefore made one at a time, process-wide, and have completed when the call returns (they are synchronous for the runtime
+// anyway); what the stream still has to produce is waited for BEFORE the lock is taken.
+std::mutex g_pageable_copy_mutex;
+
+int copy_with_host(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const void *host_side, hipStream_t st)
+{
+    if (bytes == 0) return 0;
+    if (registry_covers(host_side, bytes)) {
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
+        return 0;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    std::lock_guard<std::mutex> lock(g_pageable_copy_mutex);
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st = nullptr)
+{
+    return copy_with_host(dst_dev, src_host, bytes, hipMemcpyHostToDevice, src_host, st);
+}
+int copy_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st = nullptr)
+{
+    return copy_with_host(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, dst_host, st);
+}
+
 struct KernelInfo {
     std::string name;
     int vgprs = 0, sgprs = 0, lds = 0, scratch = 0;
@@ -957,14 +1017,14 @@ int upload_csr(const HostCsr &h, DevCsr &d)
     HIPCHK(hipMalloc((void **)&d.rowptr, sizeof(int32_t) * h.rowptr.size()));
     HIPCHK(hipMalloc((void **)&d.idx, sizeof(uint32_t) * std::max<size_t>(1, h.idx.size())));
     HIPCHK(hipMalloc((void **)&d.val, sizeof(double) * std::max<size_t>(1, h.val.size())));
-    HIPCHK(hipMemcpy(d.rowptr, h.rowptr.data(), sizeof(int32_t) * h.rowptr.size(), hipMemcpyHostToDevice));
+    if (copy_h2d(d.rowptr, h.rowptr.data(), sizeof(int32_t) * h.rowptr.size())) return -1;
     if (!h.idx.empty()) {
-        HIPCHK(hipMemcpy(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d.val, h.val.data(), sizeof(double) * h.val.size(), hipMemcpyHostToDevice));
+        if (copy_h2d(d.idx, h.idx.data(), sizeof(uint32_t) * h.idx.size())) return -1;
+        if (copy_h2d(d.val, h.val.data(), sizeof(double) * h.val.size())) return -1;
     }
     if (!h.idx2.empty()) {
         HIPCHK(hipMalloc((void **)&d.idx2, sizeof(uint32_t) * h.idx2.size()));
-        HIPCHK(hipMemcpy(d.idx2, h.idx2.data(), sizeof(uint32_t) * h.idx2.size(), hipMemcpyHostToDevice));
+        if (copy_h2d(d.idx2, h.idx2.data(), sizeof(uint32_t) * h.idx2.size())) return -1;
     }
     return 0;
 }
@@ -973,7 +1033,7 @@ template <class T>
 int upload_vec(const std::vector<T> &h, T **d)
 {
     HIPCHK(hipMalloc((void **)d, sizeof(T) * std::max<size_t>(1, h.size())));
-    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    if (!h.empty() && copy_h2d(*d, h.data(), sizeof(T) * h.size())) return -1;
     return 0;
 }
 
@@ -1162,7 +1222,7 @@ int load_blob(qgs_model *m, const std::string &fname, const KernelBlob &blob, co
         } catch (const std::exception &ex) {
             return fail(std::string("coefficient table ") + t.symbol + ": " + ex.what());
         }
-        HIPCHK(hipMemcpyHtoD(dptr, values.data(), bytes));
+        if (copy_h2d((void *)dptr, values.data(), bytes)) return -1;
     }
     hipFunction_t f;
     hipError_t e = hipModuleGetFunction(&f, mod, fname.c_str());
@@ -1722,7 +1782,7 @@ int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double
         if (!m->b_unit.p) {
             const double unit[4] = {0.0, 1.0, 1.0, 0.0};                      // time grid {0, 1}; tableau b = {1}
             if (m->b_unit.ensure(sizeof unit)) return -1;
-            HIPCHK(hipMemcpy(m->b_unit.p, unit, sizeof unit, hipMemcpyHostToDevice));
+            if (copy_h2d(m->b_unit.p, unit, sizeof unit)) return -1;
         }
         return launch_rk_lds(m, n_traj, ld, d_x, d_dx, nullptr, nullptr, m->b_unit.f64(), m->b_unit.f64() + 2, 0, 1, 0, 1, 0, 0, 1,
                              st, qgs::Kernel::TendLds);
@@ -2182,11 +2242,11 @@ int qgs_tendencies(qgs_model *m, int64_t n_traj, const double *x, double *dx)
     const int64_t ld = round_ld(n_traj);
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_rec_modes.ensure(modes_b)) return -1;
-    HIPCHK(hipMemcpy(m->b_in_rows.p, x, rows_b, hipMemcpyHostToDevice));
+    if (copy_h2d(m->b_in_rows.p, x, rows_b)) return -1;
     if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
     if (qgs_tendencies_device(m, n_traj, ld, m->b_in_modes.f64(), m->b_rec_modes.f64(), nullptr)) return -1;
     if (qgs_unpack_states(m, n_traj, ld, m->b_rec_modes.f64(), m->b_in_rows.f64(), nullptr)) return -1;
-    HIPCHK(hipMemcpy(dx, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost));
+    if (copy_d2h(dx, m->b_in_rows.p, rows_b)) return -1;
     return 0;
 }
 
@@ -2200,12 +2260,12 @@ int qgs_jacobian(qgs_model *m, int64_t n_traj, const double *x, double *jac)
     const size_t rows_b = sizeof(double) * (size_t)n_traj * m->ndim, modes_b = sizeof(double) * (size_t)ld * m->ndim;
     const size_t jm_b = sizeof(double) * (size_t)ld * nn, jr_b = sizeof(double) * (size_t)n_traj * nn;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_fm_modes.ensure(jm_b) || m->b_fm_rows.ensure(jr_b)) return -1;
-    HIPCHK(hipMemcpy(m->b_in_rows.p, x, rows_b, hipMemcpyHostToDevice));
+    if (copy_h2d(m->b_in_rows.p, x, rows_b)) return -1;
     if (qgs_pack_states(m, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), nullptr)) return -1;
     if (jacobian_device(m, n_traj, ld, m->b_in_modes.f64(), m->b_fm_modes.f64(), nullptr)) return -1;
     qgs::launch_unpack_records(nn, n_traj, ld, 1, m->b_fm_modes.f64(), m->b_fm_rows.f64(), nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(jac, m->b_fm_rows.p, jr_b, hipMemcpyDeviceToHost));
+    if (copy_d2h(jac, m->b_fm_rows.p, jr_b)) return -1;
     return 0;
 }
 
@@ -2243,34 +2303,6 @@ static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_
     if (p.W >= n_records) { p.W = n_records; p.n_windows = 1; }
     else p.n_windows = (n_records + p.W - 1) / p.W;
     return p;
-}
-
-// Host blocks THIS library has page-locked and mapped (qgs_host_register, TempPin): the only host memory a kernel may store
-// into.  What hipPointerGetAttributes says about a host address cannot be used for that decision: the runtime pins the pages
-// of pageable hipMemcpy operands on its own and keeps those pins cached -- the source of a host-to-device copy READ-ONLY --
-// and reports any later allocation that reuses such an address as "host" memory with a device pointer.  A result block that
-// landed there was taken for page-locked, the unpack kernel stored into it and the process died with "Memory access fault by
-// GPU ... Write access to a read-only page" (once in about ten runs of the GPU suite; pytest's capture hid the message).
-std::mutex g_registered_mutex;
-std::map<uintptr_t, size_t> g_registered;              // start -> bytes
-
-static void registry_add(const void *p, size_t bytes)
-{
-    std::lock_guard<std::mutex> lock(g_registered_mutex);
-    g_registered[(uintptr_t)p] = bytes;
-}
-static void registry_remove(const void *p)
-{
-    std::lock_guard<std::mutex> lock(g_registered_mutex);
-    g_registered.erase((uintptr_t)p);
-}
-static bool registry_covers(const void *p, size_t bytes)
-{
-    std::lock_guard<std::mutex> lock(g_registered_mutex);
-    auto it = g_registered.upper_bound((uintptr_t)p);
-    if (it == g_registered.begin()) return false;
-    --it;
-    return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
 }
 
 // device-side address of a destination block of `bytes` bytes: the block itself when it is device memory, its mapped alias when
@@ -2344,8 +2376,7 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
     qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, Wk, d_win, staging.f64(), st);
     HIPCHK(hipGetLastError());
     if (Wk == n_records) {
-        HIPCHK(hipMemcpyAsync(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, hipMemcpyDeviceToHost, st));
-        return 0;
+        return copy_d2h(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, st);
     }
 #ifdef QGS_PAGEABLE_2D_COPY           // (diagnostic build only: the pre-fix behaviour, to reproduce the abort described below)
     if (true) {
@@ -2397,7 +2428,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     const double *d_rows = ic_rows;
     if (!ic_on_device) {
         if (m->b_in_rows.ensure(rows_b)) return -1;
-        HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic_rows, rows_b, hipMemcpyHostToDevice, sc));
+        if (copy_h2d(m->b_in_rows.p, ic_rows, rows_b, sc)) return -1;
         d_rows = m->b_in_rows.f64();
     }
     qgs::launch_pack_states(nd, n_traj, ld, d_rows, m->b_in_modes.f64(), sc);
@@ -2505,7 +2536,7 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
     m->last_windows = plan.n_windows;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_win[0].ensure(modes_b * (size_t)plan.W) ||
         m->b_state2.ensure(modes_b) || m->b_carry.ensure(modes_b) || m->b_mom_out.ensure(sizeof(double) * 2 * (size_t)n_rows)) return -1;
-    HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice, sc));
+    if (copy_h2d(m->b_in_rows.p, ic, rows_b, sc)) return -1;
     qgs::launch_pack_states(nd, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), sc);
     HIPCHK(hipGetLastError());
     const double *d_time, *d_tab_spec, *d_tab_full;
@@ -2529,12 +2560,12 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
     }
     // device rows are (record, mode); the reference's axis order is (mode, record)
     std::vector<double> h((size_t)n_rows * 2);
-    HIPCHK(hipMemcpyAsync(h.data(), d_mean, sizeof(double) * (size_t)n_rows * (var ? 2 : 1), hipMemcpyDeviceToHost, sc));
+    if (copy_d2h(h.data(), d_mean, sizeof(double) * (size_t)n_rows * (var ? 2 : 1), sc)) return -1;
     if (final_states) {
         // the state after the last step of the directed run
         qgs::launch_unpack_states(nd, n_traj, ld, y_last, m->b_in_rows.f64(), sc);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(final_states, m->b_in_rows.p, rows_b, hipMemcpyDeviceToHost, sc));
+        if (copy_d2h(final_states, m->b_in_rows.p, rows_b, sc)) return -1;
     }
     HIPCHK(hipStreamSynchronize(sc));
     for (int64_t r = 0; r < n_records; ++r)
@@ -2567,8 +2598,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     const size_t tg_rows_b = rows_b * (size_t)n_tg, tg_modes_b = modes_b * (size_t)n_tg;
     hipStream_t sc = m->st_comp, sd = m->st_copy;
     if (m->b_in_rows.ensure(rows_b) || m->b_in_modes.ensure(modes_b) || m->b_tg_rows.ensure(tg_rows_b) || m->b_tg_modes.ensure(tg_modes_b)) return -1;
-    HIPCHK(hipMemcpyAsync(m->b_in_rows.p, ic, rows_b, hipMemcpyHostToDevice, sc));
-    HIPCHK(hipMemcpyAsync(m->b_tg_rows.p, tg_ic, tg_rows_b, hipMemcpyHostToDevice, sc));
+    if (copy_h2d(m->b_in_rows.p, ic, rows_b, sc) || copy_h2d(m->b_tg_rows.p, tg_ic, tg_rows_b, sc)) return -1;
     qgs::launch_pack_states(nd, n_traj, ld, m->b_in_rows.f64(), m->b_in_modes.f64(), sc);
     // padding lanes of the tangent state are read (never stored) by the specialised kernel: the pack defines them
     qgs::launch_pack_tangent(nd, n_tg, n_traj, ld, m->b_tg_rows.f64(), m->b_tg_modes.f64(), sc);
@@ -2674,11 +2704,11 @@ int qgs_contraction_apply(qgs_contraction *c, const double *vecs, double *res)
 {
     if (!c || !vecs || !res) return fail("bad arguments");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpy(c->d_vecs, vecs, sizeof(double) * (size_t)c->n_fac * c->n_slots, hipMemcpyHostToDevice));
+    if (copy_h2d(c->d_vecs, vecs, sizeof(double) * (size_t)c->n_fac * c->n_slots)) return -1;
     HIPCHK(hipMemsetAsync(c->d_res, 0, sizeof(double) * (size_t)c->out_len, nullptr));
     qgs::launch_contract(c->n_out, c->d_out_index, c->d_ptr, c->d_fidx, c->d_val, c->n_fac, c->d_vecs, c->n_slots, c->d_res, nullptr);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(res, c->d_res, sizeof(double) * (size_t)c->out_len, hipMemcpyDeviceToHost));
+    if (copy_d2h(res, c->d_res, sizeof(double) * (size_t)c->out_len)) return -1;
     return 0;
 }
 

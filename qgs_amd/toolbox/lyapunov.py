@@ -32,11 +32,18 @@ PyTorch is used for device buffers, streams and events only.
 """
 import multiprocessing
 import os
+import threading
 
 import numpy as np
 
 from qgs_amd.integrators import integrate as _fn
 from qgs_amd.functions.util import reverse
+
+
+#: Uploads from pageable NumPy memory are made one at a time across the shard threads of a device list: for a pageable operand
+#: the runtime pins the caller's pages in place, and several threads doing that at once (slices of one array, neighbouring small
+#: arrays) is what produced GPU write faults in round 4 (qgs_hip_api.hip copy_with_host).
+_UPLOAD_LOCK = threading.Lock()
 
 
 def _window_budget_bytes():
@@ -379,7 +386,9 @@ class LyapunovsEstimator(object):
         # base trajectory, every step recorded: R[step][mode][member], a window of steps at a time   (lyapunov.py:558 / :474)
         full_grid = np.concatenate((self._pretime[:-1], self._time))
         ic_modes = torch.zeros((ndim, ld), dtype=f64, device=dev)
-        ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
+        with _UPLOAD_LOCK:
+            ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
+            torch.cuda.current_stream(dev).synchronize()
         base = _BaseTrajectory(torch, m, n, ld, full_grid, ic_modes, budget // 4, forward, (self.b, self.c, self.a), stream)
         n_pre = len(self._pretime)
 
@@ -388,7 +397,9 @@ class LyapunovsEstimator(object):
         # (the drawn matrices go up as they are, (n, n_dim, n_vec), and are brought into the device layout F[mode][vector][member]
         # by the pack kernel: the host-side transpose of 170 MB at config-4 size took longer than the whole spin-up)
         q = torch.zeros((ndim, nv, ld), dtype=f64, device=dev)
-        a0_rows = torch.from_numpy(np.ascontiguousarray(a0)).to(dev)
+        with _UPLOAD_LOCK:
+            a0_rows = torch.from_numpy(np.ascontiguousarray(a0)).to(dev)
+            torch.cuda.current_stream(dev).synchronize()
         m.pack_tangent(n, ld, nv, a0_rows.data_ptr(), q.data_ptr(), stream)
         torch.cuda.current_stream(dev).synchronize()
         del a0_rows
