@@ -834,7 +834,10 @@ int copy_with_host(void *dst, const void *src, size_t bytes, hipMemcpyKind kind,
 {
     if (bytes == 0) return 0;
     if (registry_covers(host_side, bytes)) {
-        HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
+        // page-locked: asynchronous on the caller's stream (which the caller synchronises); a call without a stream of its
+        // own is a blocking entry point and gets the blocking copy
+        if (st) HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
+        else HIPCHK(hipMemcpy(dst, src, bytes, kind));
         return 0;
     }
     HIPCHK(hipStreamSynchronize(st));
