@@ -2194,7 +2194,11 @@ static int one_state_ready(qgs_model *m, size_t doubles)
     if (streams_ready(m) || pin_ensure(m, doubles + 1)) return -1;
     if (!m->d_one_counter) {
         HIPCHK(hipMalloc((void **)&m->d_one_counter, sizeof(unsigned)));
-        HIPCHK(hipMemset(m->d_one_counter, 0, sizeof(unsigned)));
+        // zeroed ON THE STREAM the single-state kernels run on, and waited for: a hipMemset on the null stream is not ordered
+        // with that (non-blocking) stream, and a kernel that started on an unset counter never recognises its last workgroup
+        // ("single-state kernel finished without reporting completion", seen once in a group of five one-member shards)
+        HIPCHK(hipMemsetAsync(m->d_one_counter, 0, sizeof(unsigned), m->st_comp));
+        HIPCHK(hipStreamSynchronize(m->st_comp));
     }
     return 0;
 }
