@@ -181,6 +181,11 @@ int qgs_contraction_destroy(qgs_contraction *c);
  * binding registers its recycled result blocks (qgs_amd/_lib.py _ResultPool).  Replaces nothing in the reference: its
  * results travel between processes through pickling queues (qgs/integrators/integrator.py:388-395). */
 int qgs_host_register(void *ptr, int64_t bytes);
+/* Page-locked host memory allocated by the runtime itself (portable, mapped): what result blocks should live in when the kernels
+ * are to store into them.  Unlike a registered block of the caller's it shares no pages with the C library's heap
+ * (every GPU write fault seen in round 4 hit registered heap memory). */
+int qgs_host_alloc(int64_t bytes, void **out);
+int qgs_host_free(void *ptr);
 int qgs_host_unregister(void *ptr);
 
 /* ---- device-layout entry points (pointers are device pointers on the model's device; the work

@@ -51,6 +51,8 @@ SIGNATURES = {
     'qgs_contraction_create': (_int, [_int, _int, _int, _int, _i64, _vp, _vp, ctypes.POINTER(_vp)]),
     'qgs_contraction_apply': (_int, [_vp, _f64p, _f64p]),
     'qgs_contraction_destroy': (_int, [_vp]),
+    'qgs_host_alloc': (_int, [_i64, ctypes.POINTER(_vp)]),
+    'qgs_host_free': (_int, [_vp]),
     'qgs_host_register': (_int, [_vp, _i64]),
     'qgs_host_unregister': (_int, [_vp]),
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
@@ -146,31 +148,41 @@ def _ptr(a):
 
 
 class _Store(object):
-    """One block of host memory of the result pool, page-locked while it lives (qgs_host_register): device-to-host copies
-    into it run at the pinned PCIe rate, and the page faults of a fresh allocation are taken once, not inside a copy."""
+    """One block of host memory of the result pool, page-locked while it lives: device-to-host copies into it run at the pinned
+    PCIe rate, the kernels can store into it, and the page faults of a fresh allocation are taken once, not inside a copy.
+    The block is allocated by the runtime (qgs_host_alloc = hipHostMalloc, portable + mapped), not carved out of the C
+    library's heap and registered: registered heap memory is where every GPU write fault of round 4 happened."""
 
-    #: blocks above this size are not page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB): they stay pageable and are filled
-    #: through staged copies.  Page-locking takes the pages out of the kernel's hands for good; the largest blocks measured
-    #: page-locked are 170 GB (profiles/r04_lyap_big_1000.json) and 189 GB (profiles/r03_big_record_10000.txt), and a 0.85 TB one was being set up when a box of the pool went
-    #: down (DESIGN 3.6) -- nothing of that size is handed to the driver any more.
+    #: blocks above this size are not page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB): they are ordinary NumPy memory and
+    #: are filled through staged copies.  Page-locking takes the pages out of the kernel's hands for good; the largest blocks
+    #: measured page-locked are 170 GB (profiles/r04_lyap_big_1000.json) and 189 GB (profiles/r03_big_record_10000.txt), and a
+    #: 0.85 TB one was being set up when a box of the pool went down (DESIGN 3.6) -- nothing of that size is handed to the driver
+    #: any more.
     PIN_MAX_BYTES = int(os.environ.get('QGS_HOST_PIN_MAX_BYTES', str(256 << 30)))
 
     def __init__(self, n_doubles):
-        self.array = np.empty(n_doubles)
-        self.nbytes = self.array.nbytes
         self.size = n_doubles
-        self._pinned = False
-        if self.nbytes > self.PIN_MAX_BYTES:
-            return
-        try:
-            self._pinned = lib().qgs_host_register(self.array.ctypes.data_as(_vp), self.nbytes) == 0
-        except Exception:
-            self._pinned = False
+        self.nbytes = 8 * n_doubles
+        self._ptr = None
+        if self.nbytes <= self.PIN_MAX_BYTES:
+            p = _vp()
+            try:
+                if lib().qgs_host_alloc(self.nbytes, ctypes.byref(p)) == 0 and p.value:
+                    self._ptr = p.value
+            except Exception:
+                self._ptr = None
+        if self._ptr is not None:
+            self.array = np.frombuffer((ctypes.c_char * self.nbytes).from_address(self._ptr), dtype=np.float64)
+        else:
+            self.array = np.empty(n_doubles)
+        self._pinned = self._ptr is not None
 
     def __del__(self):
         try:
-            if self._pinned:
-                lib().qgs_host_unregister(self.array.ctypes.data_as(_vp))
+            if self._ptr is not None:
+                self.array = None
+                lib().qgs_host_free(_vp(self._ptr))
+                self._ptr = None
         except Exception:
             pass
 

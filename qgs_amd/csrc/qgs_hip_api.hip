@@ -2349,6 +2349,11 @@ struct TempPin {
         size_t cap = (size_t)256 << 30;
         if (const char *e = std::getenv("QGS_HOST_PIN_MAX_BYTES")) cap = (size_t)std::strtoull(e, nullptr, 10);
         if (bytes > cap) return nullptr;
+        // ... and so do blocks below 32 MB: those come out of the C library's heap, whose pages they share with unrelated
+        // objects and whose mappings the allocator changes under them.  Every GPU write fault of round 4 ("Write access to a
+        // read-only page", about one in ten to twenty runs of the GPU suite) hit a heap address that a kernel was storing
+        // into through such a registration; blocks of this size and above are mappings of their own
+        if (bytes < ((size_t)32 << 20)) return nullptr;
         if (hipHostRegister(dst, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         p = dst;
         registry_add(dst, bytes);
@@ -2726,6 +2731,25 @@ int qgs_contraction_destroy(qgs_contraction *c)
     for (void *q : {(void *)c->d_out_index, (void *)c->d_ptr, (void *)c->d_fidx, (void *)c->d_val, (void *)c->d_vecs, (void *)c->d_res})
         if (q) (void)hipFree(q);
     delete c;
+    return 0;
+}
+
+int qgs_host_alloc(int64_t bytes, void **out)
+{
+    if (!out || bytes <= 0) return fail("bad arguments");
+    *out = nullptr;
+    void *p = nullptr;
+    HIPCHK(hipHostMalloc(&p, (size_t)bytes, hipHostMallocPortable | hipHostMallocMapped));
+    registry_add(p, (size_t)bytes);
+    *out = p;
+    return 0;
+}
+
+int qgs_host_free(void *ptr)
+{
+    if (!ptr) return 0;
+    registry_remove(ptr);
+    HIPCHK(hipHostFree(ptr));
     return 0;
 }
 
