@@ -2403,8 +2403,8 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
     // Pageable destination, strided rows: through a page-locked bounce block and a CPU scatter, so that the runtime never has
     // to pin the caller's pages in place for a strided copy (its footprint, pitch x height from the first row's address, is
     // first_record * 8 bytes more than the array has behind it).  Blocking, which a copy into pageable memory is anyway.
-    // (Introduced while hunting the GPU write fault described at g_registered, of which it was not the cause; kept: it is the
-    // simpler contract with the runtime.  -DQGS_PAGEABLE_2D_COPY restores the 2-D copy, tools/diag_pageable_2d.py.)
+    // (One of the steps of the round-4 hunt for GPU write faults; -DQGS_PAGEABLE_2D_COPY restores the 2-D copy,
+    // tools/diag_pageable_2d.py.)
     if (!m->h_bounce) {
         HIPCHK(hipHostMalloc((void **)&m->h_bounce, BOUNCE_BYTES, hipHostMallocDefault));
     }
