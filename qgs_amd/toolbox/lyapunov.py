@@ -259,6 +259,9 @@ class LyapunovsEstimator(object):
         self.func = None
         self.func_jac = None
         self._model = None
+        self._recorded_pre = None         # (_run(pre_qr=True)) the propagated matrices before their QR, per record
+        self._junction = None             # (_run(junction=True)) the states at the first recorded time
+        self._fine_base = False
         self.last_windows = None          # (base-trajectory windows, record windows) of the last run, per shard
 
     def terminate(self):
@@ -299,13 +302,25 @@ class LyapunovsEstimator(object):
             return 0
         if self._model is None:
             self.start()
-        self.ic = np.zeros(_fn.dimension_of(self.func)) if ic is None else ic
+        ic = np.zeros(_fn.dimension_of(self.func)) if ic is None else ic
+        self._run(_fn.time_grid(t0, tw, dt), _fn.time_grid(tw, t, dt), mdt, ic, write_steps, n_vec, forward, adjoint, inverse)
+
+    def _run(self, pretime, time, mdt, ic, write_steps, n_vec, forward, adjoint, inverse, a0=None, pre_qr=False, junction=False,
+             fine_base=False):
+        """The Benettin run on explicit grids (`compute_lyapunovs` builds them from t0, tw, t, dt; the covariant estimator below
+        hands over its own).  `a0`: the (n_traj, n_dim, n_vec) start matrices instead of the reference's uniform draws.
+        `pre_qr`: also keep, per record, the propagated matrix BEFORE its QR step (`_recorded_pre`; R of that step is
+        Q(next record)^T times it).  `junction`: also keep the state at the first recorded time (`_junction`).  `fine_base`:
+        the base trajectory is integrated with the `mdt` sub-steps of the intervals instead of one step per interval (the
+        reference's Ginelli loop advances its state with the tangent integrator itself, lyapunov.py:1203-1247)."""
+        self._fine_base = fine_base
+        self.ic = ic
         if len(self.ic.shape) == 1:
             self.ic = self.ic.reshape((1, -1))
         self.n_traj, self.n_dim = self.ic.shape
         self.n_vec = self.n_dim if n_vec is None else n_vec
-        self._pretime = _fn.time_grid(t0, tw, dt)
-        self._time = _fn.time_grid(tw, t, dt)
+        self._pretime = pretime
+        self._time = time
         self.write_steps = write_steps
         self._forward = 1 if forward else -1
         self._adjoint = adjoint
@@ -321,7 +336,7 @@ class LyapunovsEstimator(object):
         # Their size is what bounds a run -- checked before anything is allocated or computed.
         from qgs_amd import _lib
         nt, nd, nv, nr = self.n_traj, self.n_dim, self.n_vec, self.n_records
-        need = 8 * nt * nr * (nd * nv + nd + nv)
+        need = 8 * nt * nr * (nd * nv * (2 if pre_qr else 1) + nd + nv)
         avail = _host_memory_available()
         if avail is not None and need > 0.8 * avail:
             raise MemoryError('host memory: the records of this run (%d members x %d records x (%d x %d vectors + state + exponents)) '
@@ -331,17 +346,24 @@ class LyapunovsEstimator(object):
             out_traj = _lib._RESULTS.empty((nt, nd, nr))
             out_vec = _lib._RESULTS.empty((nt, nd, nv, nr))
             out_exp = _lib._RESULTS.empty((nt, nv, nr))
+            out_pre = _lib._RESULTS.empty((nt, nd, nv, nr)) if pre_qr else None
         except MemoryError:
             raise MemoryError('host memory: could not allocate %.1f GB for the records of this run' % (need / 1e9))
 
         # random start bases: the matrices are drawn like the reference's (one draw per trajectory, in order:
         # `np.random.random((ndim, nv))` consumes the generator exactly as n such calls in a row do) -- for the WHOLE ensemble
         # before it is split over devices
-        a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))
+        if a0 is None:
+            a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))
+        self._junction = np.zeros((nt, nd)) if junction else None
+        outs = (out_traj, out_vec, out_exp) + ((out_pre,) if pre_qr else ())
+
+        def piece(a, cnt):
+            return tuple(o[a:a + cnt] for o in outs) + ((self._junction[a:a + cnt],) if junction else (None,))
         model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
         shards = getattr(model, 'models', None)
         if shards is None:
-            self.last_windows = [self._compute_shard(model, self.ic, a0, mdt, (out_traj, out_vec, out_exp))]
+            self.last_windows = [self._compute_shard(model, self.ic, a0, mdt, piece(0, nt))]
         else:
             # several GPUs: contiguous member shards, one host thread each (the work of a shard is a chain of kernel launches)
             import threading
@@ -351,8 +373,7 @@ class LyapunovsEstimator(object):
                 try:
                     a, cnt = model.shard(self.n_traj, i)
                     if cnt > 0:
-                        windows[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt,
-                                                         (out_traj[a:a + cnt], out_vec[a:a + cnt], out_exp[a:a + cnt]))
+                        windows[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt, piece(a, cnt))
                 except Exception as e:                       # re-raised on the calling thread
                     errors.append(e)
             threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shards))]
@@ -363,11 +384,12 @@ class LyapunovsEstimator(object):
             if errors:
                 raise errors[0]
             self.last_windows = [w for w in windows if w is not None]
-        self._recorded_traj, self._recorded_vec, self._recorded_exp = out_traj, out_vec, out_exp
+        self._recorded_traj, self._recorded_vec, self._recorded_exp, self._recorded_pre = out_traj, out_vec, out_exp, out_pre
 
     def _compute_shard(self, m, ic, a0, mdt, outs):
         """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
-        fills the slices `outs` = (traj, vectors, exponents) of the result blocks (reference layouts)."""
+        fills the slices `outs` = (traj, vectors, exponents[, matrices before the QR], junction state or None) of the result
+        blocks (reference layouts)."""
         import torch
         with torch.cuda.device(torch.device('cuda', m.device)):       # this thread's current device for the duration of the call only
             return self._compute_shard_on_current_device(m, ic, a0, mdt, outs)
@@ -380,11 +402,21 @@ class LyapunovsEstimator(object):
         dev = torch.device('cuda', m.device)
         f64 = torch.float64
         stream = torch.cuda.current_stream(dev).cuda_stream
-        out_traj, out_vec, out_exp = outs
+        out_traj, out_vec, out_exp = outs[:3]
+        out_pre = outs[3] if len(outs) > 4 else None
+        out_junction = outs[-1]
         budget = _window_budget_bytes()
 
         # base trajectory, every step recorded: R[step][mode][member], a window of steps at a time   (lyapunov.py:558 / :474)
         full_grid = np.concatenate((self._pretime[:-1], self._time))
+        at = np.arange(len(full_grid))                              # interval boundary -> index in the base trajectory's grid
+        if self._fine_base:
+            pieces = []
+            for i in range(len(full_grid) - 1):
+                tt, d = full_grid[i], full_grid[i + 1] - full_grid[i]
+                pieces.append(np.arange(tt, tt + d, mdt))            # (the sub-steps `propagate` is given, without the end point)
+                at[i + 1] = at[i] + len(pieces[-1])
+            full_grid = np.concatenate(pieces + [full_grid[-1:]])
         ic_modes = torch.zeros((ndim, ld), dtype=f64, device=dev)
         with _UPLOAD_LOCK:
             ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
@@ -413,15 +445,19 @@ class LyapunovsEstimator(object):
         q_new = torch.empty((1, ndim, nv, ld), dtype=f64, device=dev)
         y_end = torch.empty((1, ndim, ld), dtype=f64, device=dev)
         # records on their way to the host: vectors F[record][mode * vector][member], states, diag(R) of the QR before the interval
-        rec = _RecordWindows(torch, m, n, ld, (ndim * nv, ndim, nv), (out_vec, out_traj, out_exp), self.n_records, budget // 2, dev)
+        rec = _RecordWindows(torch, m, n, ld, (ndim * nv, ndim, nv) + ((ndim * nv,) if out_pre is not None else ()),
+                             (out_vec, out_traj, out_exp) + ((out_pre,) if out_pre is not None else ()), self.n_records, budget // 2, dev)
         rec_dt = np.ones(self.n_records)                             # interval length behind each record's exponents
 
-        def propagate(y_index, subtime, direction):
-            """q <- Q of QR( TL_{subtime}(q) ) along the trajectory started at base[y_index]; returns diag(R)."""
+        def propagate(y_index, subtime, direction, pre=None):
+            """q <- Q of QR( TL_{subtime}(q) ) along the trajectory started at base[y_index]; returns diag(R).
+            `pre`: device view that receives TL_{subtime}(q) as it is before the QR."""
             nonlocal q, q_new
-            m.rk_tgls_integrate_device(n, ld, nv, base.state(y_index).data_ptr(), q.data_ptr(), subtime, direction, 0,
+            m.rk_tgls_integrate_device(n, ld, nv, base.state(at[y_index]).data_ptr(), q.data_ptr(), subtime, direction, 0,
                                        self.b, self.c, self.a, adjoint, self._inverse, y_end.data_ptr(), q_new.data_ptr(),
                                        stream)
+            if pre is not None:
+                pre.copy_(q_new[0].reshape(ndim * nv, ld))
             rdiag = torch.empty((nv, ld), dtype=f64, device=dev)
             m.batched_qr_device(n, ld, ndim, nv, q_new.data_ptr(), rdiag.data_ptr(), stream)
             q, q_new = q_new[0], q.unsqueeze(0)
@@ -429,14 +465,19 @@ class LyapunovsEstimator(object):
 
         def record(iw, y_index, rdiag, d):
             """record iw <- (q, base[y_index], rdiag); exponents = log|rdiag| / d (None: no interval behind it -> zeros)"""
-            s_vec, s_traj, s_rd = rec.slot(iw)
-            s_traj.copy_(base.state(y_index))
+            slots = rec.slot(iw)
+            s_vec, s_traj, s_rd = slots[:3]
+            s_traj.copy_(base.state(at[y_index]))
             s_vec.copy_(q.reshape(ndim * nv, ld))
             if rdiag is None:
                 s_rd.fill_(1.0)
             else:
                 s_rd.copy_(rdiag)
                 rec_dt[iw] = d
+            if out_pre is not None:
+                slots[3].zero_()                   # (stays zero for a record no interval follows)
+                return slots[3]
+            return None
 
         if not forward:
             # ---- backward Lyapunov vectors (lyapunov.py:564-632) ----
@@ -448,16 +489,20 @@ class LyapunovsEstimator(object):
                 rdiag = propagate(ti, sub, 1)
             if rdiag is None:       # no spin-up interval
                 rdiag = rdiag0
+            if out_junction is not None:
+                with _UPLOAD_LOCK:
+                    out_junction[...] = base.state(at[n_pre - 1])[:, :n].t().cpu().numpy()
             iw, last = 0, None
             for ti in range(len(tim) - 1):
                 tt, d = tim[ti], tim[ti + 1] - tim[ti]
                 last = (rdiag, d)                                                   # m_exp = log|diag r| / dt
+                pre = None
                 if write_steps > 0 and ti % write_steps == 0:
-                    record(iw, n_pre - 1 + ti, rdiag, d)
+                    pre = record(iw, n_pre - 1 + ti, rdiag, d)
                     iw += 1
                 sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
-                rdiag = propagate(n_pre - 1 + ti, sub, 1)
-            record(self.n_records - 1, len(full_grid) - 1, last[0] if last else None, last[1] if last else 1.0)
+                rdiag = propagate(n_pre - 1 + ti, sub, 1, pre)
+            record(self.n_records - 1, len(at) - 1, last[0] if last else None, last[1] if last else 1.0)
         else:
             # ---- forward Lyapunov vectors (lyapunov.py:480-552): integrate the tangent model backward in time ----
             tim, post = self._pretime, self._time            # the reference's (time, posttime)
@@ -500,3 +545,237 @@ class LyapunovsEstimator(object):
                 kept = np.concatenate((kept, np.full((1,), tt[-1])))
             return kept, np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
         return tt[-1], np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
+
+
+def _normalize_columns(a):
+    """Columns of every matrix of the stack `a` (..., rows, cols) scaled to unit 2-norm; returns (normalised, norms)
+    (reference: qgs/functions/util.py:55-74 normalize_matrix_columns, one matrix at a time)."""
+    norm = np.sqrt(np.sum(a * a, axis=-2))
+    return a / norm[..., None, :], norm
+
+
+def _solve_triangular(r, b):
+    """x with r x = b for stacks of upper-triangular (n_vec, n_vec) matrices, column i from the leading i x i block as the
+    reference does it (qgs/functions/util.py:77-98 solve_triangular_matrix: np.linalg.solve on the leading blocks)."""
+    x = np.zeros_like(b)
+    for i in range(2, r.shape[-1] + 1):
+        x[..., :i, i - 1] = np.linalg.solve(r[..., :i, :i], b[..., :i, i - 1][..., None])[..., 0]
+    x[..., 0, 0] = b[..., 0, 0] / r[..., 0, 0]
+    return x
+
+
+class CovariantLyapunovsEstimator(object):
+    """Covariant Lyapunov vectors (CLVs) along the trajectories of an ensemble (reference: qgs/toolbox/lyapunov.py:635-1092
+    CovariantLyapunovsEstimator, loops at :1174-1330).  Same API: ``set_func(f, fjac)``, ``compute_clvs(t0, ta, tb, tc, dt,
+    mdt, ic, write_steps, n_vec, method, backward_vectors, forward_vectors)``, ``get_clvs()``, ``get_blvs()``, ``get_flvs()``.
+
+    * ``method=0`` (Ginelli et al.): the forward part -- Benettin steps from `t0` to `tc`, keeping the backward vectors
+      between `ta` and `tb` and the R matrices between `ta` and `tc` -- is one run of the estimator above on the GPU with every
+      interval recorded (R of an interval = Q(next)^T times the propagated matrix before its QR; the QR kernel follows LAPACK's
+      sign convention, so this is the R np.linalg.qr returns).  The backward recursion on the (n_vec, n_vec) coefficient
+      matrices is sequential in time and tiny; it runs on the host, all members at once.
+    * ``method=1`` (intersection of the subspaces spanned by backward and forward vectors): two runs of the estimator above
+      (backward vectors over [t0, tb], forward vectors over [ta, tc]), the SVDs of (j+1) x (n_dim-j) matrices batched over
+      members and records on the host, and one tangent-model step of `mdt` for the local exponents (TGLS kernels).
+
+    Random numbers are drawn from `np.random` in the reference's order (per trajectory for method 0: start matrix, second
+    matrix, noise vectors; method 1: the forward run's matrices, then the backward run's), all before anything runs.
+    """
+
+    def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, noise_pert=0., method=0, device=None):
+        self.num_threads = multiprocessing.cpu_count() if num_threads is None else num_threads
+        self.device = device
+        self.b, self.c, self.a = _fn.resolve_tableau(b, c, a)
+        self.noise_pert = noise_pert
+        self.ic = None
+        self._time = None
+        self._pretime = None
+        self._aftertime = None
+        self._recorded_traj = None
+        self._recorded_exp = None
+        self._recorded_vec = None
+        self._recorded_bvec = None
+        self._recorded_fvec = None
+        self.n_traj = 0
+        self.n_dim = number_of_dimensions
+        self.n_records = 0
+        self.n_vec = 0
+        self.write_steps = 0
+        self.method = method
+        self.func = None
+        self.func_jac = None
+        self._est = None
+
+    def terminate(self):
+        if self._est is not None:
+            self._est.terminate()
+        self._est = None
+
+    def set_noise_pert(self, noise_pert):
+        self.noise_pert = noise_pert
+        self.start()
+
+    def set_bca(self, b=None, c=None, a=None, ic_init=True):
+        if a is not None:
+            self.a = a
+        if b is not None:
+            self.b = b
+        if c is not None:
+            self.c = c
+        if ic_init:
+            self.ic = None
+        self.start()
+
+    def start(self):
+        self.terminate()
+        if self.func is not None:
+            self._est = LyapunovsEstimator(num_threads=self.num_threads, b=self.b, c=self.c, a=self.a, device=self.device)
+            self._est.set_func(self.func, self.func_jac)
+
+    def set_func(self, f, fjac):
+        self.func = f
+        self.func_jac = fjac
+        self.start()
+
+    # ------------------------------------------------------------------------------------------------
+    def compute_clvs(self, t0, ta, tb, tc, dt, mdt, ic=None, write_steps=1, n_vec=None, method=None, backward_vectors=False,
+                     forward_vectors=False):
+        """CLVs between `ta` and `tb` along the trajectories started from `ic` at `t0` and integrated to `tc`: [t0, ta] lets
+        the backward vectors converge, [tb, tc] the backward recursion (method 0) or the forward vectors (method 1)
+        (lyapunov.py:863-988)."""
+        if self.func is None or self.func_jac is None:
+            print('No function to integrate defined!')
+            return 0
+        if self._est is None:
+            self.start()
+        self.ic = np.zeros(_fn.dimension_of(self.func)) if ic is None else ic
+        if len(self.ic.shape) == 1:
+            self.ic = self.ic.reshape((1, -1))
+        self.n_traj, self.n_dim = self.ic.shape
+        self.n_vec = self.n_dim if n_vec is None else n_vec
+        if method is not None:
+            self.method = method
+        self._pretime = _fn.time_grid(t0, ta, dt)
+        self._time = _fn.time_grid(ta, tb, dt)
+        self._aftertime = _fn.time_grid(tb, tc, dt)
+        self.write_steps = write_steps
+        if write_steps == 0:
+            self.n_records = 1
+        else:
+            tot = self._time[::write_steps]
+            self.n_records = len(tot) + (1 if tot[-1] != self._time[-1] else 0)
+        self._recorded_bvec = self._recorded_fvec = None
+        if self.method == 0:
+            self._ginelli(mdt)
+        else:
+            self._subspaces(mdt, backward_vectors, forward_vectors)
+
+    def _ginelli(self, mdt):
+        """lyapunov.py:1174-1288."""
+        nt, nd, nv, ws = self.n_traj, self.n_dim, self.n_vec, self.write_steps
+        tw = len(self._time) - 1
+        tew = len(self._time) + len(self._aftertime) - 2
+        # every draw of the reference's loop, trajectory by trajectory
+        a0 = np.empty((nt, nd, nv))
+        a1 = np.empty((nt, nd, nv))
+        noise_after = np.empty((nt, max(0, tew - 1 - tw), nd))
+        noise_time = np.empty((nt, tw + 1, nv))
+        for i in range(nt):
+            a0[i] = np.random.randn(nd, nv)
+            a1[i] = np.random.randn(nd, nv)
+            for k in range(noise_after.shape[1]):
+                noise_after[i, k] = np.random.randn(nd)
+            for k in range(tw + 1):
+                noise_time[i, k] = np.random.randn(nv)
+        # parts one to three: Benettin steps over [t0, ta] (spin-up) and [ta, tc], every interval recorded
+        est = self._est
+        est._run(self._pretime, np.concatenate((self._time, self._aftertime[1:])), mdt, self.ic, 1, nv, False, False, False,
+                 a0=a0, pre_qr=True, fine_base=True)
+        q_all, a_all, traj_all = est._recorded_vec, est._recorded_pre, est._recorded_traj     # (nt, nd, nv, tew + 1), ..., (nt, nd, tew + 1)
+        # R of interval ti: Q(ti + 1)^T A(ti), (nt, tew, nv, nv)
+        r_all = np.triu(np.einsum('nkit,nkjt->ntij', q_all[..., 1:], a_all[..., :-1]))
+        # parts four and five: the backward recursion on the coefficient matrices, all members at once
+        am, _ = _normalize_columns(np.stack([np.linalg.qr(a1[i])[1] for i in range(nt)]))
+        diag = np.arange(nv)
+        for k, ti in enumerate(range(tew - 1, tw, -1)):
+            am_new = _solve_triangular(r_all[:, ti], am)
+            am_new[:, diag, diag] += noise_after[:, k, :nv] * self.noise_pert
+            am, _ = _normalize_columns(am_new)
+        dte = np.concatenate((np.diff(self._time), np.full((1,), self._aftertime[1] - self._aftertime[0])))
+        rec_traj = np.zeros((nt, nd, self.n_records))
+        rec_vec = np.zeros((nt, nd, nv, self.n_records))
+        rec_exp = np.zeros((nt, nv, self.n_records))
+        iw = 1
+        mloc = np.ones((nt, nv))
+        for k, ti in enumerate(range(tw, -1, -1)):
+            am_new = _solve_triangular(r_all[:, ti], am)
+            am_new[:, diag, diag] += noise_time[:, k] * self.noise_pert
+            am, mloc = _normalize_columns(am_new)
+            if ws > 0 and (tw - ti) % ws == 0:
+                rec_traj[:, :, -iw] = traj_all[:, :, ti]
+                rec_exp[:, :, -iw] = -np.log(np.abs(mloc)) / dte[ti]
+                rec_vec[:, :, :, -iw] = q_all[:, :, :, ti] @ am
+                iw += 1
+        rec_traj[:, :, 0] = traj_all[:, :, 0]
+        rec_exp[:, :, 0] = -np.log(np.abs(mloc)) / dte[0]
+        rec_vec[:, :, :, 0] = q_all[:, :, :, 0] @ am
+        self._recorded_traj, self._recorded_exp, self._recorded_vec = rec_traj, rec_exp, rec_vec
+
+    def _subspaces(self, mdt, backward_vectors, forward_vectors):
+        """lyapunov.py:1292-1330 (always the full basis: the reference passes n_dim vectors to both runs)."""
+        nt, nd, ws = self.n_traj, self.n_dim, self.write_steps
+        a0_forward = np.random.random((nt, nd, nd))            # the reference's forward run draws first, then the backward run
+        a0_backward = np.random.random((nt, nd, nd))
+        est = self._est
+        # backward vectors on [ta, tb] after the spin-up [t0, ta]; its base trajectory also gives the states at ta
+        est._run(self._pretime, self._time, mdt, self.ic, ws, nd, False, False, False, a0=a0_backward, junction=True)
+        traj, bvec = np.array(est._recorded_traj), np.array(est._recorded_vec)
+        y_ta = est._junction
+        # forward vectors on [ta, tb]: the tangent model backward in time from tc
+        est._run(self._time, self._aftertime, mdt, y_ta, ws, nd, True, False, False, a0=a0_forward)
+        fvec = np.array(est._recorded_vec)
+        # CLV j spans the intersection of the first j + 1 backward and the last n_dim - j forward vectors' subspaces
+        nr = traj.shape[-1]
+        bb = np.moveaxis(bvec, 3, 1)                            # (nt, nr, nd, nd)
+        ff = np.moveaxis(fvec, 3, 1)
+        clv = np.zeros((nt, nr, nd, nd))
+        for j in range(nd):
+            u = np.linalg.svd(np.swapaxes(bb[..., :j + 1], -1, -2) @ ff[..., :nd - j])[0]
+            clv[..., j] = (bb[..., :j + 1] @ u[..., :, :1])[..., 0]
+        # local exponents: growth of every CLV over one step of the tangent model
+        states = np.ascontiguousarray(np.moveaxis(traj, 2, 1).reshape(nt * nr, nd))
+        _, sol = _fn.run_rk_tgls(self.func, self.func_jac, np.array([0., mdt]), states, clv.reshape(nt * nr, nd, nd), 1, 0,
+                                 self.b, self.c, self.a, False, 1., None, device=self.device)
+        _, growth = _normalize_columns(sol[..., 0])
+        self._recorded_traj = traj
+        self._recorded_exp = np.moveaxis((np.log(np.abs(growth)) / mdt).reshape(nt, nr, nd), 1, 2)
+        self._recorded_vec = np.moveaxis(clv, 1, 3)
+        self.n_vec = nd
+        if backward_vectors:
+            self._recorded_bvec = bvec
+        if forward_vectors:
+            self._recorded_fvec = fvec
+
+    def _times(self):
+        if self.write_steps > 0:
+            kept = self._time[::self.write_steps]
+            if kept[-1] != self._time[-1]:
+                kept = np.concatenate((kept, np.full((1,), self._time[-1])))
+            return kept
+        return self._time[-1]
+
+    def get_clvs(self):
+        """``(time, traj, exponents, vectors)`` of the last estimation, `np.squeeze`d (lyapunov.py:990-1018)."""
+        return self._times(), np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
+
+    def get_blvs(self):
+        """The backward vectors of the last ``method=1`` estimation with ``backward_vectors=True``, else None (lyapunov.py:1020-1055)."""
+        if self._recorded_bvec is None:
+            return None
+        return self._times(), np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_bvec)
+
+    def get_flvs(self):
+        """The forward vectors of the last ``method=1`` estimation with ``forward_vectors=True``, else None (lyapunov.py:1057-1092)."""
+        if self._recorded_fvec is None:
+            return None
+        return self._times(), np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_fvec)

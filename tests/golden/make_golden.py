@@ -412,6 +412,47 @@ def gen_lyapunov(name):
     print('[lyap %s] wrote %s (%.1f KB)' % (name, path, os.path.getsize(path) / 1024.), flush=True)
 
 
+def gen_clv(name):
+    """Covariant Lyapunov vector goldens (reference: qgs/toolbox/lyapunov.py:1174-1330, the jitted loops of
+    CovariantLyapunovsEstimator called directly so that the np.random draw order is deterministic): method 0 (Ginelli et al.)
+    and method 1 (intersection of the backward and forward subspaces)."""
+    from qgs.toolbox.lyapunov import _compute_clv_gin_jit, _compute_clv_sub_jit
+    cfg = CONFIGS[name]
+    p = cfg['make']()
+    f, Df = create_tendencies(p)
+    ndim = p.ndim
+    out = {'ndim': np.int64(ndim)}
+    ic = np.random.RandomState(777).rand(2, ndim) * cfg['ic_scale']
+    for k, v in cfg.get('ic_fix', {}).items():
+        ic[:, k] += v
+    out['ic'] = ic
+    t0, ta, tb, tc, dt, mdt = 0., 0.3, 0.7, 1.0, 0.1, 0.02
+    pretime = np.concatenate((np.arange(t0, ta, dt), np.full((1,), ta)))
+    time_ = np.concatenate((np.arange(ta, tb, dt), np.full((1,), tb)))
+    aftertime = np.concatenate((np.arange(tb, tc, dt), np.full((1,), tc)))
+    out['pretime'], out['time'], out['aftertime'] = pretime, time_, aftertime
+    cases = []
+    all_cases = [('gin_w1', 0, 1, 0.), ('gin_w3', 0, 3, 0.), ('gin_w0', 0, 0, 0.), ('gin_w1_noise', 0, 1, 1e-3),
+                 ('sub_w1', 1, 1, 0.), ('sub_w3', 1, 3, 0.), ('sub_w0', 1, 0, 0.)]
+    if name != 'rp20':                                   # larger models: one case per method
+        all_cases = [('gin_w1', 0, 1, 0.), ('sub_w3', 1, 3, 0.)]
+    for tag, method, ws, noise in all_cases:
+        np.random.seed(4321)
+        if method == 0:
+            rt, re, rv = _compute_clv_gin_jit(f, Df, pretime, time_, aftertime, mdt, ic, ndim, ws, RK4['b'], RK4['c'], RK4['a'], noise)
+        else:
+            rt, re, rv, bv, fv = _compute_clv_sub_jit(f, Df, pretime, time_, aftertime, mdt, ic, ws, RK4['b'], RK4['c'], RK4['a'])
+            out['%s_bvec' % tag], out['%s_fvec' % tag] = bv, fv
+        out['%s_traj' % tag], out['%s_exp' % tag], out['%s_vec' % tag] = rt, re, rv
+        cases.append(dict(tag=tag, method=method, ws=ws, noise_pert=noise, seed=4321))
+        print('[clv %s] %s done' % (name, tag), flush=True)
+    out['meta_json'] = np.frombuffer(json.dumps({'cases': cases, 't0': t0, 'ta': ta, 'tb': tb, 'tc': tc, 'dt': dt, 'mdt': mdt}).encode(),
+                                     dtype=np.uint8)
+    path = os.path.join(HERE, 'clv_' + name + '.npz')
+    np.savez_compressed(path, **out)
+    print('[clv %s] wrote %s (%.1f KB)' % (name, path, os.path.getsize(path) / 1024.), flush=True)
+
+
 def gen_lyapunov_t228():
     """Benettin goldens at MAOOAM 6x6 (ndim 228): the reference's loops on ONE trajectory over four re-orthonormalisation
     intervals of two sub-steps -- small enough for CPython (every tangent stage evaluates the 55 522-entry Jacobian tensor in a
@@ -583,6 +624,8 @@ if __name__ == '__main__':
             gen_lyapunov('m36')
         elif nm == 'lyap_t228':
             gen_lyapunov_t228()
+        elif nm.startswith('clv_'):
+            gen_clv(nm[4:])
         elif nm.startswith('lyap_'):
             gen_lyapunov(nm[5:])
         elif nm == 'callables':

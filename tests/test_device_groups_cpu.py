@@ -122,3 +122,24 @@ def test_host_memory_guard_reads_the_container_limits(tmp_path):
     (root / 'memory' / 'jobs' / 'x' / 'memory.limit_in_bytes').write_text('9223372036854771712\n')
     assert lyapunov._cgroup_memory_room(str(proc), str(root)) is None
     assert lyapunov._host_memory_available() > 0
+
+
+def test_clv_host_helpers_match_the_plain_loops():
+    """The batched column normalisation and triangular solve of the covariant estimator against one-matrix-at-a-time loops
+    (what qgs/functions/util.py:55-98 does per trajectory)."""
+    from qgs_amd.toolbox.lyapunov import _normalize_columns, _solve_triangular
+    rng = np.random.RandomState(5)
+    r = np.triu(rng.randn(4, 7, 7)) + 3.0 * np.eye(7)
+    b = np.triu(rng.randn(4, 7, 7))
+    x = _solve_triangular(r, b)
+    an, norm = _normalize_columns(b + np.eye(7))
+    for n in range(4):
+        want = np.zeros((7, 7))
+        for i in range(2, 8):
+            want[:i, i - 1] = np.linalg.solve(r[n, :i, :i], b[n, :i, i - 1])
+        want[0, 0] = b[n, 0, 0] / r[n, 0, 0]
+        assert np.array_equal(x[n], want)
+        assert np.abs(r[n] @ x[n] - b[n]).max() < 1e-13
+        for i in range(7):
+            col = (b[n] + np.eye(7))[:, i]
+            assert abs(norm[n, i] - np.linalg.norm(col, 2)) < 1e-15 and np.abs(an[n][:, i] - col / np.linalg.norm(col, 2)).max() < 1e-15
