@@ -37,7 +37,7 @@ import threading
 import numpy as np
 
 from qgs_amd.integrators import integrate as _fn
-from qgs_amd.functions.util import reverse
+from qgs_amd.functions.util import normalize_matrix_columns as _normalize_columns, reverse, solve_triangular_matrix as _solve_triangular
 
 
 #: Uploads from pageable NumPy memory are made one at a time across the shard threads of a device list: for a pageable operand
@@ -545,23 +545,6 @@ class LyapunovsEstimator(object):
                 kept = np.concatenate((kept, np.full((1,), tt[-1])))
             return kept, np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
         return tt[-1], np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
-
-
-def _normalize_columns(a):
-    """Columns of every matrix of the stack `a` (..., rows, cols) scaled to unit 2-norm; returns (normalised, norms)
-    (reference: qgs/functions/util.py:55-74 normalize_matrix_columns, one matrix at a time)."""
-    norm = np.sqrt(np.sum(a * a, axis=-2))
-    return a / norm[..., None, :], norm
-
-
-def _solve_triangular(r, b):
-    """x with r x = b for stacks of upper-triangular (n_vec, n_vec) matrices, column i from the leading i x i block as the
-    reference does it (qgs/functions/util.py:77-98 solve_triangular_matrix: np.linalg.solve on the leading blocks)."""
-    x = np.zeros_like(b)
-    for i in range(2, r.shape[-1] + 1):
-        x[..., :i, i - 1] = np.linalg.solve(r[..., :i, :i], b[..., :i, i - 1][..., None])[..., 0]
-    x[..., 0, 0] = b[..., 0, 0] / r[..., 0, 0]
-    return x
 
 
 class CovariantLyapunovsEstimator(object):

@@ -127,7 +127,8 @@ def test_host_memory_guard_reads_the_container_limits(tmp_path):
 def test_clv_host_helpers_match_the_plain_loops():
     """The batched column normalisation and triangular solve of the covariant estimator against one-matrix-at-a-time loops
     (what qgs/functions/util.py:55-98 does per trajectory)."""
-    from qgs_amd.toolbox.lyapunov import _normalize_columns, _solve_triangular
+    from qgs_amd.functions.util import add_to_dict, normalize_matrix_columns as _normalize_columns, solve_triangular_matrix as _solve_triangular
+    assert add_to_dict(add_to_dict({}, 'k', 2.0), 'k', 1.5) == {'k': 3.5}
     rng = np.random.RandomState(5)
     r = np.triu(rng.randn(4, 7, 7)) + 3.0 * np.eye(7)
     b = np.triu(rng.randn(4, 7, 7))
