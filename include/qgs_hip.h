@@ -248,6 +248,21 @@ int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_
 int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_cols,
                           double *d_a, double *d_rdiag, void *stream);
 
+/* Small dense algebra of the covariant Lyapunov vectors (qgs/toolbox/lyapunov.py:1174-1288, the loops the reference runs per
+ * trajectory on NumPy matrices), one matrix per member in the device layout M[row][col][member]:
+ *   qgs_batched_matmul_device   C (n_rows x n_cols) = A B, or A^T B with trans_a (A stored n_inner x n_rows).  triangular 1:
+ *                               only the upper triangle of a square C is formed, the rest is zero -- R = Q^T A of a QR step,
+ *                               the `qr[1]` of lyapunov.py:1222-1247; triangular 2: B is upper triangular (square) -- the
+ *                               `tmp_vec[ti] @ am` of :1279.  C must not alias A or B.
+ *   qgs_clv_backstep_device     one backward step of the Ginelli recursion (:1255-1273): a_out = R^-1 a_in column by column
+ *                               (solve_triangular_matrix, qgs/functions/util.py:78-98), plus d_noise[col][member] * noise_pert
+ *                               on the diagonal (d_noise may be null), columns scaled to unit 2-norm
+ *                               (normalize_matrix_columns, util.py:56-75); d_norm[col][member] receives the norms. */
+int qgs_batched_matmul_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_inner, int n_cols, int trans_a,
+                              int triangular, const double *d_a, const double *d_b, double *d_c, void *stream);
+int qgs_clv_backstep_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_vec, const double *d_r, const double *d_a_in,
+                            double *d_a_out, double *d_norm, const double *d_noise, double noise_pert, void *stream);
+
 /* Name, VGPR/SGPR/LDS/scratch use of the kernel the last *_device call launched (for profiling
  * reports).  Any pointer may be NULL. */
 int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,

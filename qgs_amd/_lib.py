@@ -66,6 +66,8 @@ SIGNATURES = {
                                             _f64p, _int, _dbl, _vp, _vp, _vp]),
     'qgs_batched_qr_device': (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
     'qgs_ensemble_moments_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'qgs_batched_matmul_device': (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    'qgs_clv_backstep_device': (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
     'qgs_rk_integrate_moments': (_int, [_vp, _i64, _f64p, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _f64p, _vp, _vp]),
     'qgs_last_kernel_info': (_int, [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_int),
                                     ctypes.POINTER(_int), ctypes.POINTER(_int)]),
@@ -444,6 +446,16 @@ class HipModel(object):
 
     def batched_qr_device(self, n_traj, ld, n_rows, n_cols, d_a, d_rdiag, stream=0):
         _check(lib().qgs_batched_qr_device(self._h, n_traj, ld, int(n_rows), int(n_cols), d_a, d_rdiag, stream or None))
+
+    def batched_matmul_device(self, n_traj, ld, n_rows, n_inner, n_cols, d_a, d_b, d_c, trans_a=False, triangular=0, stream=0):
+        """C[row][col][member] = A B (A^T B with trans_a) per member; triangular 1: upper triangle of C only, 2: B upper triangular."""
+        _check(lib().qgs_batched_matmul_device(self._h, n_traj, ld, int(n_rows), int(n_inner), int(n_cols), int(bool(trans_a)),
+                                               int(triangular), d_a, d_b, d_c, stream or None))
+
+    def clv_backstep_device(self, n_traj, ld, n_vec, d_r, d_a_in, d_a_out, d_norm, d_noise=None, noise_pert=0.0, stream=0):
+        """a_out = unit-norm columns of R^-1 a_in (+ noise * noise_pert on the diagonal); d_norm[col][member] = the norms."""
+        _check(lib().qgs_clv_backstep_device(self._h, n_traj, ld, int(n_vec), d_r, d_a_in, d_a_out, d_norm, d_noise or None,
+                                             float(noise_pert), stream or None))
 
     def rk_tgls_integrate_device(self, n_traj, ld, n_tg, d_ic, d_tg_ic, time, time_direction, write_steps, b, c, a,
                                  adjoint, inverse, d_rec, d_rec_fm, stream=0):

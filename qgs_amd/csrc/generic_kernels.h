@@ -137,6 +137,12 @@ hipError_t launch_gen_tgl_wave(const DevTensor &Jrow, int max_row_terms, const R
 // rdiag[col][member] receives diag(R).  Used by the Benettin Lyapunov
 // estimator (reference: np.linalg.qr in qgs/toolbox/lyapunov.py:540-547, 599-628).
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st);
+// C[row][col][member] = A B or A^T B per member (triangular 1: upper triangle of C only, rest zero; 2: B upper triangular)
+void launch_batched_matmul(int n_rows, int n_inner, int n_cols, int trans_a, int triangular, int64_t n_traj, int64_t ld, const double *a,
+                           const double *b, double *c, hipStream_t st);
+// a_out = columns of R^-1 a_in (+ noise * pert on the diagonal) scaled to unit norm, norm[col][member] = the norms
+void launch_clv_backstep(int nv, int64_t n_traj, int64_t ld, const double *rm, const double *a_in, double *a_out, double *norm,
+                         const double *noise, double pert, hipStream_t st);
 // any shape (n_cols > 64 or matrices beyond the LDS): matrix in a global scratch copy, scratch = n_traj * (n_rows + 1) * n_cols doubles
 void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
                               hipStream_t st);

@@ -1253,6 +1253,84 @@ void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, doubl
     hipLaunchKernelGGL(batched_qr_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(WAVE), lds, st, n_rows, n_cols, n_traj, ld, a, rdiag);
 }
 
+// ---- small dense algebra of the covariant Lyapunov vectors, one matrix per member, layout M[row][col][member] -----------------
+// C = A B (or A^T B): one lane per member, a strip of MM_TC columns of one row of C per thread; every access is coalesced over
+// the members.  triangular 1: only the upper triangle of C is formed, the rest is written as zero (R = Q^T A of a QR step);
+// triangular 2: B is upper triangular, the sum over k stops at the column index (V = Q a).
+constexpr int MM_TC = 4;
+
+__global__ void __launch_bounds__(64) batched_matmul_kernel(int n_rows, int n_inner, int n_cols, int trans_a, int triangular, int64_t n_traj,
+                                                            int64_t ld, const double *__restrict__ a, const double *__restrict__ b,
+                                                            double *__restrict__ c)
+{
+    const int64_t m = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_traj) return;
+    const int r = (int)blockIdx.y, c0 = (int)blockIdx.z * MM_TC;
+    double acc[MM_TC];
+#pragma unroll
+    for (int q = 0; q < MM_TC; ++q) acc[q] = 0.0;
+    const bool skip = triangular == 1 && c0 + MM_TC - 1 < r;               // the whole strip lies below the diagonal
+    if (!skip) {
+        const int k_end = triangular == 2 ? min(n_inner, c0 + MM_TC) : n_inner;
+        for (int k = 0; k < k_end; ++k) {
+            const double av = trans_a ? a[((int64_t)k * n_rows + r) * ld + m] : a[((int64_t)r * n_inner + k) * ld + m];
+#pragma unroll
+            for (int q = 0; q < MM_TC; ++q) {
+                const int cc = c0 + q;
+                if (cc < n_cols && !(triangular == 2 && k > cc)) acc[q] = __builtin_fma(av, b[((int64_t)k * n_cols + cc) * ld + m], acc[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < MM_TC; ++q) {
+        const int cc = c0 + q;
+        if (cc < n_cols) c[((int64_t)r * n_cols + cc) * ld + m] = (triangular == 1 && cc < r) ? 0.0 : acc[q];
+    }
+}
+
+void launch_batched_matmul(int n_rows, int n_inner, int n_cols, int trans_a, int triangular, int64_t n_traj, int64_t ld, const double *a,
+                           const double *b, double *c, hipStream_t st)
+{
+    hipLaunchKernelGGL(batched_matmul_kernel, dim3(blocks_for(n_traj, 64), (unsigned)n_rows, blocks_for(n_cols, MM_TC)), dim3(64), 0, st,
+                       n_rows, n_inner, n_cols, trans_a, triangular, n_traj, ld, a, b, c);
+}
+
+// One backward step of the Ginelli recursion (qgs/toolbox/lyapunov.py:1252-1283): column c of a_out = the solution x of
+// R x = a_in[:, c] (R upper triangular: back substitution over the leading (c+1) x (c+1) block, what solve_triangular_matrix,
+// util.py:78-98, asks of np.linalg.solve), plus noise[c] * pert on its diagonal entry, scaled to unit 2-norm; norm[c] is the
+// norm before scaling (normalize_matrix_columns, util.py:56-75).  One lane per (member, column); the partial solution lives in
+// a_out itself (a thread re-reads only what it wrote).
+__global__ void __launch_bounds__(64) clv_backstep_kernel(int nv, int64_t n_traj, int64_t ld, const double *__restrict__ rm,
+                                                          const double *__restrict__ a_in, double *a_out, double *__restrict__ norm,
+                                                          const double *__restrict__ noise, double pert)
+{
+    const int64_t m = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (m >= n_traj) return;
+    const int c = (int)blockIdx.y;
+    for (int i = c; i >= 0; --i) {
+        double s = a_in[((int64_t)i * nv + c) * ld + m];
+        for (int k = i + 1; k <= c; ++k) s = __builtin_fma(-rm[((int64_t)i * nv + k) * ld + m], a_out[((int64_t)k * nv + c) * ld + m], s);
+        a_out[((int64_t)i * nv + c) * ld + m] = s / rm[((int64_t)i * nv + i) * ld + m];
+    }
+    if (noise) a_out[((int64_t)c * nv + c) * ld + m] += noise[(int64_t)c * ld + m] * pert;
+    double ss = 0.0;
+    for (int i = 0; i <= c; ++i) {
+        const double x = a_out[((int64_t)i * nv + c) * ld + m];
+        ss = __builtin_fma(x, x, ss);
+    }
+    const double nrm = sqrt(ss);
+    for (int i = 0; i <= c; ++i) a_out[((int64_t)i * nv + c) * ld + m] /= nrm;
+    for (int i = c + 1; i < nv; ++i) a_out[((int64_t)i * nv + c) * ld + m] = 0.0;
+    norm[(int64_t)c * ld + m] = nrm;
+}
+
+void launch_clv_backstep(int nv, int64_t n_traj, int64_t ld, const double *rm, const double *a_in, double *a_out, double *norm,
+                         const double *noise, double pert, hipStream_t st)
+{
+    hipLaunchKernelGGL(clv_backstep_kernel, dim3(blocks_for(n_traj, 64), (unsigned)nv), dim3(64), 0, st, nv, n_traj, ld, rm, a_in, a_out,
+                       norm, noise, pert);
+}
+
 bool tiled_supported(int ndim) { return ndim <= 16 * TILED_NW; }
 
 hipError_t launch_gen_rk_tiled(const TiledTensor &T, const RkArgs &p, const double *y_in, double *y_out, double *rec,

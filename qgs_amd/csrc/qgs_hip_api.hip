@@ -2127,6 +2127,38 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     return 0;
 }
 
+int qgs_batched_matmul_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_inner, int n_cols, int trans_a, int triangular,
+                              const double *d_a, const double *d_b, double *d_c, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_rows < 1 || n_inner < 1 || n_cols < 1 || n_rows > 65535 || n_inner > 65535 || n_cols > 65535)
+        return fail("batched matmul: dimensions must lie in 1 ... 65535");
+    if (triangular < 0 || triangular > 2) return fail("batched matmul: triangular must be 0, 1 or 2");
+    if (triangular == 1 && n_rows != n_cols) return fail("batched matmul: the upper triangle of the product is asked of a square result");
+    if (triangular == 2 && n_inner != n_cols) return fail("batched matmul: an upper-triangular B must be square");
+    if (!d_a || !d_b || !d_c) return fail("null device pointer");
+    if (d_c == d_a || d_c == d_b) return fail("batched matmul: the result must not alias an operand");
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_batched_matmul(n_rows, n_inner, n_cols, trans_a ? 1 : 0, triangular, n_traj, ld, d_a, d_b, d_c, (hipStream_t)stream);
+    note_kernel(m, "batched_matmul_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_clv_backstep_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_vec, const double *d_r, const double *d_a_in, double *d_a_out,
+                            double *d_norm, const double *d_noise, double noise_pert, void *stream)
+{
+    if (check_common(m, n_traj, ld)) return -1;
+    if (n_vec < 1 || n_vec > 65535) return fail("backward CLV step: n_vec must lie in 1 ... 65535");
+    if (!d_r || !d_a_in || !d_a_out || !d_norm) return fail("null device pointer");
+    if (d_a_out == d_a_in || d_a_out == d_r) return fail("backward CLV step: the result must not alias an operand");
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_clv_backstep(n_vec, n_traj, ld, d_r, d_a_in, d_a_out, d_norm, d_noise, noise_pert, (hipStream_t)stream);
+    note_kernel(m, "clv_backstep_kernel", nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_rows, const double *d_x, double *d_mean,
                                 double *d_var, void *stream)
 {

@@ -229,6 +229,28 @@ class _RecordWindows(object):
         self.compute.synchronize()
 
 
+def _in_threads(work, count):
+    """work(i) for i in range(count): on the calling thread when there is one piece, else one host thread per piece (the work
+    of a shard is a chain of kernel launches on its own GPU); the first exception is re-raised on the calling thread."""
+    if count == 1:
+        work(0)
+        return
+    errors = []
+
+    def run(i):
+        try:
+            work(i)
+        except Exception as e:
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(count)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
+
+
 class LyapunovsEstimator(object):
     """Estimate the Lyapunov exponents and the Backward (default) or Forward Lyapunov Vectors.
 
@@ -588,6 +610,9 @@ class CovariantLyapunovsEstimator(object):
         self.func = None
         self.func_jac = None
         self._est = None
+        self.last_timing = None           # method 0: seconds spent in the GPU part / on R / in the backward recursion
+        self.last_path = None             # method 0: 'device' (Q / R record resident on the GPU) or 'host'
+        self.device_resident = None       # method 0: None = on the device when the Q / R record fits, else the host path; True / False force one
 
     def terminate(self):
         if self._est is not None:
@@ -659,24 +684,45 @@ class CovariantLyapunovsEstimator(object):
         tw = len(self._time) - 1
         tew = len(self._time) + len(self._aftertime) - 2
         # every draw of the reference's loop, trajectory by trajectory
-        a0 = np.empty((nt, nd, nv))
-        a1 = np.empty((nt, nd, nv))
-        noise_after = np.empty((nt, max(0, tew - 1 - tw), nd))
-        noise_time = np.empty((nt, tw + 1, nv))
-        for i in range(nt):
-            a0[i] = np.random.randn(nd, nv)
-            a1[i] = np.random.randn(nd, nv)
-            for k in range(noise_after.shape[1]):
-                noise_after[i, k] = np.random.randn(nd)
-            for k in range(tw + 1):
-                noise_time[i, k] = np.random.randn(nv)
+        # (start matrix, second matrix, one noise vector of n_dim entries per step behind tb, one of n_vec entries per step on
+        # [ta, tb]; np.random.randn delivers the same stream however the calls are cut, so this is one call)
+        k_after = max(0, tew - 1 - tw)
+        cuts = np.cumsum([nd * nv, nd * nv, k_after * nd, (tw + 1) * nv])
+        stream = np.random.randn(nt, cuts[-1])
+        a0 = stream[:, :cuts[0]].reshape(nt, nd, nv)
+        a1 = stream[:, cuts[0]:cuts[1]].reshape(nt, nd, nv)
+        noise_after = stream[:, cuts[1]:cuts[2]].reshape(nt, k_after, nd)
+        noise_time = stream[:, cuts[2]:].reshape(nt, tw + 1, nv)
+        if len(self._aftertime) < 2:
+            raise ValueError('method 0 needs tc > tb: the backward recursion starts behind the window the vectors are kept on')
+        draws = (a0, a1, noise_after, noise_time)
+        want = self.device_resident
+        if want is None or want:
+            done = self._ginelli_device(mdt, draws)
+            if want and not done:
+                raise MemoryError('the Q / R record of this run does not fit the device(s)')
+            if done:
+                return
+        self._ginelli_host(mdt, draws)
+
+    def _ginelli_host(self, mdt, draws):
+        """The forward part on the GPU with its records delivered to the host (device windows: any length the host can hold),
+        R = Q^T A and the backward recursion in NumPy, all members at once."""
+        import time as _clock
+        nt, nd, nv, ws = self.n_traj, self.n_dim, self.n_vec, self.write_steps
+        tw = len(self._time) - 1
+        tew = len(self._time) + len(self._aftertime) - 2
+        a0, a1, noise_after, noise_time = draws
         # parts one to three: Benettin steps over [t0, ta] (spin-up) and [ta, tc], every interval recorded
+        t_start = _clock.perf_counter()
         est = self._est
         est._run(self._pretime, np.concatenate((self._time, self._aftertime[1:])), mdt, self.ic, 1, nv, False, False, False,
                  a0=a0, pre_qr=True, fine_base=True)
         q_all, a_all, traj_all = est._recorded_vec, est._recorded_pre, est._recorded_traj     # (nt, nd, nv, tew + 1), ..., (nt, nd, tew + 1)
         # R of interval ti: Q(ti + 1)^T A(ti), (nt, tew, nv, nv)
-        r_all = np.triu(np.einsum('nkit,nkjt->ntij', q_all[..., 1:], a_all[..., :-1]))
+        t_device = _clock.perf_counter()
+        r_all = np.triu(np.matmul(np.transpose(q_all[..., 1:], (0, 3, 2, 1)), np.transpose(a_all[..., :-1], (0, 3, 1, 2))))
+        t_r = _clock.perf_counter()
         # parts four and five: the backward recursion on the coefficient matrices, all members at once
         am, _ = _normalize_columns(np.stack([np.linalg.qr(a1[i])[1] for i in range(nt)]))
         diag = np.arange(nv)
@@ -703,6 +749,177 @@ class CovariantLyapunovsEstimator(object):
         rec_exp[:, :, 0] = -np.log(np.abs(mloc)) / dte[0]
         rec_vec[:, :, :, 0] = q_all[:, :, :, 0] @ am
         self._recorded_traj, self._recorded_exp, self._recorded_vec = rec_traj, rec_exp, rec_vec
+        # where the time went: the GPU part (Benettin run incl. its records reaching the host), R = Q^T A, the backward recursion
+        self.last_path = 'host'
+        self.last_timing = {'benettin_run_s': t_device - t_start, 'r_matrices_s': t_r - t_device,
+                            'backward_recursion_s': _clock.perf_counter() - t_r}
+
+    def _ginelli_device(self, mdt, draws):
+        """Everything on the GPU(s): the Q of [ta, tb] and the R of [ta, tc] stay in device memory between the forward part and
+        the backward recursion (`qgs_batched_matmul_device` for R = Q^T A and for the vectors Q a, `qgs_clv_backstep_device` for
+        a <- normalise(R^-1 a)); only the records the caller asked for travel to the host.  Returns False when that Q / R
+        record does not fit the free device memory of a shard's GPU (the host path has no such limit)."""
+        import time as _clock
+        import torch
+        from qgs_amd import _lib
+        nt, nd, nv = self.n_traj, self.n_dim, self.n_vec
+        tw = len(self._time) - 1
+        tew = len(self._time) + len(self._aftertime) - 2
+        model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, nt))
+        shards = getattr(model, 'models', None)
+        pieces = [(model, 0, nt)] if shards is None else [(shards[i],) + tuple(model.shard(nt, i)) for i in range(len(shards))]
+        pieces = [p for p in pieces if p[2] > 0]
+        # does the record fit?  (shards that share a GPU share its memory)
+        need = {}
+        for m, a, cnt in pieces:
+            ld = (cnt + 63) // 64 * 64
+            need[m.device] = need.get(m.device, 0) + 8 * ld * (tew * nv * nv + (tw + 1) * (nd * nv + nd) + 8 * nd * nv)
+        for d, bytes_needed in need.items():
+            free, _total = torch.cuda.mem_get_info(torch.device('cuda', d))
+            if bytes_needed + 3 * _window_budget_bytes() // 4 > 0.8 * free:
+                return False
+        t_start = _clock.perf_counter()
+        nr = self.n_records
+        rec_traj = _lib._RESULTS.empty((nt, nd, nr))
+        rec_vec = _lib._RESULTS.empty((nt, nd, nv, nr))
+        rec_exp = _lib._RESULTS.empty((nt, nv, nr))
+        timing = [None] * len(pieces)
+
+        def work(i):
+            m, a, cnt = pieces[i]
+            with torch.cuda.device(torch.device('cuda', m.device)):
+                timing[i] = self._ginelli_shard(m, self.ic[a:a + cnt], mdt, [x[a:a + cnt] for x in draws],
+                                                (rec_traj[a:a + cnt], rec_vec[a:a + cnt], rec_exp[a:a + cnt]))
+        _in_threads(work, len(pieces))
+        self._recorded_traj, self._recorded_exp, self._recorded_vec = rec_traj, rec_exp, rec_vec
+        self.last_path = 'device'
+        self.last_timing = {'benettin_run_s': max(t[0] for t in timing), 'r_matrices_s': 0.0,
+                            'backward_recursion_s': max(t[1] for t in timing), 'wall_s': _clock.perf_counter() - t_start}
+        return True
+
+    def _ginelli_shard(self, m, ic, mdt, draws, outs):
+        import time as _clock
+        import torch
+        a0, a1, noise_after, noise_time = draws
+        nd, nv, n, ws = self.n_dim, self.n_vec, ic.shape[0], self.write_steps
+        ld = (n + 63) // 64 * 64
+        dev = torch.device('cuda', m.device)
+        f64 = torch.float64
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        budget = _window_budget_bytes()
+        b, c, a = self.b, self.c, self.a
+        tw = len(self._time) - 1
+        tew = len(self._time) + len(self._aftertime) - 2
+        n_pre = len(self._pretime)
+        t_start = _clock.perf_counter()
+
+        def upload(host):                                   # (n, ...) host rows -> device tensor, one pageable copy at a time
+            with _UPLOAD_LOCK:
+                t = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+                torch.cuda.current_stream(dev).synchronize()
+            return t
+
+        def basis(rows):
+            """(n, nd, nv) host matrices -> (Q[mode][vector][member] of their QR, R[nv][nv][member] = Q^T A)"""
+            rows_dev = upload(rows)
+            mat = torch.zeros((nd, nv, ld), dtype=f64, device=dev)
+            m.pack_tangent(n, ld, nv, rows_dev.data_ptr(), mat.data_ptr(), stream)
+            q0 = mat.clone()
+            rd = torch.empty((nv, ld), dtype=f64, device=dev)
+            m.batched_qr_device(n, ld, nd, nv, q0.data_ptr(), rd.data_ptr(), stream)
+            r0 = torch.zeros((nv, nv, ld), dtype=f64, device=dev)
+            m.batched_matmul_device(n, ld, nv, nd, nv, q0.data_ptr(), mat.data_ptr(), r0.data_ptr(), trans_a=True, triangular=1, stream=stream)
+            torch.cuda.current_stream(dev).synchronize()
+            return q0, r0
+
+        # base trajectory on the sub-step grid (the reference's loop advances the state with the tangent integrator, :1203-1247)
+        coarse = np.concatenate((self._pretime[:-1], self._time, self._aftertime[1:]))
+        at = np.arange(len(coarse))
+        fine = []
+        for i in range(len(coarse) - 1):
+            tt, d = coarse[i], coarse[i + 1] - coarse[i]
+            fine.append(np.arange(tt, tt + d, mdt))
+            at[i + 1] = at[i] + len(fine[-1])
+        ic_modes = torch.zeros((nd, ld), dtype=f64, device=dev)
+        ic_modes[:, :n] = upload(ic.T)
+        base = _BaseTrajectory(torch, m, n, ld, np.concatenate(fine + [coarse[-1:]]), ic_modes, budget // 4, False, (b, c, a), stream)
+
+        # parts one to three (:1195-1247): Benettin steps; Q and the states kept on [ta, tb], R on [ta, tc]
+        q, _ = basis(a0)
+        q_new = torch.empty((1, nd, nv, ld), dtype=f64, device=dev)
+        pre = torch.empty((nd, nv, ld), dtype=f64, device=dev)
+        y_end = torch.empty((1, nd, ld), dtype=f64, device=dev)
+        rdiag = torch.empty((nv, ld), dtype=f64, device=dev)
+        q_all = torch.empty((tw + 1, nd * nv, ld), dtype=f64, device=dev)
+        t_all = torch.empty((tw + 1, nd, ld), dtype=f64, device=dev)
+        r_all = torch.empty((tew, nv * nv, ld), dtype=f64, device=dev)
+        for i in range(len(coarse) - 1):
+            ti = i - (n_pre - 1)                             # interval index on [ta, tc]; negative during the spin-up
+            if 0 <= ti <= tw:
+                q_all[ti].copy_(q.reshape(nd * nv, ld))
+                t_all[ti].copy_(base.state(at[i]))
+            tt, d = coarse[i], coarse[i + 1] - coarse[i]
+            sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
+            m.rk_tgls_integrate_device(n, ld, nv, base.state(at[i]).data_ptr(), q.data_ptr(), sub, 1, 0, b, c, a, False, 1.,
+                                       y_end.data_ptr(), q_new.data_ptr(), stream)
+            if ti >= 0:
+                pre.copy_(q_new[0])
+            m.batched_qr_device(n, ld, nd, nv, q_new.data_ptr(), rdiag.data_ptr(), stream)
+            if ti >= 0:
+                m.batched_matmul_device(n, ld, nv, nd, nv, q_new.data_ptr(), pre.data_ptr(), r_all[ti].data_ptr(), trans_a=True,
+                                        triangular=1, stream=stream)
+            q, q_new = q_new[0], q.unsqueeze(0)
+        torch.cuda.current_stream(dev).synchronize()
+        t_forward = _clock.perf_counter()
+
+        # parts four and five (:1249-1283): a <- normalise(R^-1 a) backward in time, from the R of a second random matrix
+        _, r1 = basis(a1)
+        eye = torch.zeros((nv, nv, ld), dtype=f64, device=dev)
+        for i in range(nv):
+            eye[i, i].fill_(1.0)
+        am = torch.empty((nv, nv, ld), dtype=f64, device=dev)
+        am_new = torch.empty((nv, nv, ld), dtype=f64, device=dev)
+        norm = torch.empty((nv, ld), dtype=f64, device=dev)
+        m.clv_backstep_device(n, ld, nv, eye.data_ptr(), r1.data_ptr(), am.data_ptr(), norm.data_ptr(), stream=stream)   # = normalise(r1)
+        pert = float(self.noise_pert)
+
+        def noise_on_device(host):                           # (n, steps, >= nv) -> [step][vector][member]
+            if pert == 0.0 or host.shape[1] == 0:
+                return None
+            t = torch.zeros((host.shape[1], nv, ld), dtype=f64, device=dev)
+            t[:, :, :n] = upload(np.transpose(host[:, :, :nv], (1, 2, 0)))
+            return t
+        nz_after, nz_time = noise_on_device(noise_after), noise_on_device(noise_time)
+        for k, ti in enumerate(range(tew - 1, tw, -1)):
+            m.clv_backstep_device(n, ld, nv, r_all[ti].data_ptr(), am.data_ptr(), am_new.data_ptr(), norm.data_ptr(),
+                                  nz_after[k].data_ptr() if nz_after is not None else None, pert, stream)
+            am, am_new = am_new, am
+        out_traj, out_vec, out_exp = outs
+        rec = _RecordWindows(torch, m, n, ld, (nd * nv, nd, nv), (out_vec, out_traj, out_exp), self.n_records, budget // 2, dev)
+        dte = np.concatenate((np.diff(self._time), np.full((1,), self._aftertime[1] - self._aftertime[0])))
+        rec_dt = np.ones(self.n_records)
+
+        def record(index, ti):
+            s_vec, s_traj, s_norm = rec.slot(index)
+            m.batched_matmul_device(n, ld, nd, nv, nv, q_all[ti].data_ptr(), am.data_ptr(), s_vec.data_ptr(), triangular=2, stream=stream)
+            s_traj.copy_(t_all[ti])
+            s_norm.copy_(norm)
+            rec_dt[index] = dte[ti]
+        iw = 1
+        for k, ti in enumerate(range(tw, -1, -1)):
+            m.clv_backstep_device(n, ld, nv, r_all[ti].data_ptr(), am.data_ptr(), am_new.data_ptr(), norm.data_ptr(),
+                                  nz_time[k].data_ptr() if nz_time is not None else None, pert, stream)
+            am, am_new = am_new, am
+            if ws > 0 and (tw - ti) % ws == 0:
+                record(self.n_records - iw, ti)
+                iw += 1
+        record(0, 0)
+        rec.finish()
+        # local exponents from the recorded norms, in place on the host block: -log|norm| / dt
+        np.abs(out_exp, out=out_exp)
+        np.log(out_exp, out=out_exp)
+        out_exp /= -rec_dt
+        return t_forward - t_start, _clock.perf_counter() - t_forward
 
     def _subspaces(self, mdt, backward_vectors, forward_vectors):
         """lyapunov.py:1292-1330 (always the full basis: the reference passes n_dim vectors to both runs)."""

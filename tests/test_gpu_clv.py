@@ -29,12 +29,18 @@ def test_clv_estimator_vs_reference(name, device):
     f, Df = create_tendencies(MAKERS[name]())
     est = CovariantLyapunovsEstimator(num_threads=1, device=device)
     est.set_func(f, Df)
-    for cs in meta['cases']:
+    runs = [(cs, resident) for cs in meta['cases'] for resident in ((True, False) if cs['method'] == 0 else (None,))]
+    for cs, resident in runs:
         tag = cs['tag']
         np.random.seed(cs['seed'])
         est.set_noise_pert(cs['noise_pert'])
+        # method 0 both ways: the Q / R record resident on the GPU (R, the backward recursion and the vectors in HIP kernels),
+        # and the records delivered to the host with the recursion in NumPy (what a record too large for the GPU falls back to)
+        est.device_resident = resident
         est.compute_clvs(meta['t0'], meta['ta'], meta['tb'], meta['tc'], meta['dt'], meta['mdt'], ic=g['ic'], write_steps=cs['ws'],
                          method=cs['method'], backward_vectors=True, forward_vectors=True)
+        if cs['method'] == 0:
+            assert est.last_path == ('device' if resident else 'host')
         tt, traj, exps, vecs = est.get_clvs()
         assert traj.shape == np.squeeze(g[tag + '_traj']).shape and vecs.shape == np.squeeze(g[tag + '_vec']).shape, tag
         assert rel_err(traj, np.squeeze(g[tag + '_traj'])) < 1e-12, tag
@@ -80,6 +86,7 @@ def test_clvs_are_covariant(name, n_vec, sub):
     est.compute_clvs(0., 0.5 if sub == 1 else 0.125, 1.5 if sub == 1 else 0.5, 2.0 if sub == 1 else 0.75, dt, mdt, ic=ic, write_steps=1,
                      n_vec=n_vec, method=0)
     tt, traj, exps, vecs = est.get_clvs()
+    assert est.last_path == 'device'
     assert vecs.shape == (3, g.ndim, n_vec, n_rec) and np.isfinite(exps).all()
     b, c, a = fn.resolve_tableau(None, None, None)
     for r in range(n_rec - 1):
@@ -94,4 +101,63 @@ def test_clvs_are_covariant(name, n_vec, sub):
         growth = np.log(np.sqrt(np.sum(sol[..., 0] ** 2, axis=1))) / d
         assert np.abs(growth - exps[:, :, r]).max() < 1e-8 * max(1.0, np.abs(exps).max()), r
     est.terminate()
+    f.operands.release()
+
+
+def test_batched_matmul_and_backstep_kernels_vs_numpy():
+    """The two kernels of the covariant estimator against NumPy, member by member: C = A B, A^T B, the upper triangle of a square
+    product, a product with an upper-triangular right factor; one backward step a <- normalise(R^-1 a + noise) with
+    solve_triangular_matrix / normalize_matrix_columns of qgs_amd/functions/util.py (the reference's helpers, util.py:56-98)."""
+    import torch
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.functions.util import normalize_matrix_columns, solve_triangular_matrix
+    f, _ = tendencies_from_tensor(2, np.array([[1, 0, 1]], dtype=np.int32), np.array([1.0]))
+    m = f.hip_model()
+    rng = np.random.RandomState(8)
+
+    def to_dev(x, ld):                                   # (n, r, c) -> [r][c][member]
+        d = torch.zeros(x.shape[1:] + (ld,), dtype=torch.float64, device='cuda')
+        d[..., :x.shape[0]] = torch.from_numpy(np.ascontiguousarray(np.moveaxis(x, 0, -1))).cuda()
+        return d
+
+    def to_host(d, n):
+        return np.moveaxis(d[..., :n].cpu().numpy(), -1, 0)
+    for n, (r, k, c) in ((70, (5, 7, 6)), (3, (36, 36, 36)), (130, (1, 3, 9)), (2, (228, 40, 5))):
+        ld = (n + 63) // 64 * 64
+        a, b = rng.randn(n, r, k), rng.randn(n, k, c)
+        d_a, d_at, d_b = to_dev(a, ld), to_dev(np.swapaxes(a, 1, 2), ld), to_dev(b, ld)
+        out = torch.full((r, c, ld), 7.0, dtype=torch.float64, device='cuda')
+        m.batched_matmul_device(n, ld, r, k, c, d_a.data_ptr(), d_b.data_ptr(), out.data_ptr())
+        assert np.abs(to_host(out, n) - a @ b).max() < 1e-12 * k
+        assert m.last_kernel_info()['name'] == 'batched_matmul_kernel'
+        out.fill_(7.0)
+        m.batched_matmul_device(n, ld, r, k, c, d_at.data_ptr(), d_b.data_ptr(), out.data_ptr(), trans_a=True)
+        assert np.abs(to_host(out, n) - a @ b).max() < 1e-12 * k
+        assert float(out[..., n:].min()) == 7.0 == float(out[..., n:].max())          # padding lanes are not touched
+    for n, nv, nd in ((70, 6, 9), (3, 36, 36), (65, 1, 4)):
+        ld = (n + 63) // 64 * 64
+        q, a = rng.randn(n, nd, nv), rng.randn(n, nd, nv)
+        am = np.triu(rng.randn(n, nv, nv))
+        rm = np.triu(rng.randn(n, nv, nv)) + 4.0 * np.eye(nv)
+        noise = rng.randn(n, nv)
+        d_q, d_a, d_am, d_rm = to_dev(q, ld), to_dev(a, ld), to_dev(am, ld), to_dev(rm, ld)
+        d_noise = to_dev(noise[:, :, None], ld)                     # [vector][1][member]
+        out = torch.full((nv, nv, ld), 7.0, dtype=torch.float64, device='cuda')
+        m.batched_matmul_device(n, ld, nv, nd, nv, d_q.data_ptr(), d_a.data_ptr(), out.data_ptr(), trans_a=True, triangular=1)
+        assert np.abs(to_host(out, n) - np.triu(np.swapaxes(q, 1, 2) @ a)).max() < 1e-12 * nd
+        vec = torch.full((nd, nv, ld), 7.0, dtype=torch.float64, device='cuda')
+        m.batched_matmul_device(n, ld, nd, nv, nv, d_q.data_ptr(), d_am.data_ptr(), vec.data_ptr(), triangular=2)
+        assert np.abs(to_host(vec, n) - q @ am).max() < 1e-12 * nv
+        # one backward step
+        for pert, with_noise in ((0.0, False), (1e-2, True)):
+            want = solve_triangular_matrix(rm, am)
+            want[:, np.arange(nv), np.arange(nv)] += noise * pert
+            want, want_norm = normalize_matrix_columns(want)
+            a_out = torch.full((nv, nv, ld), 7.0, dtype=torch.float64, device='cuda')
+            nrm = torch.zeros((nv, ld), dtype=torch.float64, device='cuda')
+            m.clv_backstep_device(n, ld, nv, d_rm.data_ptr(), d_am.data_ptr(), a_out.data_ptr(), nrm.data_ptr(),
+                                  d_noise.data_ptr() if with_noise else None, pert)
+            assert m.last_kernel_info()['name'] == 'clv_backstep_kernel'
+            assert np.abs(to_host(a_out, n) - want).max() < 1e-12
+            assert np.abs(nrm[:, :n].cpu().numpy().T - want_norm).max() < 1e-12 * max(1.0, np.abs(want_norm).max())
     f.operands.release()

@@ -466,6 +466,20 @@ def test_cabi_rejects_bad_arguments_and_stays_usable():
     expect_fail(L.qgs_unpack_records(m._h, 70, 128, 0, 6, d_r.data_ptr(), d_r.data_ptr(), None), 'n_inner 0')
     expect_fail(L.qgs_batched_qr_device(m._h, 70, 128, 4, 5, d_r.data_ptr(), d_x.data_ptr(), None), 'cols > rows')
     expect_fail(L.qgs_ensemble_moments_device(m._h, 70, 128, 0, d_r.data_ptr(), d_x.data_ptr(), None, None), 'n_rows 0')
+    # the small dense algebra of the covariant Lyapunov vectors
+    pa, pb, pc = d_r[0].data_ptr(), d_r[1].data_ptr(), d_r[2].data_ptr()
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 0, 4, 4, 0, 0, pa, pb, pc, None), 'n_rows 0')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 4, 4, 4, 0, 3, pa, pb, pc, None), 'triangular 3')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 3, 4, 4, 1, 1, pa, pb, pc, None), 'upper triangle of a 3 x 4 result')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 4, 3, 4, 0, 2, pa, pb, pc, None), 'triangular B 3 x 4')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 4, 4, 4, 0, 0, pa, pb, pa, None), 'result aliases A')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 128, 4, 4, 4, 0, 0, pa, None, pc, None), 'null B')
+    expect_fail(L.qgs_batched_matmul_device(m._h, 70, 100, 4, 4, 4, 0, 0, pa, pb, pc, None), 'ld 100')
+    expect_fail(L.qgs_batched_matmul_device(None, 70, 128, 4, 4, 4, 0, 0, pa, pb, pc, None), 'null model')
+    expect_fail(L.qgs_clv_backstep_device(m._h, 70, 128, 0, pa, pb, pc, d_x.data_ptr(), None, 0., None), 'n_vec 0')
+    expect_fail(L.qgs_clv_backstep_device(m._h, 70, 128, 4, pa, pb, pb, d_x.data_ptr(), None, 0., None), 'result aliases the input')
+    expect_fail(L.qgs_clv_backstep_device(m._h, 70, 128, 4, pa, pb, pc, None, None, 0., None), 'null norms')
+    expect_fail(L.qgs_clv_backstep_device(m._h, 0, 128, 4, pa, pb, pc, d_x.data_ptr(), None, 0., None), 'n_traj 0')
     expect_fail(L.qgs_model_set_kernel(m._h, 7), 'kind 7')
     # model creation: rank, ndim, coordinates out of range, device out of range
     h = vp()
