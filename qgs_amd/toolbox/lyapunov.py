@@ -569,6 +569,32 @@ class LyapunovsEstimator(object):
         return tt[-1], np.squeeze(self._recorded_traj), np.squeeze(self._recorded_exp), np.squeeze(self._recorded_vec)
 
 
+def _intersect_subspaces(bvec, fvec, num_threads=1):
+    """CLV j at every (member, record): the direction in which the span of the first j + 1 backward vectors meets the span of
+    the last n_dim - j forward vectors -- B_j u with u the leading left singular vector of B_j^T F_j (lyapunov.py:1313-1317).
+    `bvec`, `fvec`: (n_traj, n_dim, n_dim, n_records); returns (n_traj, n_records, n_dim, n_dim).  The SVDs are LAPACK's, batched
+    over members and records, the members spread over `num_threads` host threads (NumPy releases the GIL inside them)."""
+    nt, nd = bvec.shape[0], bvec.shape[1]
+    bb = np.moveaxis(bvec, 3, 1)                                # (nt, nr, nd, nd)
+    ff = np.moveaxis(fvec, 3, 1)
+    clv = np.zeros(bb.shape)
+
+    def block(lo, hi):
+        for j in range(nd):
+            u = np.linalg.svd(np.swapaxes(bb[lo:hi, ..., :j + 1], -1, -2) @ ff[lo:hi, ..., :nd - j])[0]
+            clv[lo:hi, ..., j] = (bb[lo:hi, ..., :j + 1] @ u[..., :, :1])[..., 0]
+    workers = int(max(1, min(num_threads or 1, nt, 32)))
+    if workers == 1:
+        block(0, nt)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        cuts = [nt * w // workers for w in range(workers + 1)]
+        with ThreadPoolExecutor(workers) as pool:
+            for fut in [pool.submit(block, cuts[w], cuts[w + 1]) for w in range(workers)]:
+                fut.result()
+    return clv
+
+
 class CovariantLyapunovsEstimator(object):
     """Covariant Lyapunov vectors (CLVs) along the trajectories of an ensemble (reference: qgs/toolbox/lyapunov.py:635-1092
     CovariantLyapunovsEstimator, loops at :1174-1330).  Same API: ``set_func(f, fjac)``, ``compute_clvs(t0, ta, tb, tc, dt,
@@ -588,6 +614,7 @@ class CovariantLyapunovsEstimator(object):
     """
 
     def __init__(self, num_threads=None, b=None, c=None, a=None, number_of_dimensions=None, noise_pert=0., method=0, device=None):
+        # (the reference's worker processes; here: host threads of the batched SVDs of method 1)
         self.num_threads = multiprocessing.cpu_count() if num_threads is None else num_threads
         self.device = device
         self.b, self.c, self.a = _fn.resolve_tableau(b, c, a)
@@ -934,14 +961,8 @@ class CovariantLyapunovsEstimator(object):
         # forward vectors on [ta, tb]: the tangent model backward in time from tc
         est._run(self._time, self._aftertime, mdt, y_ta, ws, nd, True, False, False, a0=a0_forward)
         fvec = np.array(est._recorded_vec)
-        # CLV j spans the intersection of the first j + 1 backward and the last n_dim - j forward vectors' subspaces
         nr = traj.shape[-1]
-        bb = np.moveaxis(bvec, 3, 1)                            # (nt, nr, nd, nd)
-        ff = np.moveaxis(fvec, 3, 1)
-        clv = np.zeros((nt, nr, nd, nd))
-        for j in range(nd):
-            u = np.linalg.svd(np.swapaxes(bb[..., :j + 1], -1, -2) @ ff[..., :nd - j])[0]
-            clv[..., j] = (bb[..., :j + 1] @ u[..., :, :1])[..., 0]
+        clv = _intersect_subspaces(bvec, fvec, self.num_threads)             # (nt, nr, nd, nd)
         # local exponents: growth of every CLV over one step of the tangent model
         states = np.ascontiguousarray(np.moveaxis(traj, 2, 1).reshape(nt * nr, nd))
         _, sol = _fn.run_rk_tgls(self.func, self.func_jac, np.array([0., mdt]), states, clv.reshape(nt * nr, nd, nd), 1, 0,

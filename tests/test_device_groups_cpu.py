@@ -144,3 +144,23 @@ def test_clv_host_helpers_match_the_plain_loops():
         for i in range(7):
             col = (b[n] + np.eye(7))[:, i]
             assert abs(norm[n, i] - np.linalg.norm(col, 2)) < 1e-15 and np.abs(an[n][:, i] - col / np.linalg.norm(col, 2)).max() < 1e-15
+
+
+def test_subspace_intersection_matches_the_plain_loops_on_any_number_of_threads():
+    """Method 1 of the covariant estimator on the host: batched over members and records, one thread or several, against the
+    loop the reference runs per trajectory, record and vector (qgs/toolbox/lyapunov.py:1313-1317)."""
+    from qgs_amd.toolbox.lyapunov import _intersect_subspaces
+    rng = np.random.RandomState(12)
+    nt, nd, nr = 5, 7, 3
+    bvec, fvec = np.empty((nt, nd, nd, nr)), np.empty((nt, nd, nd, nr))
+    for i in range(nt):
+        for r in range(nr):
+            bvec[i, :, :, r] = np.linalg.qr(rng.randn(nd, nd))[0]
+            fvec[i, :, :, r] = np.linalg.qr(rng.randn(nd, nd))[0]
+    one = _intersect_subspaces(bvec, fvec, 1)
+    assert np.array_equal(one, _intersect_subspaces(bvec, fvec, 3)) and np.array_equal(one, _intersect_subspaces(bvec, fvec, 64))
+    for i in range(nt):
+        for r in range(nr):
+            for j in range(nd):
+                u = np.linalg.svd(bvec[i, :, :j + 1, r].T @ fvec[i, :, :nd - j, r])[0]
+                assert np.abs(one[i, r, :, j] - (bvec[i, :, :j + 1, r] @ u)[:, 0]).max() < 1e-14

@@ -19,7 +19,7 @@ def main():
     from qgs_amd.toolbox.lyapunov import CovariantLyapunovsEstimator
     g = load_golden('m36')
     f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
-    est = CovariantLyapunovsEstimator(num_threads=1)
+    est = CovariantLyapunovsEstimator()           # (num_threads = the host's cores: the SVDs of method 1)
     est.set_func(f, Df)
     out = []
     method = int(os.environ.get('CLV_BENCH_METHOD', '0'))
