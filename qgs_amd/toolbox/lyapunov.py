@@ -956,11 +956,11 @@ class CovariantLyapunovsEstimator(object):
         est = self._est
         # backward vectors on [ta, tb] after the spin-up [t0, ta]; its base trajectory also gives the states at ta
         est._run(self._pretime, self._time, mdt, self.ic, ws, nd, False, False, False, a0=a0_backward, junction=True)
-        traj, bvec = np.array(est._recorded_traj), np.array(est._recorded_vec)
+        traj, bvec = est._recorded_traj, est._recorded_vec        # (result blocks stay the caller's while referenced, _lib._ResultPool)
         y_ta = est._junction
         # forward vectors on [ta, tb]: the tangent model backward in time from tc
         est._run(self._time, self._aftertime, mdt, y_ta, ws, nd, True, False, False, a0=a0_forward)
-        fvec = np.array(est._recorded_vec)
+        fvec = est._recorded_vec
         nr = traj.shape[-1]
         clv = _intersect_subspaces(bvec, fvec, self.num_threads)             # (nt, nr, nd, nd)
         # local exponents: growth of every CLV over one step of the tangent model
