@@ -282,6 +282,7 @@ class LyapunovsEstimator(object):
         self.func_jac = None
         self._model = None
         self._recorded_pre = None         # (_run(pre_qr=True)) the propagated matrices before their QR, per record
+        self._recorded_r = None           # (host path) the R of the QR step that follows each record
         self._junction = None             # (_run(junction=True)) the states at the first recorded time
         self._fine_base = False
         self.last_windows = None          # (base-trajectory windows, record windows) of the last run, per shard
@@ -291,7 +292,7 @@ class LyapunovsEstimator(object):
 
     def start(self):
         self.terminate()
-        if self.func is not None:
+        if self.func is not None and _fn.on_device(self.func):       # (a user-written callable has no model: host_lyapunov.py)
             self._model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device))
             if self.func_jac is not None and _fn.hip_model_of(self.func_jac, 'fjac', device=_fn.resolve_device(self.device)) is not self._model:
                 raise TypeError('f and fjac must come from the same create_tendencies() call')
@@ -322,7 +323,7 @@ class LyapunovsEstimator(object):
         if self.func is None or self.func_jac is None:
             print('No function to integrate defined!')
             return 0
-        if self._model is None:
+        if self._model is None and _fn.on_device(self.func):
             self.start()
         ic = np.zeros(_fn.dimension_of(self.func)) if ic is None else ic
         self._run(_fn.time_grid(t0, tw, dt), _fn.time_grid(tw, t, dt), mdt, ic, write_steps, n_vec, forward, adjoint, inverse)
@@ -353,6 +354,18 @@ class LyapunovsEstimator(object):
         else:
             tot = rec_grid[::write_steps]
             self.n_records = len(tot) + (1 if tot[-1] != rec_grid[-1] else 0)
+
+        if not (_fn.on_device(self.func) and _fn.on_device(self.func_jac)):
+            # user-written Python callables: the same loops in NumPy on the host steppers (host_lyapunov.py)
+            from qgs_amd.toolbox import host_lyapunov
+            if a0 is None:
+                a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))
+            res = host_lyapunov.benettin(self.func, self.func_jac, pretime, time, mdt, self.ic, self.n_vec, write_steps, forward,
+                                         adjoint, self._inverse, (self.b, self.c, self.a), a0, fine_base=fine_base)
+            self._recorded_traj, self._recorded_vec, self._recorded_exp = res['traj'], res['vec'], res['exp']
+            self._recorded_pre, self._recorded_r, self._junction = None, res['r'], res['junction']
+            self.last_windows = None
+            return
 
         # the result blocks of the WHOLE ensemble, in host memory and in the reference's layouts; every shard fills its slice.
         # Their size is what bounds a run -- checked before anything is allocated or computed.
@@ -407,6 +420,7 @@ class LyapunovsEstimator(object):
                 raise errors[0]
             self.last_windows = [w for w in windows if w is not None]
         self._recorded_traj, self._recorded_vec, self._recorded_exp, self._recorded_pre = out_traj, out_vec, out_exp, out_pre
+        self._recorded_r = None
 
     def _compute_shard(self, m, ic, a0, mdt, outs):
         """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
@@ -723,7 +737,7 @@ class CovariantLyapunovsEstimator(object):
         if len(self._aftertime) < 2:
             raise ValueError('method 0 needs tc > tb: the backward recursion starts behind the window the vectors are kept on')
         draws = (a0, a1, noise_after, noise_time)
-        want = self.device_resident
+        want = self.device_resident if _fn.on_device(self.func) else False      # (user-written callables: host loops)
         if want is None or want:
             done = self._ginelli_device(mdt, draws)
             if want and not done:
@@ -748,7 +762,10 @@ class CovariantLyapunovsEstimator(object):
         q_all, a_all, traj_all = est._recorded_vec, est._recorded_pre, est._recorded_traj     # (nt, nd, nv, tew + 1), ..., (nt, nd, tew + 1)
         # R of interval ti: Q(ti + 1)^T A(ti), (nt, tew, nv, nv)
         t_device = _clock.perf_counter()
-        r_all = np.triu(np.matmul(np.transpose(q_all[..., 1:], (0, 3, 2, 1)), np.transpose(a_all[..., :-1], (0, 3, 1, 2))))
+        if a_all is not None:
+            r_all = np.triu(np.matmul(np.transpose(q_all[..., 1:], (0, 3, 2, 1)), np.transpose(a_all[..., :-1], (0, 3, 1, 2))))
+        else:                                                   # the host loops keep the R of np.linalg.qr themselves
+            r_all = np.moveaxis(est._recorded_r[..., :-1], 3, 1)
         t_r = _clock.perf_counter()
         # parts four and five: the backward recursion on the coefficient matrices, all members at once
         am, _ = _normalize_columns(np.stack([np.linalg.qr(a1[i])[1] for i in range(nt)]))
@@ -777,7 +794,7 @@ class CovariantLyapunovsEstimator(object):
         rec_vec[:, :, :, 0] = q_all[:, :, :, 0] @ am
         self._recorded_traj, self._recorded_exp, self._recorded_vec = rec_traj, rec_exp, rec_vec
         # where the time went: the GPU part (Benettin run incl. its records reaching the host), R = Q^T A, the backward recursion
-        self.last_path = 'host'
+        self.last_path = 'host' if a_all is not None else 'host (user-written callables)'
         self.last_timing = {'benettin_run_s': t_device - t_start, 'r_matrices_s': t_r - t_device,
                             'backward_recursion_s': _clock.perf_counter() - t_r}
 

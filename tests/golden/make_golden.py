@@ -513,6 +513,46 @@ def rp20_boundary(t, x):
     return 0.01 * x
 
 
+def gen_lyap_callables():
+    """The Lyapunov toolbox on a user-written system (Lorenz-84, the system of the reference's own example,
+    qgs/toolbox/lyapunov.py:1334-1397): Benettin loops and both covariant-vector loops, seeded -- the cases of
+    qgs_amd/toolbox/host_lyapunov.py."""
+    from qgs.toolbox.lyapunov import (_compute_backward_lyap_jit, _compute_forward_lyap_jit, _compute_clv_gin_jit,
+                                      _compute_clv_sub_jit)
+    out = {}
+    ic = np.random.RandomState(21).randn(3, 3)
+    out['ic'] = ic
+    t0, tw, t, dt, mdt = 0., 0.5, 1.0, 0.125, 0.03125
+    pretime = np.concatenate((np.arange(t0, tw, dt), np.full((1,), tw)))
+    time_ = np.concatenate((np.arange(tw, t, dt), np.full((1,), t)))
+    cases = []
+    for tag, forward, ws, n_vec, adjoint, inverse in [('b_w1', False, 1, 3, False, False), ('b_w3_v2', False, 3, 2, False, False),
+                                                      ('b_w0', False, 0, 3, False, False), ('f_w1', True, 1, 3, False, False),
+                                                      ('f_w2_v2_adj_inv', True, 2, 2, True, True)]:
+        np.random.seed(99)
+        fn = _compute_forward_lyap_jit if forward else _compute_backward_lyap_jit
+        rt, re, rv = fn(fL84, DfL84, pretime, time_, mdt, ic, n_vec, ws, adjoint, -1. if inverse else 1., RK4['b'], RK4['c'], RK4['a'])
+        out['%s_traj' % tag], out['%s_exp' % tag], out['%s_vec' % tag] = rt, re, rv
+        cases.append(dict(tag=tag, forward=forward, ws=ws, n_vec=n_vec, adjoint=adjoint, inverse=inverse, seed=99))
+    ta, tb, tc = 0.25, 0.75, 1.0
+    grids = [np.concatenate((np.arange(x, y, dt), np.full((1,), y))) for x, y in ((t0, ta), (ta, tb), (tb, tc))]
+    clv_cases = []
+    for tag, method, ws, noise in [('gin_w1', 0, 1, 0.), ('gin_w2_noise', 0, 2, 1e-3), ('sub_w1', 1, 1, 0.), ('sub_w0', 1, 0, 0.)]:
+        np.random.seed(98)
+        if method == 0:
+            rt, re, rv = _compute_clv_gin_jit(fL84, DfL84, grids[0], grids[1], grids[2], mdt, ic, 3, ws, RK4['b'], RK4['c'], RK4['a'], noise)
+        else:
+            rt, re, rv, bv, fv = _compute_clv_sub_jit(fL84, DfL84, grids[0], grids[1], grids[2], mdt, ic, ws, RK4['b'], RK4['c'], RK4['a'])
+            out['%s_bvec' % tag], out['%s_fvec' % tag] = bv, fv
+        out['%s_traj' % tag], out['%s_exp' % tag], out['%s_vec' % tag] = rt, re, rv
+        clv_cases.append(dict(tag=tag, method=method, ws=ws, noise_pert=noise, seed=98))
+    meta = dict(cases=cases, clv_cases=clv_cases, t0=t0, tw=tw, t=t, dt=dt, mdt=mdt, ta=ta, tb=tb, tc=tc)
+    out['meta_json'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, 'lyap_callables.npz')
+    np.savez_compressed(path, **out)
+    print('[lyap callables] wrote %s (%.1f KB)' % (path, os.path.getsize(path) / 1024.), flush=True)
+
+
 def gen_callables():
     """User-written callables through the reference's integrators (functional API, classes, boundary term): the cases of the
     host stepper of qgs_amd (qgs_amd/integrators/host_stepper.py)."""
@@ -624,12 +664,16 @@ if __name__ == '__main__':
             gen_lyapunov('m36')
         elif nm == 'lyap_t228':
             gen_lyapunov_t228()
+        elif nm == 'lyap_callables':
+            gen_lyap_callables()
         elif nm.startswith('clv_'):
             gen_clv(nm[4:])
         elif nm.startswith('lyap_'):
             gen_lyapunov(nm[5:])
         elif nm == 'callables':
             gen_callables()
+        elif nm == 'lyap_callables':
+            gen_lyap_callables()
         elif nm == 'init':
             gen_initialize()
         else:
