@@ -401,23 +401,13 @@ class LyapunovsEstimator(object):
             self.last_windows = [self._compute_shard(model, self.ic, a0, mdt, piece(0, nt))]
         else:
             # several GPUs: contiguous member shards, one host thread each (the work of a shard is a chain of kernel launches)
-            import threading
-            windows, errors = [None] * len(shards), []
+            windows = [None] * len(shards)
 
             def run(i):
-                try:
-                    a, cnt = model.shard(self.n_traj, i)
-                    if cnt > 0:
-                        windows[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt, piece(a, cnt))
-                except Exception as e:                       # re-raised on the calling thread
-                    errors.append(e)
-            threads = [threading.Thread(target=run, args=(i,)) for i in range(len(shards))]
-            for th in threads:
-                th.start()
-            for th in threads:
-                th.join()
-            if errors:
-                raise errors[0]
+                a, cnt = model.shard(self.n_traj, i)
+                if cnt > 0:
+                    windows[i] = self._compute_shard(shards[i], self.ic[a:a + cnt], a0[a:a + cnt], mdt, piece(a, cnt))
+            _in_threads(run, len(shards))
             self.last_windows = [w for w in windows if w is not None]
         self._recorded_traj, self._recorded_vec, self._recorded_exp, self._recorded_pre = out_traj, out_vec, out_exp, out_pre
         self._recorded_r = None
