@@ -656,7 +656,7 @@ def copy_ref_data():
 
 
 if __name__ == '__main__':
-    names = sys.argv[1:] or (list(CONFIGS) + ['lyap', 'callables', 'init'])
+    names = sys.argv[1:] or (list(CONFIGS) + ['lyap', 'clv_rp20', 'clv_m36', 'callables', 'lyap_callables', 'init'])
     copy_ref_data()
     for nm in names:
         if nm == 'lyap':
@@ -672,8 +672,6 @@ if __name__ == '__main__':
             gen_lyapunov(nm[5:])
         elif nm == 'callables':
             gen_callables()
-        elif nm == 'lyap_callables':
-            gen_lyap_callables()
         elif nm == 'init':
             gen_initialize()
         else:
