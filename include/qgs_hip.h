@@ -268,6 +268,13 @@ int qgs_clv_backstep_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_vec,
 int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,
                          int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
 
+/* Effective shader clock of the LAST generated kernel this model launched (blocks until the device is idle): lane 0 of
+ * workgroup 0 notes the shader-clock counter and the constant 100 MHz counter when it starts and when it has issued its last
+ * store.  *shader_ghz = shader cycles per nanosecond over that interval, *elapsed_ms = the interval (one workgroup's life: the
+ * whole launch for the one-wavefront-per-SIMD steppers).  For the roofline report of bench.py: the FP64 peak scales with the
+ * clock the chip actually ran at.  Fails for the generic (non-generated) kernels, which carry no probe.  Pointers may be NULL. */
+int qgs_kernel_clock(qgs_model *m, double *shader_ghz, double *elapsed_ms);
+
 /* Compile and cache the specialised kernels of a model WITHOUT touching a device (build hosts have no
  * GPU; the cached code objects travel with the source tree).  stage_counts lists the RK stage counts
  * to pre-build; arch NULL = $QGS_HIP_ARCH or gfx950. */

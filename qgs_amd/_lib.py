@@ -65,6 +65,7 @@ SIGNATURES = {
     'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
                                             _f64p, _int, _dbl, _vp, _vp, _vp]),
     'qgs_batched_qr_device': (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
+    'qgs_kernel_clock': (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'qgs_ensemble_moments_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     'qgs_batched_matmul_device': (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'qgs_clv_backstep_device': (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
@@ -342,6 +343,14 @@ class HipModel(object):
         _check(lib().qgs_last_kernel_info(self._h, name, 128, ctypes.byref(v), ctypes.byref(s), ctypes.byref(l),
                                           ctypes.byref(sc)))
         return dict(name=name.value.decode(), vgprs=v.value, sgprs=s.value, lds_bytes=l.value, scratch_bytes=sc.value)
+
+    def kernel_clock(self):
+        """(shader GHz, milliseconds) of the last generated kernel's clock probe (qgs_kernel_clock), or None when the last
+        kernel carries none (the generic kernels)."""
+        ghz, ms = ctypes.c_double(0.), ctypes.c_double(0.)
+        if lib().qgs_kernel_clock(self._h, ctypes.byref(ghz), ctypes.byref(ms)) != 0:
+            return None
+        return ghz.value, ms.value
 
     def kernel_source(self):
         n = lib().qgs_model_kernel_source(self._h, None, 0)

@@ -367,6 +367,11 @@ typedef const double __attribute__((address_space(4))) kf64;   // coefficient ta
 typedef double v8d __attribute__((ext_vector_type(8)));
 typedef const v8d __attribute__((address_space(4), aligned(64))) kv8;
 #define QGS_WAVE 64
+// Effective shader clock of a launch: lane 0 of workgroup 0 notes the shader-clock counter (s_memtime) and the constant 100 MHz
+// counter (s_memrealtime) when it starts and when it has issued its last store; qgs_kernel_clock reads the four words back.
+__device__ unsigned long long qgs_clock_probe[4];
+#define QGS_CLOCK_MARK(k) if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { \
+    qgs_clock_probe[k] = __builtin_amdgcn_s_memtime(); qgs_clock_probe[(k) + 1] = __builtin_amdgcn_s_memrealtime(); }
 )";
 
 // Record bookkeeping shared by the steppers (reference integrate.py:190-223): record `iw` of the directed
@@ -520,6 +525,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
       << "    const f64* __restrict__ dtime,  // directed time grid\n"
       << "    const f64* __restrict__ tab,    // b[0.." << S - 1 << "], a[1][0], a[2][1], ...\n"
       << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final)\n{\n";
+    o << "    QGS_CLOCK_MARK(0)\n";
     if (spread_rec || store_stages) o << "    const unsigned lane8 = threadIdx.x * 8u;\n";
     o << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + threadIdx.x;\n"
       << "    const bool live = m0 < n_traj;\n"
@@ -618,7 +624,7 @@ void emit_rk_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &r
     o << "        }\n        if (write_final) {\n"
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * ld] = y" << d << ";\n";
-    o << "        }\n    }\n}\n";
+    o << "        }\n    }\n    QGS_CLOCK_MARK(2)\n}\n";
     emit_ktable(out, kname + "_kt", table);
     out << o.str();
 }
@@ -908,6 +914,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
           << "    const i64 l = (l0 < L) ? l0 : (L - 1);\n"
           << "    i64 m = l % ld; if (m >= n_traj) m = n_traj - 1;\n";
     }
+    o << "    QGS_CLOCK_MARK(0)\n";
     o << "    " << decl_list("v", ndim) << "\n";
     for (int d = 1; d <= ndim; ++d) o << "    v" << d << " = w_in_p[" << (d - 1) << " * L + l];\n";
     for (int st = 0; st < S; ++st) o << "    const f64 tb" << st << " = tab[" << st << "];\n";
@@ -1036,7 +1043,7 @@ void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::v
     o << "        }\n        if (write_final) {\n"
       << "            f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * L + l;\n";
     for (int d = 1; d <= ndim; ++d) o << "            p[" << (d - 1) << " * L] = v" << d << ";\n";
-    o << "        }\n    }\n}\n";
+    o << "        }\n    }\n    QGS_CLOCK_MARK(2)\n}\n";
     for (int pass = 0; pass < 2; ++pass) emit_ktable(out, kname + "_kt" + std::to_string(pass), tables[pass]);
     out << o.str();
 }
@@ -1410,7 +1417,8 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
       << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
       << "    const bool live = m0 < n_traj;\n"
       << "    const i64 m = live ? m0 : (n_traj - 1);\n"
-      << "    f64* const yw = ywork + (i64)blockIdx.x * " << ndim * 64 << " + lane;   // row d of this member at yw[(d-1)*64]\n";
+      << "    f64* const yw = ywork + (i64)blockIdx.x * " << ndim * 64 << " + lane;   // row d of this member at yw[(d-1)*64]\n"
+      << "    QGS_CLOCK_MARK(0)\n";
     if (dense) o << "    f64* const pw = pwork + (i64)blockIdx.x * S * " << ndim * 64 << " + lane;   // slot q of this workgroup at pw + q * " << ndim * 64 << "\n";
     LdsStats stats;
     for (int w = 0; w < W; ++w) {
@@ -1512,7 +1520,7 @@ void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row
         for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = " << "acc" << d << ";\n";
         o << I3 << "}\n" << I2 << "}\n    }\n";
     }
-    o << "}\n";
+    o << "    QGS_CLOCK_MARK(2)\n}\n";
     out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient fetches\n";
     {
@@ -1674,83 +1682,309 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 
 }  // namespace
 
-// Batched Householder QR, one (n_rows x n_cols) matrix per wavefront, fully unrolled for the given shape: lane c keeps
-// column c in registers, the pivot column of step j is broadcast from lane j with v_readlane (j is a compile-time
-// constant, so is every row index: no selects, no LDS, no barriers), after which every lane has the reflector and forms
-// norm / beta / tau itself.  Same conventions as the LDS kernel of generic_kernels.hip (LAPACK dgeqr2 + dorg2r).
-GeneratedKernel generate_qr_kernel(int n_rows, int n_cols)
+// Batched Householder QR (dgeqr2 + dorg2r, the algorithm behind np.linalg.qr), fully unrolled for one shape, one workgroup per
+// TILE OF M = 16 (or 8) CONSECUTIVE MEMBERS.  lane = (member mm = lane % M, column lane cc = lane / M), and lane (mm, cc) of
+// wavefront w keeps, in registers, the columns c = L (s W + w) + cc of its member for the slots s = 0 .. P-1 (L = 64 / M column
+// lanes, W wavefronts per workgroup: L P W >= n_cols).  A global access of a wavefront is then L whole runs of M members: with
+// M = 16 every 128-byte line of A[row][col][m0 .. m0+15] belongs to one workgroup and moves in one instruction; with M = 8 a
+// line is shared by two workgroups that the block index places next to each other on one XCD (one L2).  (Rounds 1-4 had one
+// wavefront per member with lane = column: 36 lines of 8 bytes per instruction, the 16 members of a line spread over 16
+// workgroups -- at 36 x 36 x 16 384 the L2 evicted part-written lines, WRITE_SIZE 5.8 x the matrix, 0.35 ms against a 0.043 ms
+// HBM floor.)
+//
+// The pivot column of step j lives in the lanes (w_j, cc_j) of slot s_j, all compile-time constants; those M lanes form
+// norm / beta / tau and publish v (and tau, 1 / (alpha - beta)) through a double-buffered LDS block vb[2][R + 2][M]; one barrier
+// per step, after which every lane reads the M-member row v_i as one conflict-free ds_read_b64 (L lanes per address).
+// LOOK-AHEAD: the wavefront that owns column j + 1 updates that slot first and forms and publishes pivot j + 1 in the same
+// basic block as the update of its other slots, so the norm / sqrt / divisions are off the critical path when P > 1.  In the
+// second phase (dorg2r) reflector j - 1 is published during step j: the reflectors are final by then.
+// The arithmetic per column is statement for statement that of the one-wavefront kernel it replaces (same sums in the same
+// order; `chains` > 1 splits the dot products into that many partial sums); the reflector is applied as
+//   w = t (q_j + scale (v.q)),  q -= (w scale) v           with v unscaled, u = v * scale only ever formed in the pivot lanes.
+// A wavefront none of whose columns is > j skips the step (uniform branch: no LDS reads); slots dead in every wavefront are
+// not emitted.
+QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
 {
-    // Householder QR (dgeqr2 + dorg2r, the algorithm behind np.linalg.qr), one wavefront per matrix, lane = column, the column
-    // in registers.  The pivot column of step j is broadcast from lane j with two v_readlane per entry and stays in SGPRs:
-    // every sum that needs it takes it as the scalar operand of a v_fma_f64.  The scaled reflector u = v * scale is never
-    // formed outside lane j:  w = t (q_j + u.q) = t (q_j + scale (v.q)),  q -= w u = q - (w scale) v;  lanes <= j run the
-    // same statements with w = 0, so the only conditional code is lane j storing its reflector (q_i *= scale).  Against the
-    // first version (u in 2 x (R - j) registers per lane, conditional moves): 95 instead of 155 registers at 36 x 36, 155
-    // instead of 312 + scratch at 64 x 64.
-    const int R = n_rows, C = n_cols, K = std::min(R, C);
+    // registers a lane needs: 2 R per slot for the columns + 2 R for the reflector + temporaries; what it may use: the 512 of a
+    // SIMD lane shared by the wavefronts of one workgroup on that SIMD, at most 256
+    auto make = [&](int M, int P, QrPlan &p) {
+        const int L = 64 / M;
+        p.members = M;
+        p.slots = std::max(1, std::min(P, (n_cols + L - 1) / L));
+        p.waves = (n_cols + L * p.slots - 1) / (L * p.slots);
+        if (p.waves > 16) return false;
+        p.slots = (n_cols + L * p.waves - 1) / (L * p.waves);         // (no slot that is empty in every wavefront)
+        const int cap = std::min(256, 512 / ((p.waves + 3) / 4));
+        p.reload = false;
+        return 2 * n_rows * (p.slots + 1) + 30 <= cap;
+    };
+    QrPlan p;
+    const int m_lo = (members == 8 || members == 16) ? members : 16, m_hi = (members == 8 || members == 16) ? members : 8;
+    for (int M = m_lo; M >= m_hi; M -= 8)
+        for (int P = slots > 0 ? slots : 4; P >= (slots > 0 ? slots : 1); --P)
+            if (make(M, P, p)) return p;
+    // nothing holds columns and reflector at once: one column per lane, the reflector read from LDS twice per step
+    make(m_hi, slots > 0 ? slots : 1, p);
+    p.reload = true;
+    return p;
+}
+
+std::string qr_plan_signature(const QrPlan &p)
+{
+    std::ostringstream s;
+    s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0) << "a" << (p.lookahead ? 1 : 0);
+    return s.str();
+}
+
+GeneratedKernel generate_qr_kernel(int n_rows, int n_cols, const QrPlan &plan)
+{
+    const int R = n_rows, C = n_cols, K = std::min(R, C), P = plan.slots, W = plan.waves, NCH = std::max(1, plan.chains);
+    const int M = plan.members, L = 64 / std::max(1, M);
+    if ((M != 8 && M != 16) || P < 1 || W < 1 || W > 16 || L * P * W < C) throw std::runtime_error("batched QR: plan does not cover the columns");
     std::ostringstream o;
-    // sum_{i = lo .. R-1} a_i * b_i into `name` (one chain; four independent partial sums measured no faster)
-    auto dot = [&](const std::string &name, const std::string &a, const std::string &b, int lo) {
-        o << "        f64 " << name << " = 0.0;\n";
-        for (int i = lo; i < R; ++i) o << "        " << name << " = __builtin_fma(" << a << i << ", " << b << i << ", " << name << ");\n";
+    const std::string I2 = "        ", I3 = "            ", I4 = "                ", I5 = "                    ";
+    auto q = [](int s, int i) { return "q" + std::to_string(s) + "_" + std::to_string(i); };
+    // sum_{i = lo .. R-1} a_i * b_i into `name`; one chain, or NCH partial sums added pairwise at the end
+    auto dot = [&](const std::string &ind, const std::string &name, const std::function<std::string(int)> &a,
+                   const std::function<std::string(int)> &b, int lo) {
+        const int n = std::max(0, R - lo), nch = std::max(1, std::min(NCH, n));
+        if (nch == 1) {
+            o << ind << "f64 " << name << " = 0.0;\n";
+            for (int i = lo; i < R; ++i) o << ind << name << " = __builtin_fma(" << a(i) << ", " << b(i) << ", " << name << ");\n";
+            return;
+        }
+        for (int k = 0; k < nch; ++k) o << ind << "f64 " << name << "_" << k << " = 0.0;\n";
+        for (int i = lo; i < R; ++i) {
+            const std::string acc = name + "_" + std::to_string((i - lo) % nch);
+            o << ind << acc << " = __builtin_fma(" << a(i) << ", " << b(i) << ", " << acc << ");\n";
+        }
+        std::vector<std::string> parts;
+        for (int k = 0; k < nch; ++k) parts.push_back(name + "_" + std::to_string(k));
+        while (parts.size() > 1) {
+            std::vector<std::string> nx;
+            for (size_t k = 0; k + 1 < parts.size(); k += 2) nx.push_back("(" + parts[k] + " + " + parts[k + 1] + ")");
+            if (parts.size() & 1) nx.push_back(parts.back());
+            parts.swap(nx);
+        }
+        o << ind << "const f64 " << name << " = " << parts[0] << ";\n";
+    };
+    struct Owner { int w, s, cc; };
+    auto owner = [&](int j) { return Owner{(j / L) % W, (j / L) / W, j % L}; };
+    // columns of slot s: L (s W + w) + cc; the slot is live at step j when some wavefront has a column > j in it
+    auto slot_ever_live = [&](int s, int j) { return std::min(C - 1, L * (s * W + W - 1) + L - 1) > j; };
+    // (uniform) "this wavefront has a column > j (and < C) in slot s"; empty when that holds for every wavefront
+    auto slot_cond = [&](int s, int j) -> std::string {
+        const bool all_gt = L * (s * W) + L - 1 > j, all_in = L * (s * W + W - 1) < C;
+        if (all_gt && all_in) return "";
+        std::ostringstream c;
+        c << "(";
+        if (!all_gt) c << L << " * (" << s * W << " + w) + " << L - 1 << " > " << j;
+        if (!all_gt && !all_in) c << " && ";
+        if (!all_in) c << L << " * (" << s * W << " + w) < " << C;
+        c << ")";
+        return c.str();
+    };
+    // ... in any of the slots (empty: always)
+    auto any_cond = [&](const std::vector<int> &slots, int j) -> std::string {
+        std::string c;
+        for (int s : slots) {
+            const std::string one = slot_cond(s, j);
+            if (one.empty()) return "";
+            c += (c.empty() ? "" : " || ") + one;
+        }
+        return c;
     };
     o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
-    o << "__device__ __forceinline__ f64 qgs_bcast(f64 x, int lane)\n{\n"
-      << "    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);\n"
-      << "    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);\n"
-      << "    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);\n"
-      << "    return __builtin_bit_cast(f64, ((unsigned long long)hi << 32) | lo);\n}\n";
-    o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << " per wavefront, lane = column\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(64) qgs_spec_qr_" << R << "x" << C
-      << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld)\n{\n";
-    // Workgroups go round-robin to the 8 XCDs, each with its own L2, and 16 consecutive members share every 128-byte line of
-    // A[row][col][member]: XCD x takes the x-th eighth of the ensemble, so that the wavefronts sharing a line run on one XCD
-    // at about the same time (grid = 8 * ceil(n_traj / 8) workgroups).
-    o << "    const i64 per = (n_traj + 7) / 8;\n"
-      << "    const i64 m = (i64)(blockIdx.x & 7) * per + (i64)(blockIdx.x >> 3);\n"
-      << "    if (m >= n_traj) return;\n"
-      << "    const int c = threadIdx.x;\n    const bool col = c < " << C << ";\n";
-    o << "    f64* const ap = a + (col ? c : 0) * ld + m;\n";
-    for (int i = 0; i < R; ++i) o << "    f64 q" << i << " = col ? ap[(i64)" << i * C << " * ld] : 0.0;\n";
-    o << "    f64 tau = 0.0;                       // lane j keeps tau_j\n";
-    for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
+    o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << ", " << M << " members per workgroup of " << W
+      << " wavefronts,\n// lane = (member, column lane), " << P << " column(s) per lane (" << qr_plan_signature(plan) << ")\n";
+    // (tools/ubench/qr_phases.cpp builds the kernel with -DQGS_QR_PROFILE: wave 0 notes the 100 MHz clock at the phase boundaries)
+    o << "#ifdef QGS_QR_PROFILE\n#define QGS_QR_MARK(k) if (threadIdx.x == 0) prof[(i64)blockIdx.x * 160 + (k)] = (k) < 8 ? wall_clock64() : __builtin_amdgcn_s_memtime();\n"
+      << "#define QGS_QR_PROF_ARG , unsigned long long* prof\n#else\n#define QGS_QR_MARK(k)\n#define QGS_QR_PROF_ARG\n#endif\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") qgs_spec_qr_" << R << "x" << C
+      << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld QGS_QR_PROF_ARG)\n{\n";
+    o << "    __shared__ f64 vb[2][" << R + 2 << "][" << M << "];      // rows j+1 .. R-1 of the reflector, [R] = tau, [R+1] = 1 / (alpha - beta)\n";
+    o << "    const int lane = threadIdx.x & 63, mm = lane & " << M - 1 << ", cc = lane >> " << (M == 16 ? 4 : 3) << ";\n"
+      << "    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n";
+    if (M == 16)
+        o << "    const i64 tile = blockIdx.x;\n";
+    else   // the two half-line tiles 2 t, 2 t + 1 go to blocks b, b + 8: the same XCD (blocks go round-robin over the 8 XCDs), back to back
+        o << "    const i64 tile = 2 * (8 * (i64)(blockIdx.x >> 4) + (blockIdx.x & 7)) + ((blockIdx.x >> 3) & 1);\n";
+    o << "    if (tile * " << M << " >= n_traj) return;                // (the whole workgroup)\n"
+      << "    const i64 m = tile * " << M << " + mm;\n"
+      << "    const bool live = m < n_traj;\n"
+      << "    const i64 ms = live ? m : 0;\n";
+    for (int s = 0; s < P; ++s) {
+        o << "    const int c" << s << " = " << L << " * (" << s * W << " + w) + cc;\n"
+          << "    const bool col" << s << " = live && c" << s << " < " << C << ";\n"
+          << "    f64* const ap" << s << " = a + (i64)(c" << s << " < " << C << " ? c" << s << " : 0) * ld + ms;\n";
+        for (int i = 0; i < R; ++i)
+            o << "    f64 " << q(s, i) << " = col" << s << " ? ap" << s << "[(i64)" << i * C << " * ld] : 0.0;\n";
+        o << "    f64 tau" << s << " = 0.0;\n";
+    }
+    o << "    QGS_CLOCK_MARK(0)\n";
+    o << "    QGS_QR_MARK(0)\n#ifdef QGS_QR_PROFILE\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n#endif\n    QGS_QR_MARK(1)\n";
+    int step = 0;                                   // broadcast steps so far: step & 1 is the LDS buffer of the next one
+    // pivot j: norm / beta / tau in the owner wavefront (caller has emitted `if (w == w_j)`), the pivot lanes publish the reflector
+    // into buffer B when some column is left to update, and keep u = v * scale, beta, tau
+    auto pivot = [&](const std::string &ind, int j, int B, bool publish) {
+        const Owner ow = owner(j);
+        const std::string in2 = ind + "    ";
+        o << ind << "{   // pivot " << j << "\n";
+        dot(in2, "xn2", [&](int i) { return q(ow.s, i); }, [&](int i) { return q(ow.s, i); }, j + 1);
+        o << in2 << "const f64 alpha = " << q(ow.s, j) << ";\n"
+          << in2 << "f64 pt = 0.0, beta = alpha, pscale = 0.0;\n"
+          << in2 << "if (xn2 != 0.0) {\n"
+          << in2 << "    beta = -__builtin_copysign(__builtin_sqrt(__builtin_fma(alpha, alpha, xn2)), alpha);\n"
+          << in2 << "    pt = (beta - alpha) / beta;\n"
+          << in2 << "    pscale = 1.0 / (alpha - beta);\n"
+          << in2 << "}\n";
+        o << in2 << "if (cc == " << ow.cc << ") {            // the pivot lanes\n";
+        if (publish) {
+            for (int i = j + 1; i < R; ++i) o << in2 << "    vb[" << B << "][" << i << "][mm] = " << q(ow.s, i) << ";\n";
+            o << in2 << "    vb[" << B << "][" << R << "][mm] = pt;\n" << in2 << "    vb[" << B << "][" << R + 1 << "][mm] = pscale;\n";
+        }
+        o << in2 << "    tau" << ow.s << " = pt;\n"
+          << in2 << "    if (live) rdiag[(i64)" << j << " * ld + m] = beta;\n"
+          << in2 << "    " << q(ow.s, j) << " = beta;\n";
+        for (int i = j + 1; i < R; ++i) o << in2 << "    " << q(ow.s, i) << " *= pscale;\n";
+        o << in2 << "}\n" << ind << "}\n";
+    };
+    // second phase, reflector j: the pivot lanes publish u and tau into buffer B (when a column is left to update) and turn their
+    // column into column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u)
+    auto publish_q = [&](const std::string &ind, int j, int B, bool publish) {
+        const Owner ow = owner(j);
+        o << ind << "if (w == " << ow.w << " && cc == " << ow.cc << ") {   // reflector " << j << "\n";
+        if (publish) {
+            for (int i = j + 1; i < R; ++i) o << ind << "    vb[" << B << "][" << i << "][mm] = " << q(ow.s, i) << ";\n";
+            o << ind << "    vb[" << B << "][" << R << "][mm] = tau" << ow.s << ";\n";
+        }
+        for (int i = 0; i < j; ++i) o << ind << "    " << q(ow.s, i) << " = 0.0;\n";
+        o << ind << "    " << q(ow.s, j) << " = 1.0 - tau" << ow.s << ";\n";
+        for (int i = j + 1; i < R; ++i) o << ind << "    " << q(ow.s, i) << " *= -tau" << ow.s << ";\n";
+        o << ind << "}\n";
+    };
+    // slot s updated by the reflector of step j (t, scale, v<i> in scope, or re-read from buffer B in reload mode)
+    auto update = [&](const std::string &ind, int s, int j, int B, bool qr_phase) {
+        const std::string S = std::to_string(s), in2 = ind + "    ";
+        auto load_v = [&](const std::string &name) {
+            for (int i = j + 1; i < R; ++i) o << in2 << "const f64 " << name << i << " = vb[" << B << "][" << i << "][mm];\n";
+        };
+        o << ind << "{   // slot " << s << "\n";
+        std::string vn = "v";
+        if (plan.reload) { vn = "va"; load_v(vn); }
+        dot(in2, "sd", [&](int i) { return vn + std::to_string(i); }, [&](int i) { return q(s, i); }, j + 1);
+        if (qr_phase)
+            o << in2 << "const f64 wv = (c" << S << " > " << j << ") ? t * __builtin_fma(scale, sd, " << q(s, j) << ") : 0.0;\n"
+              << in2 << q(s, j) << " -= wv;\n" << in2 << "const f64 wsc = -(wv * scale);\n";
+        else
+            o << in2 << "const f64 wv = (c" << S << " > " << j << ") ? t * (" << q(s, j) << " + sd) : 0.0;\n"
+              << in2 << q(s, j) << " -= wv;\n" << in2 << "const f64 wsc = -wv;\n";
+        if (plan.reload) {
+            o << in2 << "asm volatile(\"\" ::: \"memory\");      // second pass over the reflector: read again, do not keep\n";
+            vn = "vc"; load_v(vn);
+        }
+        for (int i = j + 1; i < R; ++i)
+            o << in2 << q(s, i) << " = __builtin_fma(wsc, " << vn << i << ", " << q(s, i) << ");\n";
+        o << ind << "}\n";
+    };
+    // one broadcast step: barrier, read the reflector, update; `ahead` emits the owner's look-ahead work after its first slot
+    auto broadcast_step = [&](int j, bool qr_phase, int ahead_w, int ahead_s, const std::function<void(const std::string &)> &ahead) {
+        const int B = step & 1;
+        o << I2 << "QGS_QR_MARK(" << 8 + step << ")\n";
+        o << I2 << "__syncthreads();\n";
+        std::vector<int> slots;
+        for (int s = 0; s < P; ++s) if (slot_ever_live(s, j)) slots.push_back(s);
+        // the wavefront takes part when one of its slots still has a column > j (the owner of pivot j + 1 always has)
+        {
+            const std::string part = any_cond(slots, j);
+            o << I2 << "if (" << (part.empty() ? std::string("true") : part) << ") {\n";
+        }
+        o << I3 << "const f64 t = vb[" << B << "][" << R << "][mm];\n";
+        if (qr_phase) o << I3 << "const f64 scale = vb[" << B << "][" << R + 1 << "][mm];\n";
+        if (!plan.reload)
+            for (int i = j + 1; i < R; ++i) o << I3 << "const f64 v" << i << " = vb[" << B << "][" << i << "][mm];\n";
+        auto others = [&](const std::string &ind, int skip) {
+            for (int s : slots) {
+                if (s == skip) continue;
+                const std::string c = slot_cond(s, j);
+                if (!c.empty()) o << ind << "if (" << c << ")\n";
+                update(ind, s, j, B, qr_phase);
+            }
+        };
+        if (ahead_w >= 0 && !plan.lookahead) {
+            others(I3, -1);
+            o << I2 << "}\n";
+            o << I2 << "if (w == " << ahead_w << ")\n";
+            ahead(I2);
+            ++step;
+            return;
+        }
+        if (ahead_w >= 0) {
+            o << I3 << "if (w == " << ahead_w << ") {\n";
+            if (std::find(slots.begin(), slots.end(), ahead_s) != slots.end()) update(I4, ahead_s, j, B, qr_phase);
+            ahead(I4);
+            others(I4, ahead_s);
+            o << I3 << "} else {\n";
+            others(I4, -1);
+            o << I3 << "}\n";
+        } else others(I3, -1);
+        o << I2 << "}\n";
+        ++step;
+    };
+    // ---- dgeqr2: columns > j exist for j < C - 1; pivot j + 1 is formed during step j
+    o << "    if (w == " << owner(0).w << ")\n";
+    pivot("    ", 0, 0, C > 1);
+    for (int j = 0; j + 1 < C; ++j) {
         o << "    {   // column " << j << "\n";
-        for (int i = j; i < R; ++i) o << "        const f64 v" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
-        dot("xn2", "v", "v", j + 1);
-        o << "        const f64 alpha = v" << j << ";\n"
-          << "        f64 t = 0.0, beta = alpha, scale = 0.0;\n"
-          << "        if (xn2 != 0.0) {\n"
-          << "            beta = -__builtin_copysign(__builtin_sqrt(__builtin_fma(alpha, alpha, xn2)), alpha);\n"
-          << "            t = (beta - alpha) / beta;\n"
-          << "            scale = 1.0 / (alpha - beta);\n"
-          << "        }\n";
-        dot("s", "v", "q", j + 1);
-        o << "        const f64 w = (c > " << j << ") ? t * __builtin_fma(scale, s, q" << j << ") : 0.0;\n"
-          << "        q" << j << " -= w;\n"
-          << "        const f64 ws = w * scale;\n";
-        for (int i = j + 1; i < R; ++i) o << "        q" << i << " = __builtin_fma(-ws, v" << i << ", q" << i << ");\n";
-        o << "        if (c == " << j << ") {              // this lane's column is v itself: keep the reflector u = v * scale\n"
-          << "            tau = t;\n            rdiag[(i64)" << j << " * ld + m] = beta;\n            q" << j << " = beta;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " *= scale;\n";
-        o << "        }\n    }\n";
+        const bool more = j + 1 < K;
+        const Owner nx = owner(j + 1);
+        const int Bn = (step + 1) & 1;
+        broadcast_step(j, true, more ? nx.w : -1, more ? nx.s : -1, [&](const std::string &ind) { pivot(ind, j + 1, Bn, j + 2 < C); });
+        o << "    }\n";
     }
-    for (int j = K - 1; j >= 0; --j) {              // ---- dorg2r
-        o << "    {   // Q: reflector " << j << "\n";
-        o << "        const f64 t = qgs_bcast(tau, " << j << ");\n";
-        for (int i = j + 1; i < R; ++i) o << "        const f64 u" << i << " = qgs_bcast(q" << i << ", " << j << ");\n";
-        dot("s", "u", "q", j + 1);
-        o << "        const f64 w = (c > " << j << ") ? t * (q" << j << " + s) : 0.0;\n"
-          << "        q" << j << " -= w;\n";
-        for (int i = j + 1; i < R; ++i) o << "        q" << i << " = __builtin_fma(-w, u" << i << ", q" << i << ");\n";
-        o << "        if (c == " << j << ") {              // column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u)\n";
-        for (int i = 0; i < j; ++i) o << "            q" << i << " = 0.0;\n";
-        o << "            q" << j << " = 1.0 - t;\n";
-        for (int i = j + 1; i < R; ++i) o << "            q" << i << " *= -t;\n";
-        o << "        }\n    }\n";
+    o << "    QGS_QR_MARK(2)\n";
+    // ---- dorg2r: reflector j acts on the columns > j; reflector j - 1 is published during step j
+    if (K - 1 >= 0 && !(K - 2 >= 0 && C > 1)) publish_q("    ", K - 1, 0, false);
+    if (C > 1 && K >= 2) {
+        // column K - 1 = C - 1 has nothing to its right: it only becomes a column of Q; reflector K - 2 is the first to be applied
+        publish_q("    ", K - 1, 0, false);
+        publish_q("    ", K - 2, step & 1, true);
+        for (int j = K - 2; j >= 0; --j) {
+            o << "    {   // Q: reflector " << j << "\n";
+            const int Bn = (step + 1) & 1;
+            o << I2 << "QGS_QR_MARK(" << 8 + step << ")\n";
+            o << I2 << "__syncthreads();\n";
+            // (no data dependence on this step's update: published before the update so that it is never waited for)
+            if (j > 0) publish_q(I2, j - 1, Bn, true);
+            // body without its own barrier
+            {
+                const int B = step & 1;
+                std::vector<int> slots;
+                for (int s = 0; s < P; ++s) if (slot_ever_live(s, j)) slots.push_back(s);
+                const std::string part = any_cond(slots, j);
+                o << I2 << "if (" << (part.empty() ? std::string("true") : part) << ") {\n";
+                o << I3 << "const f64 t = vb[" << B << "][" << R << "][mm];\n";
+                if (!plan.reload)
+                    for (int i = j + 1; i < R; ++i) o << I3 << "const f64 v" << i << " = vb[" << B << "][" << i << "][mm];\n";
+                for (int s : slots) {
+                    const std::string c = slot_cond(s, j);
+                    if (!c.empty()) o << I3 << "if (" << c << ")\n";
+                    update(I3, s, j, B, false);
+                }
+                o << I2 << "}\n";
+                ++step;
+            }
+            o << "    }\n";
+        }
     }
-    o << "    if (col) {\n";
-    for (int i = 0; i < R; ++i) o << "        ap[(i64)" << i * C << " * ld] = q" << i << ";\n";
-    o << "    }\n}\n";
+    o << "    QGS_QR_MARK(" << 8 + step << ")\n    QGS_QR_MARK(3)\n";
+    for (int s = 0; s < P; ++s) {
+        o << "    if (col" << s << ") {\n";
+        for (int i = 0; i < R; ++i) o << I2 << "ap" << s << "[(i64)" << i * C << " * ld] = " << q(s, i) << ";\n";
+        o << "    }\n";
+    }
+    o << "    QGS_QR_MARK(4)\n#ifdef QGS_QR_PROFILE\n    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n#endif\n    QGS_QR_MARK(5)\n";
+    o << "    QGS_CLOCK_MARK(2)\n}\n";
     GeneratedKernel g;
     g.source = o.str();
     return g;
@@ -1941,39 +2175,40 @@ std::vector<Term> merge_duplicates(const std::vector<Term> &in)
 
 }  // namespace
 
-// Magnitudes that differ by at most this many units in the last place are ONE magnitude (the one that appears first): see
-// codegen.h Canonical.
-constexpr int64_t MAGNITUDE_ULP_TOLERANCE = 2;
-
-bool magnitudes_close(double a, double b)
+// Magnitudes that differ by at most `ulp` units in the last place are ONE magnitude (the one that appears first): see codegen.h
+// Canonical.  Only normal numbers are ever merged (a relative bound: among subnormals a unit in the last place is not small
+// against the value); zero, subnormals, infinities and NaNs are classes by their bit pattern.
+bool magnitudes_close(double a, double b, int ulp)
 {
     if (a == b) return true;
-    if (!(a > 0.0) || !(b > 0.0) || !std::isfinite(a) || !std::isfinite(b)) return false;       // zero stays apart from everything else
+    if (ulp <= 0) return false;
+    if (!std::isnormal(a) || !std::isnormal(b) || !(a > 0.0) || !(b > 0.0)) return false;
     const int64_t d = (int64_t)magnitude_bits(a) - (int64_t)magnitude_bits(b);
-    return d >= -MAGNITUDE_ULP_TOLERANCE && d <= MAGNITUDE_ULP_TOLERANCE;
+    return d >= -(int64_t)ulp && d <= (int64_t)ulp;
 }
 
-void canonicalize(const std::vector<Term> &terms, Canonical &c)
+void canonicalize(const std::vector<Term> &terms, Canonical &c, int ulp)
 {
+    ulp = std::max(0, std::min(ulp, 64));
     c.terms = merge_duplicates(terms);
     c.magnitude.assign(1, 0.0);
     std::unordered_map<uint64_t, int> id;                  // exact magnitude (bit pattern) -> class
-    std::map<double, int> reps;                            // class representatives (finite, > 0), for the neighbourhood search
+    std::map<double, int> reps;                            // class representatives (normal numbers), for the neighbourhood search
     id.emplace(magnitude_bits(0.0), 0);
     for (Term &t : c.terms) {
         const double a = std::fabs(t.v);
         auto it = id.find(magnitude_bits(t.v));
         int cls = -1;
         if (it != id.end()) cls = it->second;
-        else if (a > 0.0 && std::isfinite(a)) {
+        else if (ulp > 0 && std::isnormal(a)) {
             // the closest representative within the tolerance (the lower class id on a tie)
             auto hi = reps.lower_bound(a);
-            int64_t best = MAGNITUDE_ULP_TOLERANCE + 1;
+            int64_t best = (int64_t)ulp + 1;
             for (int side = 0; side < 2; ++side) {
                 auto q = hi;
                 if (side == 0) { if (q == reps.begin()) continue; --q; }
                 else if (q == reps.end()) continue;
-                if (!magnitudes_close(a, q->first)) continue;
+                if (!magnitudes_close(a, q->first, ulp)) continue;
                 const int64_t d = std::llabs((int64_t)magnitude_bits(a) - (int64_t)magnitude_bits(q->first));
                 if (d < best || (d == best && q->second < cls)) { best = d; cls = q->second; }
             }
@@ -1981,7 +2216,7 @@ void canonicalize(const std::vector<Term> &terms, Canonical &c)
         if (cls < 0) {
             cls = (int)c.magnitude.size();
             c.magnitude.push_back(a);
-            if (a > 0.0 && std::isfinite(a)) reps.emplace(a, cls);
+            if (std::isnormal(a)) reps.emplace(a, cls);
         }
         id.emplace(magnitude_bits(t.v), cls);              // (the same bits again: straight to this class)
         t.v = std::copysign((double)cls, t.v);

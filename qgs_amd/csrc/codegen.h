@@ -110,17 +110,22 @@ struct GeneratedKernel {
 // coefficients of THIS tensor.  The tendencies tensor and the Jacobian tensor are canonicalised separately: a kernel reads
 // one of them (kernel_uses_jacobian), and its cache entry depends on that one only.
 //
-// Magnitudes within 2 units in the last place of each other are ONE magnitude (the first to appear): the inner products of a
-// spectral model reach analytically equal coefficients along different floating-point routes, and whether two such results
-// agree in the last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ... 0.0300: three different
-// patterns of such splits in eleven values, a fourth at 0.031 -- taken literally, as many structures and sets of code objects
-// where the model has one).  The perturbation, <= 4.4e-16 relative on a coefficient, is far below the fp64 tolerances stated for the path.
+// Magnitudes within `ulp` units in the last place of each other (default 2; normal numbers only) are ONE magnitude, the first
+// to appear: the inner products of a spectral model reach analytically equal coefficients along different floating-point routes,
+// and whether two such results agree in the last bit changes from one parameter value to the next (MAOOAM-36, kd = 0.0290 ...
+// 0.0300: three different patterns of such splits in eleven values, a fourth at 0.031 -- taken literally, as many structures and
+// sets of code objects where the model has one).  The specialised kernels therefore compute with the class representative:
+// a perturbation of <= ulp * 2.2e-16 relative on a coefficient, far below the fp64 tolerances stated for the path.  The generic
+// kernels, the contraction kernel and the reference's loops use the values as given (`val` is a run-time operand,
+// qgs/functions/sparse_mul.py:76-81).  QGS_HIP_MAGNITUDE_ULP=0 makes every distinct value its own class (exact coefficients
+// in the specialised kernels too, more structures in a parameter sweep); the value is part of the kernel-cache key.
 struct Canonical {
     std::vector<Term> terms;
     std::vector<double> magnitude;       // magnitude[0] = 0.0
     void decode(const std::vector<double> &table, std::vector<double> &out) const;
 };
-void canonicalize(const std::vector<Term> &terms, Canonical &out);
+constexpr int DEFAULT_MAGNITUDE_ULP = 2;
+void canonicalize(const std::vector<Term> &terms, Canonical &out, int ulp = DEFAULT_MAGNITUDE_ULP);
 
 enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense,
                     RkStagesPair, TglPair };
@@ -137,10 +142,22 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der = Derived());
 
-// Batched Householder QR fully unrolled for one matrix shape (n_rows, n_cols <= 64): kernel `qgs_spec_qr_<rows>x<cols>`
-// (a, rdiag, n_traj, ld), one wavefront per matrix, columns in registers.  Replaces np.linalg.qr in the Benettin loops
-// (qgs/toolbox/lyapunov.py:540-547, 599-628).
-GeneratedKernel generate_qr_kernel(int n_rows, int n_cols);
+// Batched Householder QR fully unrolled for one matrix shape (n_cols <= n_rows <= 64): kernel `qgs_spec_qr_<rows>x<cols>`
+// (a, rdiag, n_traj, ld), workgroups of 64 * plan.waves threads, plan.members consecutive members per workgroup,
+// lane = (member, column lane), plan.slots columns per lane in registers, the reflector broadcast through LDS (codegen.cpp).
+// grid: members == 16: ceil(n_traj / 16) workgroups; members == 8: ceil(n_traj / 8) rounded up to a multiple of 16.
+// Replaces np.linalg.qr in the Benettin loops (qgs/toolbox/lyapunov.py:540-547, 599-628).
+struct QrPlan {
+    int members = 16;     // members per workgroup (16: whole 128-byte lines; 8: half lines, two workgroups per line on one XCD)
+    int slots = 1;        // columns per lane
+    int waves = 1;        // wavefronts per workgroup ((64 / members) * slots * waves >= n_cols)
+    int chains = 1;       // partial sums per dot product (1 = one left-to-right chain)
+    bool reload = false;  // read the reflector from LDS once for the dot products and again for the update (large n_rows)
+    bool lookahead = false; // the owner of column j + 1 forms pivot j + 1 between the updates of its slots (else: after them)
+};
+QrPlan qr_plan(int n_rows, int n_cols, int members = 0, int slots = 0);      // 0: the default choice
+std::string qr_plan_signature(const QrPlan &plan);     // (part of the cache key)
+GeneratedKernel generate_qr_kernel(int n_rows, int n_cols, const QrPlan &plan);
 
 // Rough count of fp64 VALU instructions of one tendency evaluation in the generated code
 // (used for the roofline note in the bench output and DESIGN.md).

@@ -62,7 +62,7 @@ int main(int argc, char **argv)
         if (ndim <= 64)
             for (K k : {K::RkDense, K::TglDense}) std::fputs(qgs::generate_kernel(ndim, T, J, k, stages[0], opt, der).source.c_str(), stdout);
         for (K k : {K::RkLds, K::TendLds, K::RkLdsDense, K::TglLds, K::AdjLds}) std::fputs(qgs::generate_kernel(ndim, T, J, k, 0, opt, der).source.c_str(), stdout);
-        std::fputs(qgs::generate_qr_kernel(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5).source.c_str(), stdout);
+        std::fputs(qgs::generate_qr_kernel(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5, qgs::qr_plan(ndim < 64 ? ndim : 64, ndim < 5 ? ndim : 5)).source.c_str(), stdout);
     }
     if (tables) {
         // the coefficient tables of the fused stepper, decoded back to this tensor's values

@@ -37,6 +37,7 @@
 
 #include "codegen.h"
 #include "generic_kernels.h"
+#include "host_bridge.h"
 
 extern char **environ;
 
@@ -792,7 +793,7 @@ struct UploadRing {
     }
 };
 
-// Host blocks THIS library has page-locked and mapped (qgs_host_register, TempPin): the only host memory a kernel may store
+// Host blocks THIS library has page-locked and mapped (qgs_host_alloc, qgs_host_register): the only host memory a kernel may store
 // into.  What hipPointerGetAttributes says about a host address cannot be used for that decision: the runtime pins the pages
 // of pageable hipMemcpy operands on its own and keeps those pins cached -- the source of a host-to-device copy READ-ONLY --
 // and reports any later allocation that reuses such an address as "host" memory with a device pointer.  A result block that
@@ -820,16 +821,13 @@ bool registry_covers(const void *p, size_t bytes)
     return (uintptr_t)p >= it->first && (uintptr_t)p + bytes <= it->first + it->second;
 }
 
-// Copies between device memory and the CALLER's host memory.  A block this library page-locked itself is copied asynchronously
-// on `st`.  Any other host memory is pageable as far as the library knows, and for a pageable operand the runtime pins the
-// caller's pages in place -- read-only when they are the source.  Several host threads doing that at once (the shards of a
-// device group: their slices, and small neighbouring arrays of the caller, share pages) let a page end up read-only for the
-// GPU while another thread's device-to-host copy is writing to it: "Memory access fault by GPU ... Write access to a read-only
-// page", three times in about thirty runs of the GPU suite in round 4, never with serialised launches.  Pageable copies are
-// therefore made one at a time, process-wide, and have completed when the call returns (they are synchronous for the runtime
-// anyway); what the stream still has to produce is waited for BEFORE the lock is taken.
-std::mutex g_pageable_copy_mutex;
-
+// Copies between device memory and the CALLER's host memory.  A block this library page-locked itself (or the caller handed over
+// with qgs_host_register) is copied asynchronously on `st`.  Any other host memory is pageable as far as the library knows and is
+// never shown to the runtime: it is reached through the page-locked bounce blocks of host_bridge.cpp (DMA to / from a bounce
+// block, gather / scatter by host threads), blocking -- which a copy with a pageable operand is anyway.  Rounds 1-4 handed such
+// operands to hipMemcpy, which pins the caller's pages in place (read-only when they are the source); concurrent copies of
+// that kind from the shard threads of a device group produced "Memory access fault by GPU ... Write access to a read-only page"
+// about once in ten to twenty runs of the GPU suite.
 int copy_with_host(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const void *host_side, hipStream_t st)
 {
     if (bytes == 0) return 0;
@@ -840,11 +838,9 @@ int copy_with_host(void *dst, const void *src, size_t bytes, hipMemcpyKind kind,
         else HIPCHK(hipMemcpy(dst, src, bytes, kind));
         return 0;
     }
-    HIPCHK(hipStreamSynchronize(st));
-    std::lock_guard<std::mutex> lock(g_pageable_copy_mutex);
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, kind, st));
-    HIPCHK(hipStreamSynchronize(st));
-    return 0;
+    std::string err;
+    const int rc = kind == hipMemcpyHostToDevice ? qgs::bridge_h2d(dst, src, bytes, st, &err) : qgs::bridge_d2h(dst, src, bytes, st, &err);
+    return rc ? fail(err) : 0;
 }
 int copy_h2d(void *dst_dev, const void *src_host, size_t bytes, hipStream_t st = nullptr)
 {
@@ -893,6 +889,11 @@ struct LaunchTuning {
 };
 
 }  // namespace
+
+struct DrainSlot {
+    int64_t ticket = 0;
+    hipEvent_t ev = nullptr;
+};
 
 struct qgs_model {
     int device = 0;
@@ -970,7 +971,9 @@ struct qgs_model {
     // single-state fast path of f / Df: page-locked staging block the kernels read and write directly
     double *h_pin = nullptr, *d_pin = nullptr;
     size_t pin_cap = 0;
-    double *h_bounce = nullptr;                        // page-locked bounce block of the strided copies into pageable host memory
+    int magnitude_ulp = qgs::DEFAULT_MAGNITUDE_ULP;     // coefficient classes of the specialised kernels (QGS_HIP_MAGNITUDE_ULP, codegen.h Canonical)
+    std::vector<int64_t> drain_tickets;                // windows on their way into pageable host memory (host_bridge.h), oldest first
+    std::map<const Buffer *, DrainSlot> drain_slots;   // per staging block: its window in flight, the event that marks its unpack
     unsigned *d_one_counter = nullptr;                 // "workgroups finished" word of the single-state kernels
     unsigned long long one_seq = 0;                    // sequence number of the last single-state call (the kernel echoes it into h_pin[0])
     // Jacobian tensor grouped by output element (generic_kernels.h OnePairs), models of up to 1024 variables
@@ -1194,7 +1197,8 @@ void free_csr(DevCsr &d)
 // identity of kernel `k` of this model's structure in the kernel cache (obtain_blob adds compiler, flags, architecture)
 std::string kernel_key(const qgs_model *m, qgs::Kernel k, int S)
 {
-    return qgs::kernel_name(k, S, m->cg) + "|" + qgs::options_signature(m->cg) + "|ndim=" + std::to_string(m->ndim) + "|" +
+    return qgs::kernel_name(k, S, m->cg) + "|" + qgs::options_signature(m->cg) + "|ulp=" + std::to_string(m->magnitude_ulp) + "|ndim=" +
+           std::to_string(m->ndim) + "|" +
            (qgs::kernel_uses_jacobian(k) ? "J" + m->hash_j.hex() : "T" + m->hash_t.hex());
 }
 
@@ -1337,6 +1341,35 @@ void apply_env_options(qgs::CodegenOptions &cg)
 #else
     (void)cg;
 #endif
+}
+
+// QGS_HIP_MAGNITUDE_ULP (a normal-build knob): coefficients of a tensor within this many units in the last place
+// are one magnitude class of the specialised kernels (default 2); 0 = every distinct value is its own class.
+int magnitude_ulp_from_env()
+{
+    if (const char *e = std::getenv("QGS_HIP_MAGNITUDE_ULP")) {
+        char *end = nullptr;
+        const long v = std::strtol(e, &end, 10);
+        if (end != e && v >= 0 && v <= 64) return (int)v;
+    }
+    return qgs::DEFAULT_MAGNITUDE_ULP;
+}
+
+// Layout of the shape-specialised batched QR (codegen.h QrPlan); a developer build can re-measure the alternatives.
+qgs::QrPlan qr_plan_for(int n_rows, int n_cols)
+{
+    int members = 0, slots = 0;
+#ifdef QGS_HIP_DEV_KNOBS
+    if (const char *e = std::getenv("QGS_HIP_QR_MEMBERS")) members = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_QR_SLOTS")) slots = std::max(1, std::min(8, std::atoi(e)));
+#endif
+    qgs::QrPlan p = qgs::qr_plan(n_rows, n_cols, members, slots);
+#ifdef QGS_HIP_DEV_KNOBS
+    if (const char *e = std::getenv("QGS_HIP_QR_CHAINS")) p.chains = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("QGS_HIP_QR_RELOAD")) p.reload = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_QR_LOOKAHEAD")) p.lookahead = (*e == '1');
+#endif
+    return p;
 }
 
 // explicit scheme: a[i][j] == 0 for j >= i
@@ -1553,8 +1586,9 @@ static int load_tensors(qgs_model *m, int rank, int64_t nnz, const int32_t *coo,
     if (!read(jnnz, jcoo, jval, jr, true)) return fail("jacobian coordinate out of range");
     qgs::reduce_polynomial(ndim, rank, nnz, coo, val, false, m->T, m->der.t);
     qgs::reduce_polynomial(ndim, rank, jnnz, jcoo, jval, true, m->J, m->der.j);
-    qgs::canonicalize(m->T, m->canon_t);
-    qgs::canonicalize(m->J, m->canon_j);
+    m->magnitude_ulp = magnitude_ulp_from_env();
+    qgs::canonicalize(m->T, m->canon_t, m->magnitude_ulp);
+    qgs::canonicalize(m->J, m->canon_j, m->magnitude_ulp);
     // structure hash: everything of a canonical form the generated source can depend on
     auto hash_form = [&](const qgs::Canonical &c, const std::vector<std::pair<int, int>> &der, char tag) {
         Hasher h;
@@ -1653,11 +1687,11 @@ int qgs_model_destroy(qgs_model *m)
         if (m->ev_comp[i]) (void)hipEventDestroy(m->ev_comp[i]);
         if (m->ev_copy[i]) (void)hipEventDestroy(m->ev_copy[i]);
     }
+    for (auto &kv : m->drain_slots) if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
     m->uploads.release();
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
     if (m->h_pin) (void)hipHostFree(m->h_pin);
-    if (m->h_bounce) (void)hipHostFree(m->h_bounce);
     for (void *q : {(void *)m->d_one_counter, (void *)m->p_lut, (void *)m->p_ptr, (void *)m->p_idx, (void *)m->p_idx2, (void *)m->p_val})
         if (q) (void)hipFree(q);
     delete m;
@@ -1689,6 +1723,28 @@ int qgs_model_set_kernel(qgs_model *m, int kind)
     m->kernel_kind = kind;
     m->tune = LaunchTuning();             // the selection knobs are read here and at model creation, never in a launch path
     m->tune.read_env();
+    return 0;
+}
+
+int qgs_kernel_clock(qgs_model *m, double *shader_ghz, double *elapsed_ms)
+{
+    if (!m) return fail("null model");
+    auto it = m->modules.find(m->last.name);
+    if (it == m->modules.end()) return fail("the last kernel (" + m->last.name + ") is not a generated one: no clock probe");
+    HIPCHK(hipSetDevice(m->device));
+    hipDeviceptr_t dptr = nullptr;
+    size_t bytes = 0;
+    if (hipModuleGetGlobal(&dptr, &bytes, it->second, "qgs_clock_probe") != hipSuccess || bytes != 4 * sizeof(unsigned long long)) {
+        (void)hipGetLastError();
+        return fail("kernel " + m->last.name + " carries no clock probe");
+    }
+    HIPCHK(hipDeviceSynchronize());
+    unsigned long long h[4];
+    if (copy_d2h(h, (const void *)dptr, sizeof h)) return -1;
+    if (h[3] <= h[1] || h[2] <= h[0]) return fail("kernel " + m->last.name + ": the clock probe has not been written by a completed launch");
+    const double ns = (double)(h[3] - h[1]) * 10.0;                         // s_memrealtime: 100 MHz
+    if (shader_ghz) *shader_ghz = (double)(h[2] - h[0]) / ns;
+    if (elapsed_ms) *elapsed_ms = ns * 1e-6;
     return 0;
 }
 
@@ -2104,21 +2160,27 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         return 0;
     }
     if (m->kernel_kind != 1 && n_rows <= 64) {
-        // shape-specialised kernel, columns in registers (codegen generate_qr_kernel), compiled once per shape
+        // shape-specialised kernel, 16 members per workgroup, columns in registers (codegen generate_qr_kernel), compiled once per shape
+        const qgs::QrPlan plan = qr_plan_for(n_rows, n_cols);
         const std::string fname = "qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols);
+        const std::string key = fname + "|" + qgs::qr_plan_signature(plan);
         hipFunction_t f = nullptr;
-        auto it = m->functions.find(fname);
+        auto it = m->functions.find(key);
         if (it != m->functions.end()) f = it->second;
         else {
             std::shared_ptr<const KernelBlob> blob;
             bool cached = false;
-            if (obtain_blob(fname, m->arch, {}, [&] { return qgs::generate_qr_kernel(n_rows, n_cols); }, &blob, &cached)) return -1;
+            if (obtain_blob(key, m->arch, {}, [&] { return qgs::generate_qr_kernel(n_rows, n_cols, plan); }, &blob, &cached)) return -1;
             if (load_blob(m, fname, *blob, m->canon_t, &f)) return -1;          // (no tables)
+            m->functions[key] = f;
         }
         long long nt = n_traj, l = ld;
         void *args[] = {(void *)&d_a, (void *)&d_rdiag, &nt, &l};
         note_kernel(m, fname, f);
-        HIPCHK(hipModuleLaunchKernel(f, (unsigned)(8 * ((n_traj + 7) / 8)), 1, 1, 64, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+        // workgroups: 16 members each (row design: 4 wavefronts x 4 members; tile design with 16-member tiles), or 8-member tiles in pairs
+        const int64_t tiles = (n_traj + (plan.members == 8 ? 8 : 16) - 1) / (plan.members == 8 ? 8 : 16);
+        const unsigned grid = (unsigned)(plan.members == 8 ? (tiles + 15) / 16 * 16 : tiles);
+        HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, 64u * (unsigned)plan.waves, 1, 1, 0, (hipStream_t)stream, args, nullptr));
         return 0;
     }
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
@@ -2345,7 +2407,7 @@ static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_
 }
 
 // device-side address of a destination block of `bytes` bytes: the block itself when it is device memory, its mapped alias when
-// it lies inside a host block this library has page-locked (qgs_host_register / TempPin), null for any other host memory
+// it lies inside a host block this library has page-locked (qgs_host_alloc / qgs_host_register), null for any other host memory
 static double *device_alias(qgs_model *m, double *dst, size_t bytes, bool *is_device = nullptr)
 {
     if (is_device) *is_device = false;
@@ -2369,44 +2431,40 @@ static bool prefer_copy_route(const qgs_model *m, bool dst_is_device, int64_t n_
     return m->tune.window_bytes / std::max<size_t>(1, bytes_per_record * 3) >= (size_t)n_records;
 }
 
-// A pageable destination that needs several windows is page-locked for the duration of the call: the strided copies of staged
-// windows into pageable memory reach 5-16 GB/s (tools/d2h_routes.py), the unpack kernel's stores into a page-locked block 40-50,
-// and page-locking costs about 0.04 s per GB (7.8 s for 189 GB).  Failure to lock (limits, foreign memory) just keeps the copies.
-struct TempPin {
-    void *p = nullptr;
-    double *lock(qgs_model *m, double *dst, size_t bytes)
-    {
-        if (m->tune.d2h_mode == 2) return nullptr;
-        // blocks above QGS_HOST_PIN_MAX_BYTES (default 256 GiB; the largest measured page-locked: 189 GB) stay pageable
-        size_t cap = (size_t)256 << 30;
-        if (const char *e = std::getenv("QGS_HOST_PIN_MAX_BYTES")) cap = (size_t)std::strtoull(e, nullptr, 10);
-        if (bytes > cap) return nullptr;
-        // ... and so do blocks below 32 MB: those come out of the C library's heap, whose pages they share with unrelated
-        // objects and whose mappings the allocator changes under them.  Every GPU write fault of round 4 ("Write access to a
-        // read-only page", about one in ten to twenty runs of the GPU suite) hit a heap address that a kernel was storing
-        // into through such a registration; blocks of this size and above are mappings of their own
-        if (bytes < ((size_t)32 << 20)) return nullptr;
-        if (hipHostRegister(dst, bytes, hipHostRegisterPortable | hipHostRegisterMapped) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        p = dst;
-        registry_add(dst, bytes);
-        void *dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, dst, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-        return (double *)dp;
-    }
-    ~TempPin() { if (p) { registry_remove(p); (void)hipHostUnregister(p); } }
-};
+// A pageable destination is never page-locked by this library (rounds 3-4 hipHostRegister'ed blocks of 32 MB and more for the
+// duration of a call, on the assumption that the C library serves such blocks from mappings of their own; a kernel storing into
+// a registered heap block is where every GPU write fault of round 4 was found).  hipHostRegister happens in
+// qgs_host_register only -- the caller's explicit request, with the guarantees include/qgs_hip.h lists -- and a pageable
+// block is filled by host threads from page-locked bounce blocks (host_bridge.h), window k on its way while window k + 1 is
+// computed: 189 GB of records reach pageable memory at tools/big_record.py's rate in profiles/r05_big_record.txt.
 
 // Whatever way a pipelined call ends -- also on an error in the middle of it -- nothing of it may still be in flight when its
-// buffers, its page-lock (TempPin, declared before the guard: released after it) or the caller's blocks go away.
+// buffers or the caller's blocks go away: both streams, and every window still with the drain thread.
 struct DrainGuard {
+    qgs_model *m;
     hipStream_t a, b;
-    ~DrainGuard() { (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); }
+    ~DrainGuard()
+    {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        for (int64_t t : m->drain_tickets) (void)qgs::bridge_wait_done(t, nullptr);
+        m->drain_tickets.clear();
+    }
 };
 
+// every window handed to the drain thread has arrived in the caller's memory (first failure reported)
+static int drain_finish(qgs_model *m)
+{
+    int rc = 0;
+    std::string err, first;
+    for (int64_t t : m->drain_tickets)
+        if (qgs::bridge_wait_done(t, &err) && !rc) { rc = -1; first = err; }
+    m->drain_tickets.clear();
+    return rc ? fail(first) : 0;
+}
 
-constexpr size_t BOUNCE_BYTES = (size_t)16 << 20;
-
-// one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging + copy
+// one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging, then
+// either one copy (page-locked destination, or a single window) or the bounce ring of host_bridge.h (pageable destination)
 static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
                         const double *d_win, double *alias, double *dst_host, Buffer &staging, hipStream_t st)
 {
@@ -2416,39 +2474,31 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
         return 0;
     }
     const size_t rows = (size_t)n_traj * (size_t)n_inner;
+    const bool pinned = registry_covers(dst_host, sizeof(double) * rows * (size_t)n_records);
+    // the staging block is read by the drain thread until the last byte of its previous window has left the device
+    std::string err;
+    DrainSlot &slot = m->drain_slots[&staging];
+    if (slot.ticket > 0 && qgs::bridge_wait_copied(slot.ticket, &err)) return fail(err);
     if (staging.ensure(sizeof(double) * rows * (size_t)Wk)) return -1;
     qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, Wk, d_win, staging.f64(), st);
     HIPCHK(hipGetLastError());
-    if (Wk == n_records) {
-        return copy_d2h(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, st);
-    }
-#ifdef QGS_PAGEABLE_2D_COPY           // (diagnostic build only: the pre-fix behaviour, to reproduce the abort described below)
-    if (true) {
-#else
-    if (registry_covers(dst_host, sizeof(double) * rows * (size_t)n_records)) {
-#endif
-        // page-locked destination (QGS_HIP_D2H=copy): one strided DMA copy
+    if (pinned) {
+        // page-locked destination (QGS_HIP_D2H=copy, or one window): one (strided) DMA copy
+        if (Wk == n_records) return copy_d2h(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, st);
         HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
                                 sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
         return 0;
     }
-    // Pageable destination, strided rows: through a page-locked bounce block and a CPU scatter, so that the runtime never has
-    // to pin the caller's pages in place for a strided copy (its footprint, pitch x height from the first row's address, is
-    // first_record * 8 bytes more than the array has behind it).  Blocking, which a copy into pageable memory is anyway.
-    // (One of the steps of the round-4 hunt for GPU write faults; -DQGS_PAGEABLE_2D_COPY restores the 2-D copy,
-    // tools/diag_pageable_2d.py.)
-    if (!m->h_bounce) {
-        HIPCHK(hipHostMalloc((void **)&m->h_bounce, BOUNCE_BYTES, hipHostMallocDefault));
-    }
-    const size_t per_row = sizeof(double) * (size_t)Wk;
-    const size_t chunk_rows = std::max<size_t>(1, BOUNCE_BYTES / per_row);
-    for (size_t r0 = 0; r0 < rows; r0 += chunk_rows) {
-        const size_t nr = std::min(chunk_rows, rows - r0);
-        HIPCHK(hipMemcpyAsync(m->h_bounce, staging.f64() + r0 * (size_t)Wk, nr * per_row, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (size_t r = 0; r < nr; ++r)
-            std::memcpy(dst_host + lo_s + (r0 + r) * (size_t)n_records, m->h_bounce + r * (size_t)Wk, per_row);
-    }
+    // pageable destination: rows of Wk doubles -> runs `n_records` doubles apart, by the device's drain thread.  The event marks
+    // the end of the unpack kernel on st; the ticket is waited for by the next window (staging) and at the end of the call.
+    // (the slot's event can be recorded again: its previous job has passed its wait, it has even finished reading)
+    if (!slot.ev) HIPCHK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(slot.ev, st));
+    const int64_t ticket = qgs::bridge_d2h_rows_async((char *)(dst_host + lo_s), sizeof(double) * (size_t)n_records, (const char *)staging.p,
+                                                      sizeof(double) * (size_t)Wk, rows, slot.ev, &err);
+    if (ticket < 0) return fail(err);
+    slot.ticket = ticket;
+    m->drain_tickets.push_back(ticket);
     return 0;
 }
 
@@ -2482,10 +2532,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     bool dst_dev = false;
     double *alias = device_alias(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records, &dst_dev);
     if (alias && prefer_copy_route(m, dst_dev, n_records, modes_b)) alias = nullptr;
-    TempPin pin;
-    if (!alias && !dst_dev && !prefer_copy_route(m, false, n_records, modes_b))
-        alias = pin.lock(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records);
-    DrainGuard drain{sc, sd};
+    DrainGuard drain{m, sc, sd};
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
@@ -2510,7 +2557,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     }
     HIPCHK(hipStreamSynchronize(sc));
     HIPCHK(hipStreamSynchronize(sd));
-    return 0;
+    return drain_finish(m);
 }
 
 int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, int backward, int64_t W, int64_t k, int64_t *out)
@@ -2535,7 +2582,11 @@ int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner,
         first_record + n_window > n_records || !d_window || !dst) return fail("bad window arguments");
     HIPCHK(hipSetDevice(m->device));
     double *alias = device_alias(m, dst, sizeof(double) * (size_t)n_traj * (size_t)n_inner * (size_t)n_records);
-    return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream);
+    if (drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream)) {
+        (void)drain_finish(m);
+        return -1;
+    }
+    return drain_finish(m);          // (a pageable destination: the window has arrived when the call returns)
 }
 
 int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const double *time, int64_t n_time,
@@ -2652,12 +2703,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     bool dev_t = false, dev_f = false;
     double *alias_t = device_alias(m, traj, rows_b * (size_t)n_records, &dev_t), *alias_f = device_alias(m, fmatrix, tg_rows_b * (size_t)n_records, &dev_f);
     if (prefer_copy_route(m, dev_t || dev_f, n_records, modes_b + tg_modes_b)) alias_t = alias_f = nullptr;
-    TempPin pin_t, pin_f;
-    if (!dev_t && !dev_f && !prefer_copy_route(m, false, n_records, modes_b + tg_modes_b)) {
-        if (!alias_t) alias_t = pin_t.lock(m, traj, rows_b * (size_t)n_records);
-        if (!alias_f) alias_f = pin_f.lock(m, fmatrix, tg_rows_b * (size_t)n_records);
-    }
-    DrainGuard drain{sc, sd};
+    DrainGuard drain{m, sc, sd};
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
                                          (alias_t && alias_f) ? 2 : 3);
     m->last_windows = plan.n_windows;
@@ -2682,7 +2728,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     }
     HIPCHK(hipStreamSynchronize(sc));
     HIPCHK(hipStreamSynchronize(sd));
-    return 0;
+    return drain_finish(m);
 }
 
 // ---- the general contraction: sparse_mul3 / sparse_mul5 / sparse_mul2 / sparse_mul4 with any vectors -----------------------
@@ -2919,11 +2965,6 @@ int qgs_group_rk_integrate(qgs_group *g, int64_t n_traj, const double *ic, const
     if (!g || !ic || !traj || n_traj < 1) return fail("bad arguments");
     if (!time || n_time < 1) return fail("bad time grid");
     const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
-    // a large pageable result block is page-locked once here, as a whole (the shards' slices share boundary pages, so they could
-    // not each lock their own): every GPU then stores its slice itself
-    TempPin pin;
-    const size_t bytes = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec;
-    if (bytes >= ((size_t)32 << 20) && !device_alias(g->models[0], traj, bytes)) (void)pin.lock(g->models[0], traj, bytes);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_integrate(g->models[(size_t)i], n, ic + a0 * nd, time, n_time, time_direction, write_steps, s, b, c, a,
                                 traj + a0 * nd * nrec);
@@ -2938,10 +2979,6 @@ int qgs_group_rk_tgls_integrate(qgs_group *g, int64_t n_traj, int64_t n_tg, cons
     if (!g || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
     if (!time || n_time < 1) return fail("bad time grid");
     const int64_t nd = g->models[0]->ndim, nrec = qgs_n_records(time, n_time, write_steps);
-    TempPin pin_t, pin_f;
-    const size_t bytes_t = sizeof(double) * (size_t)n_traj * (size_t)nd * (size_t)nrec, bytes_f = bytes_t * (size_t)n_tg;
-    if (bytes_t >= ((size_t)32 << 20) && !device_alias(g->models[0], traj, bytes_t)) (void)pin_t.lock(g->models[0], traj, bytes_t);
-    if (bytes_f >= ((size_t)32 << 20) && !device_alias(g->models[0], fmatrix, bytes_f)) (void)pin_f.lock(g->models[0], fmatrix, bytes_f);
     return for_each_shard(g, n_traj, [&](int i, int64_t a0, int64_t n) {
         return qgs_rk_tgls_integrate(g->models[(size_t)i], n, n_tg, ic + a0 * nd, tg_ic + a0 * nd * n_tg, time, n_time,
                                      time_direction, write_steps, s, b, c, a, adjoint, inverse, traj + a0 * nd * nrec,
@@ -3001,8 +3038,10 @@ int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
     if (!prebuild_mine()) return 0;
     std::shared_ptr<const KernelBlob> blob;
     bool cached;
-    return obtain_blob("qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols), (arch && *arch) ? arch : target_arch(-1), {},
-                       [&] { return qgs::generate_qr_kernel(n_rows, n_cols); }, &blob, &cached, BlobMode::Publish);
+    const qgs::QrPlan plan = qr_plan_for(n_rows, n_cols);
+    return obtain_blob("qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols) + "|" + qgs::qr_plan_signature(plan),
+                       (arch && *arch) ? arch : target_arch(-1), {}, [&] { return qgs::generate_qr_kernel(n_rows, n_cols, plan); }, &blob,
+                       &cached, BlobMode::Publish);
 }
 
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,

@@ -78,27 +78,27 @@ def _fast_form(vs, coo):
             and not (np.asarray(coo)[:, 0] == 0).any())
 
 
-def sparse_mul3(coo, val, a, b):
-    """``res[i] = sum_n val[n] * a[j_n] * b[k_n]`` over the COO entries, ``res[0] = 1`` (sparse_mul.py:48-81).
-    `coo` is (nnz, 3)."""
-    a, b = _vectors((a, b))
+def sparse_mul3(coo, value, vec_a, vec_b):
+    """``res[i] = sum_n value[n] * vec_a[j_n] * vec_b[k_n]`` over the COO entries, ``res[0] = 1`` (sparse_mul.py:48-81; same
+    parameter names, so keyword calls of the reference carry over).  `coo` is (nnz, 3)."""
+    a, b = _vectors((vec_a, vec_b))
     n = a.shape[0] - 1
     if _fast_form((a, b), coo):
         res = np.empty(n + 1)
-        res[1:] = _model('mul3', n, coo, val)[0].tendencies(a[1:])
+        res[1:] = _model('mul3', n, coo, value)[0].tendencies(a[1:])
     else:
-        res = _contraction(n + 1, coo, val, False).apply(a, b)
+        res = _contraction(n + 1, coo, value, False).apply(a, b)
     res[0] = 1.
     return res
 
 
-def sparse_mul2(coo, val, vec):
-    """``res[i, j] = sum_n val[n] * vec[k_n]`` -> (ndim+1, ndim+1) (sparse_mul.py:13-45)."""
+def sparse_mul2(coo, value, vec):
+    """``res[i, j] = sum_n value[n] * vec[k_n]`` -> (ndim+1, ndim+1) (sparse_mul.py:13-45)."""
     vec, = _vectors((vec,))
     n = vec.shape[0] - 1
     if not _fast_form((vec,), coo):
-        return _contraction(n + 1, coo, val, True).apply(vec)
-    model, col0 = _model('mul2', n, coo, val)
+        return _contraction(n + 1, coo, value, True).apply(vec)
+    model, col0 = _model('mul2', n, coo, value)
     res = np.zeros((n + 1, n + 1))
     res[1:, 1:] = model.jacobian(vec[1:])
     if col0 is not None:
@@ -106,27 +106,27 @@ def sparse_mul2(coo, val, vec):
     return res
 
 
-def sparse_mul5(coo, val, a, b, c, d):
-    """``res[i] = sum_n val[n] * a[j_n] * b[k_n] * c[l_n] * d[m_n]``, ``res[0] = 1`` (sparse_mul.py:123-158).
+def sparse_mul5(coo, value, vec_a, vec_b, vec_c, vec_d):
+    """``res[i] = sum_n value[n] * vec_a[j_n] * vec_b[k_n] * vec_c[l_n] * vec_d[m_n]``, ``res[0] = 1`` (sparse_mul.py:122-158).
     `coo` is (nnz, 5)."""
-    vs = _vectors((a, b, c, d))
+    vs = _vectors((vec_a, vec_b, vec_c, vec_d))
     n = vs[0].shape[0] - 1
     if _fast_form(vs, coo):
         res = np.empty(n + 1)
-        res[1:] = _model('mul5', n, coo, val)[0].tendencies(vs[0][1:])
+        res[1:] = _model('mul5', n, coo, value)[0].tendencies(vs[0][1:])
     else:
-        res = _contraction(n + 1, coo, val, False).apply(*vs)
+        res = _contraction(n + 1, coo, value, False).apply(*vs)
     res[0] = 1.
     return res
 
 
-def sparse_mul4(coo, val, a, b, c):
-    """``res[i, j] = sum_n val[n] * a[k_n] * b[l_n] * c[m_n]`` -> (ndim+1, ndim+1) (sparse_mul.py:84-120)."""
-    vs = _vectors((a, b, c))
+def sparse_mul4(coo, value, vec_a, vec_b, vec_c):
+    """``res[i, j] = sum_n value[n] * vec_a[k_n] * vec_b[l_n] * vec_c[m_n]`` -> (ndim+1, ndim+1) (sparse_mul.py:84-120)."""
+    vs = _vectors((vec_a, vec_b, vec_c))
     n = vs[0].shape[0] - 1
     if not _fast_form(vs, coo):
-        return _contraction(n + 1, coo, val, True).apply(*vs)
-    model, col0 = _model('mul4', n, coo, val)
+        return _contraction(n + 1, coo, value, True).apply(*vs)
+    model, col0 = _model('mul4', n, coo, value)
     res = np.zeros((n + 1, n + 1))
     res[1:, 1:] = model.jacobian(vs[0][1:])
     if col0 is not None:

@@ -15,6 +15,7 @@ per-row Python loops; every product involves the same diagonal matrices (a^-1, (
 (M + G U)^-1) so the entries come out bit-identical to the reference's.
 """
 import pickle
+from contextlib import redirect_stdout
 
 import numpy as np
 
@@ -49,6 +50,18 @@ class CooTensor(object):
         out.coords = np.array(np.unravel_index(uniq[keep], shape))
         out.data = summed[keep]
         return out
+
+    @classmethod
+    def sum_of(cls, parts, shape):
+        """Element-wise sum ``((parts[0] + parts[1]) + parts[2]) + ...`` of COO operands given as (coords, data) pairs, each with
+        unique coordinates: what a chain of binary additions of pydata/sparse arrays gives (an entry absent from an operand
+        adds nothing), zeros dropped at the end."""
+        lins = [np.ravel_multi_index(tuple(np.asarray(c, dtype=np.int64).reshape(len(shape), -1)), shape) for c, _ in parts]
+        uniq = np.unique(np.concatenate(lins)) if lins else np.zeros(0, dtype=np.int64)
+        acc = np.zeros(len(uniq))
+        for lin, (_, d) in zip(lins, parts):
+            acc[np.searchsorted(uniq, lin)] += np.asarray(d, dtype=np.float64)
+        return cls.from_sorted_keys(uniq, acc, shape)
 
     @classmethod
     def from_sorted_keys(cls, keys, data, shape):
@@ -345,6 +358,42 @@ class QgsTensor(object):
         for coo, val in zip(self.jacobian_tensor.coords.T, self.jacobian_tensor.data):
             self._string_format(print, name, coo, val)
 
+    def print_tensor_to_file(self, filename, tensor_name=""):
+        """`print_tensor` into the text file `filename` (qgtensor.py:792-804)."""
+        with open(filename, 'w') as f:
+            with redirect_stdout(f):
+                self.print_tensor(tensor_name)
+
+    def print_jacobian_tensor_to_file(self, filename, tensor_name=""):
+        """`print_jacobian_tensor` into the text file `filename` (qgtensor.py:819-831)."""
+        with open(filename, 'w') as f:
+            with redirect_stdout(f):
+                self.print_jacobian_tensor(tensor_name)
+
+    # ---- the two derivations as the reference's static helpers, on any COO tensor (rank 3 or 5) ---------
+    @staticmethod
+    def jacobian_from_tensor(tensor):
+        """Jacobian tensor of `tensor` (anything with `.coords` (rank, nnz), `.data`, `.shape`): the tensor plus its copies
+        with axis 1 swapped with every later axis, ``T + T.swapaxes(1, 2) [+ T.swapaxes(1, 3) + T.swapaxes(1, 4)]``
+        (qgtensor.py:701-722), added one after the other; zeros dropped.  `tensor` has unique coordinates (a COO array);
+        returns a `CooTensor`."""
+        coords = np.asarray(tensor.coords, dtype=np.int64)
+        data = np.asarray(tensor.data, dtype=np.float64)
+        parts = [(coords, data)]
+        for ax in range(2, len(tensor.shape)):
+            sw = coords.copy()
+            sw[[1, ax]] = sw[[ax, 1]]
+            parts.append((sw, data))
+        return CooTensor.sum_of(parts, tuple(tensor.shape))
+
+    @staticmethod
+    def simplify_tensor(tensor):
+        """Upper-triangularised `tensor`: for every entry the indices after the first are sorted, entries that land on one
+        coordinate are summed in their incoming order, zeros dropped (qgtensor.py:725-746); returns a `CooTensor`."""
+        coords = np.asarray(tensor.coords, dtype=np.int64).copy()
+        coords[1:, :] = np.sort(coords[1:, :], axis=0)
+        return CooTensor.from_coords(coords, np.asarray(tensor.data, dtype=np.float64).copy(), tuple(tensor.shape))
+
 
 class QgsTensorDynamicT(QgsTensor):
     """Tendencies tensor of the models with dynamic reference temperatures (reference: qgtensor.py:843-1170): rank 5,
@@ -411,16 +460,11 @@ class QgsTensorDynamicT(QgsTensor):
             coords.append(c)
             data.append(d)
         coords, data = np.hstack(coords), np.concatenate(data)
-        # Jacobian tensor: the un-simplified tensor plus its copies with axis 1 swapped with axes 2, 3, 4
-        jc = [coords]
-        for ax in (2, 3, 4):
-            sw = coords.copy()
-            sw[[1, ax]] = sw[[ax, 1]]
-            jc.append(sw)
-        self.jacobian_tensor = CooTensor.from_coords(np.hstack(jc), np.tile(data, 4), shape)
-        srt = coords.copy()
-        srt[1:] = np.sort(coords[1:], axis=0)
-        self.tensor = CooTensor.from_coords(srt, data, shape)
+        # as the reference (qgtensor.py:662-666): the un-simplified entries become one COO array (duplicates summed), from which
+        # the Jacobian tensor and the simplified tensor are derived
+        raw = CooTensor.from_coords(coords, data, shape)
+        self.jacobian_tensor = self.jacobian_from_tensor(raw)
+        self.tensor = self.simplify_tensor(raw)
 
 
 class QgsTensorT4(QgsTensorDynamicT):

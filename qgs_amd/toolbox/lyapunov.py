@@ -158,17 +158,22 @@ class _BaseTrajectory(object):
         self.k = k
 
     def state(self, i):
+        if i < 0 or i > len(self.grid) - 1:
+            raise IndexError('base trajectory: grid index out of range')
         lo, hi = self._bounds(self.k)
-        if i < lo or i > hi:
-            k = self.k + (-1 if i < lo else 1)
+        # a consumer may skip several windows between two calls (the Ginelli / CLV runs ask for one state every dt / mdt
+        # steps, and a window can be shorter than that): move window by window until i is resident
+        while i > hi or i < lo:
             if self.descending:
-                self._load(k, self.starts[k])
+                if i > hi:
+                    raise RuntimeError('base trajectory states must be consumed in monotone (descending) order')
+                self._load(self.k - 1, self.starts[self.k - 1])
             else:
+                if i < lo:
+                    raise RuntimeError('base trajectory states must be consumed in monotone (ascending) order')
                 start = self.buf[hi - lo].clone()             # the last state of the window that is about to be overwritten
-                self._load(k, start)
-            lo, hi = self._bounds(k)
-            if i < lo or i > hi:
-                raise RuntimeError('base trajectory states must be consumed in monotone order')
+                self._load(self.k + 1, start)
+            lo, hi = self._bounds(self.k)
         return self.buf[i - lo]
 
 

@@ -104,6 +104,37 @@ def test_clvs_are_covariant(name, n_vec, sub):
     f.operands.release()
 
 
+@pytest.mark.parametrize('resident', [True, False])
+def test_clv_base_trajectory_windows_shorter_than_an_interval(monkeypatch, resident):
+    """Method 0 reads the fine base trajectory once per interval, dt / mdt = 10 grid steps apart; with a window budget that
+    holds 3 states the reader has to cross several windows between two reads (`_BaseTrajectory.state`, which used to move one
+    window per call and then refuse).  Bitwise the run with everything resident."""
+    from conftest import load_golden
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.toolbox.lyapunov import CovariantLyapunovsEstimator
+    g = load_golden('m36')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = np.random.RandomState(5).rand(64, g.ndim) * 0.01
+    est = CovariantLyapunovsEstimator(num_threads=1)
+    est.set_func(f, Df)
+    est.device_resident = resident
+
+    def run():
+        np.random.seed(4)
+        est.compute_clvs(0., 0.5, 1.5, 2.0, 0.1, 0.01, ic=ic, write_steps=1, n_vec=4, method=0)
+        tt, traj, exps, vecs = est.get_clvs()
+        return np.array(traj), np.array(exps), np.array(vecs)
+    monkeypatch.delenv('QGS_HIP_RECORD_WINDOW_MB', raising=False)
+    whole = run()
+    # base trajectory: budget / 4 over states of 36 x 64 x 8 bytes -> windows of 3 steps
+    monkeypatch.setenv('QGS_HIP_RECORD_WINDOW_MB', '%.6f' % (4 * 4 * 36 * 64 * 8 / 1048576.))
+    cut = run()
+    for a, b in zip(whole, cut):
+        assert a.shape == b.shape and np.isfinite(a).all() and np.array_equal(a, b)
+    est.terminate()
+    f.operands.release()
+
+
 def test_batched_matmul_and_backstep_kernels_vs_numpy():
     """The two kernels of the covariant estimator against NumPy, member by member: C = A B, A^T B, the upper triangle of a square
     product, a product with an upper-triangular right factor; one backward step a <- normalise(R^-1 a + noise) with

@@ -177,6 +177,59 @@ def test_oracle_agrees_with_own_tensor_on_f(built):
         assert np.array_equal(m.f(0., g['fx_x']), g['fx_f'])
 
 
+def test_static_tensor_helpers_against_golden_tensors(built, tmp_path):
+    """`QgsTensor.jacobian_from_tensor` / `simplify_tensor` by name, as the reference's users call them (qgtensor.py:701, 725),
+    on the a36 golden tensors and on the rank-5 d38 ones; `print_*_to_file` (qgtensor.py:792, 819)."""
+    import inspect
+    from qgs_amd.tensors.qgtensor import CooTensor, QgsTensor
+    for name in ('a36', 'd38'):
+        g = load_golden(name)
+        shape = (int(g['ndim']) + 1,) * g['coo'].shape[1]
+        t = CooTensor.from_coords(g['coo'].T, g['val'], shape)
+        assert np.array_equal(t.coords.T, g['coo']) and np.array_equal(t.data, g['val'])
+        s = QgsTensor.simplify_tensor(tensor=t)                          # already upper triangular: unchanged, bitwise
+        assert np.array_equal(s.coords.T, g['coo']) and np.array_equal(s.data, g['val'])
+        if name == 'a36':
+            # rank 3: J = T + T.swapaxes(1, 2) is the same two-operand sum whether T is simplified or not
+            j = QgsTensor.jacobian_from_tensor(tensor=t)
+            assert np.array_equal(j.coords.T, g['jcoo']) and np.array_equal(j.data, g['jval'])
+    # an un-simplified random tensor against the dense arrays
+    rng = np.random.RandomState(3)
+    for rank in (3, 5):
+        n = 6
+        dense = np.where(rng.rand(*(n,) * rank) < 0.2, rng.randn(*(n,) * rank), 0.)
+        t = CooTensor(dense)
+        jd = dense.copy()
+        for ax in range(2, rank):
+            jd = jd + dense.swapaxes(1, ax)
+        j = QgsTensor.jacobian_from_tensor(t)
+        assert np.array_equal(j.todense(), jd) and np.array_equal(j.coords, np.array(np.nonzero(jd)))
+        s = QgsTensor.simplify_tensor(t)
+        assert (np.diff(s.coords[1:], axis=0) >= 0).all()
+        x = rng.randn(n)
+        ein = 'ijk,j,k->i' if rank == 3 else 'ijklm,j,k,l,m->i'
+        assert np.allclose(np.einsum(ein, s.todense(), *(x,) * (rank - 1)), np.einsum(ein, dense, *(x,) * (rank - 1)), rtol=1e-13, atol=1e-13)
+    assert list(inspect.signature(QgsTensor.jacobian_from_tensor).parameters) == ['tensor']
+    assert list(inspect.signature(QgsTensor.simplify_tensor).parameters) == ['tensor']
+    T = built['rp20'][4]
+    T.print_tensor_to_file(str(tmp_path / 't.txt'), tensor_name='T')
+    T.print_jacobian_tensor_to_file(filename=str(tmp_path / 'j.txt'))
+    lines = open(str(tmp_path / 't.txt')).read().strip().split('\n')
+    assert len(lines) == 225 and lines[0].startswith('T[1][0][')
+    jl = open(str(tmp_path / 'j.txt')).read().strip().split('\n')
+    assert jl[0].startswith('QgsTensorJacobian[1][') and len(jl) == int((np.abs(T.jacobian_tensor.data) >= np.finfo(float).eps).sum())
+
+
+def test_sparse_mul_signatures_are_the_references():
+    """Keyword calls of user code written against the reference (sparse_mul.py:14, 49, 85, 122; user_guide.rst:437-458)."""
+    import inspect
+    from qgs_amd.functions import sparse_mul as sm
+    assert list(inspect.signature(sm.sparse_mul2).parameters) == ['coo', 'value', 'vec']
+    assert list(inspect.signature(sm.sparse_mul3).parameters) == ['coo', 'value', 'vec_a', 'vec_b']
+    assert list(inspect.signature(sm.sparse_mul4).parameters) == ['coo', 'value', 'vec_a', 'vec_b', 'vec_c']
+    assert list(inspect.signature(sm.sparse_mul5).parameters) == ['coo', 'value', 'vec_a', 'vec_b', 'vec_c', 'vec_d']
+
+
 def test_print_tensor(built, capsys):
     built['rp20'][4].print_tensor('T')
     out = capsys.readouterr().out.strip().split('\n')
