@@ -53,6 +53,25 @@ sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+PEAK_CLOCK_GHZ = 2.4           # the clock that peak is quoted at
+
+
+def clock_fields(model, achieved_tflops):
+    """`effective_clock_ghz` of the kernel just timed and the FP64 fraction against the peak AT THAT CLOCK.  The clock comes from
+    the kernel itself (qgs_kernel_clock: lane 0 of workgroup 0 reads the shader-clock counter and the constant 100 MHz counter
+    at entry and after its last store), so it is the clock the timed launch ran at -- no profiler pass, no smi sampling.  Boxes
+    of this pool differ in what they sustain under the fp64 load (2.07-2.4 GHz seen): `frac` moves with it, this figure does not."""
+    try:
+        clk = model.kernel_clock()
+    except Exception:
+        clk = None
+    if not clk or not clk[0] > 0:
+        return {'effective_clock_ghz': None, 'frac_at_effective_clock': None}
+    ghz, ms = clk
+    out = {'effective_clock_ghz': ghz, 'clock_probe_ms': ms, 'clock_source': 'in-kernel s_memtime / s_memrealtime of workgroup 0 of the last timed launch'}
+    if achieved_tflops is not None:
+        out['frac_at_effective_clock'] = achieved_tflops / (FP64_VALU_PEAK_TFLOPS * ghz / PEAK_CLOCK_GHZ)
+    return out
 
 
 def rk4_tableau():
@@ -297,6 +316,8 @@ def event_ms(torch, fn, n, warm=1):
     return float(np.median(ts)), ts
 
 
+LDS228_FLOOR_MS = 30.0         # qgs_spec_rklds16, 65 536 members x 100 steps: 44 996 fp64 instructions per workgroup-stage x 4 cycles / 4 SIMDs x 1 600 workgroup-stages per CU / 2.4 GHz (profiles/r05_lds228.md)
+
 TRAFFIC_SOURCE = 'profiles/hbm_traffic.json (rocprofv3 PMC passes of round 4, tools/r04_profiles.sh, committed; a constant attached by kernel name, not measured in this run)'
 
 
@@ -362,6 +383,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     ms = event_ms(torch, lambda: rec_runs(1), 4)[0] / reps       # (last: `rec` holds the write_steps = 1 record of the timed launches)
     rec_bytes = float(rec.numel() * 8)
     kname_rec = model.last_kernel_info()['name']
+    clk_rec = clock_fields(model, flops36 * n * steps / (ms * 1e-3) / 1e12)
     idx = sample_members(n, 8)
     got = rec[:, :, torch.from_numpy(idx).to(dev)].cpu().numpy().transpose(2, 1, 0)          # (member, mode, record)
     ref = ora.integrate_runge_kutta_jit(t, np.ascontiguousarray(ic_h[:, idx].T), 1, 1, b, c, a)
@@ -379,7 +401,9 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                      'fp64_valu_frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      # a plateau, reported as one: the floor of THIS formulation (issue slots of 2 076 fp64 instructions + 36 row
                      # stores per member-step on a lone wavefront per SIMD), profiles/r03_record_path.txt
-                     'floor_ms': 0.546, 'frac_of_floor': 0.546 / ms},
+                     'floor_ms': 0.546, 'frac_of_floor': 0.546 / ms,
+                     'effective_clock_ghz': clk_rec.get('effective_clock_ghz'),
+                     'fp64_valu_frac_at_effective_clock': clk_rec.get('frac_at_effective_clock')},
         'parity_check': pc}
     del rec
 
@@ -454,6 +478,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     ic = torch.from_numpy(ic_h).to(dev)
     rec = torch.empty((1, ndim, n), dtype=torch.float64, device=dev)
     ms, _ = event_ms(torch, lambda: model.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 3)
+    clk5 = clock_fields(model, flops36 * n * steps / (ms * 1e-3) / 1e12)
     idx = np.array(sorted(set(sample_members(65536, 6).tolist() + [524287, 1048575])))
     got = rec[0][:, torch.from_numpy(idx).to(dev)].cpu().numpy().T
     ref = ora.integrate_runge_kutta_jit(t, np.ascontiguousarray(ic_h[:, idx].T), 1, 0, b, c, a)[:, :, 0]
@@ -465,7 +490,9 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                                'the 8-GPU line carries its own measured single_gpu_reference'},
         'roofline': {'bound': 'fp64_valu', 'achieved': flops36 * n * steps / (ms * 1e-3) / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': flops36 * n * steps / (ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                     'traffic': measured_traffic('qgs_spec_rk_s4@1048576'), 'traffic_source': TRAFFIC_SOURCE},
+                     'traffic': measured_traffic('qgs_spec_rk_s4@1048576'), 'traffic_source': TRAFFIC_SOURCE,
+                     'effective_clock_ghz': clk5.get('effective_clock_ghz'), 'frac_at_effective_clock': clk5.get('frac_at_effective_clock'),
+                     'clock_note': 'workgroup 0 lives for one sixteenth of this launch (16 waves of workgroups): the clock of its first wave'},
         'parity_check': pc}
     del ic, rec
 
@@ -488,6 +515,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     ms, _ = event_ms(torch, tgls_calls, 3)
     ms_call = ms / calls
     kname = model.last_kernel_info()
+    clk4 = model.kernel_clock()
     # the propagators and end states the timed calls left behind, before the QR overwrites them
     idx = sample_members(n, 4)
     sel = torch.from_numpy(idx).to(dev)
@@ -497,7 +525,21 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     ref_y, ref_fm = ora.integrate_runge_kutta_tgls_jit(t, np.ascontiguousarray(ic_h[:, idx].T), eye, 1, 0, b, c, a, False, 1.)
     pc = parity_entry(kname['name'], 'propagators (36 x 36) and end states of sampled members after the timed calls',
                       max(rel_err(got_fm, ref_fm[..., 0]), rel_err(got_y, ref_y[..., 0])), 1e-11, idx)
-    ms_qr, _ = event_ms(torch, lambda: model.batched_qr_device(n, n, ndim, n_tg, recm.data_ptr(), rdiag.data_ptr(), st), 5)
+    # the QR of the Benettin step on those propagators, checked against LAPACK member by member (np.linalg.qr is what the
+    # reference calls, lyapunov.py:599-628), then timed on them (Q of an orthonormal matrix costs the same as the first one)
+    model.batched_qr_device(n, n, ndim, n_tg, recm.data_ptr(), rdiag.data_ptr(), st)
+    torch.cuda.synchronize()
+    q_dev = recm[0][:, :, sel].cpu().numpy().transpose(2, 0, 1)
+    r_dev = rdiag[:, sel].cpu().numpy().T
+    qr_err = 0.0
+    for k in range(len(idx)):
+        q_ref, r_ref = np.linalg.qr(got_fm[k])
+        qr_err = max(qr_err, float(np.abs(q_dev[k] - q_ref).max()), float(np.abs(r_dev[k] - np.diag(r_ref)).max() / max(1.0, np.abs(np.diag(r_ref)).max())))
+    ms_qr, _ = event_ms(torch, lambda: model.batched_qr_device(n, n, ndim, n_tg, recm.data_ptr(), rdiag.data_ptr(), st), 9)
+    clk_qr = model.kernel_clock()
+    qr_kernel = model.last_kernel_info()
+    qr_bytes = 2.0 * 8 * ndim * n_tg * n + 8.0 * n_tg * n                             # A in, Q out, diag(R) out
+    qr_traffic = measured_traffic(qr_kernel['name'])
     flops_tgls = 4 * (2 * jnnz) + 4 * 2 * ndim ** 3 + 7 * 2 * ndim * ndim + flops36     # 4.02e5 at ndim 36
     rate = n * steps / (ms_call * 1e-3)
     # what the two kernels of a call EXECUTE: fp64 instructions of their step loops, counted in the ISA (tools/kisa.py ->
@@ -516,7 +558,15 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
         'workload': 'MAOOAM-36 tangent model, 16 384 members x 36 tangent vectors (identity), 10 sub-steps per call, '
                     '%d calls timed together (trajectory pass + tangent pass per call)' % calls,
         'kernel': kname['name'], 'kernel_info': kname, 'ms_per_call': ms_call, 'traj_steps_per_s': rate,
-        'qr_kernel': model.last_kernel_info()['name'], 'qr_ms': ms_qr,
+        'qr_kernel': qr_kernel['name'], 'qr_kernel_info': qr_kernel, 'qr_ms': ms_qr,
+        'qr_roofline': {'bound': 'hbm', 'bytes': qr_bytes, 'achieved': qr_bytes / (ms_qr * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': qr_bytes / (ms_qr * 1e-3) / 1e9 / HBM_PEAK_GBS, 'floor_ms': qr_bytes / (HBM_PEAK_GBS * 1e9) * 1e3,
+                        'traffic': qr_traffic, 'traffic_source': TRAFFIC_SOURCE,
+                        'traffic_over_algorithmic': (qr_traffic / qr_bytes) if qr_traffic else None,
+                        'effective_clock_ghz': clk_qr[0] if clk_qr else None,
+                        'max_abs_err_vs_lapack': qr_err, 'lapack_tolerance': 1e-12, 'lapack_ok': bool(qr_err < 1e-12),
+                        'note': '16 384 matrices of 36 x 36 in, Q and diag(R) out; the time is the 70 dependent reflector steps '
+                                '(one barrier and one LDS broadcast each), not the memory system: profiles/r05_qr.md'},
         'roofline': {'bound': 'fp64_valu', 'achieved': rate * flops_tgls / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': rate * flops_tgls / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      'flops_per_traj_step': flops_tgls,
@@ -530,7 +580,10 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                      'hbm_algorithmic_frac': rate * 2 * 8 * (ndim + ndim * n_tg) / 1e9 / HBM_PEAK_GBS,
                      # a plateau, reported as one: instruction floor of the two kernels of a call (0.57 + 0.07 ms,
                      # profiles/r03_tgls.txt: one wavefront per SIMD at 380 VGPRs, 405 accumulation-register moves per column-step)
-                     'floor_ms': 0.64, 'frac_of_floor': 0.64 / ms_call},
+                     'floor_ms': 0.64, 'frac_of_floor': 0.64 / ms_call,
+                     'effective_clock_ghz': clk4[0] if clk4 else None,
+                     'executed_fp64_frac_at_effective_clock': (rate * executed['flops_per_traj_step'] / 1e12 /
+                                                               (FP64_VALU_PEAK_TFLOPS * clk4[0] / PEAK_CLOCK_GHZ)) if (executed and clk4) else None},
         'parity_check': pc}
     del tg, recm, rdiag
 
@@ -544,6 +597,7 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     ic = torch.from_numpy(ic_h).to(dev)
     rec = torch.empty((1, nd3, n), dtype=torch.float64, device=dev)
     ms, _ = event_ms(torch, lambda: m3.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st), 3)
+    clk3 = m3.kernel_clock()
     idx = sample_members(n, 8)
     got = rec[0][:, torch.from_numpy(idx).to(dev)].cpu().numpy().T
     ref = OracleModel(nd3, g['coo'], g['val']).integrate_runge_kutta_jit(t, np.ascontiguousarray(ic_h[:, idx].T), 1, 0, b, c, a)[:, :, 0]
@@ -559,7 +613,12 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                      'frac': rate * flops228 / 1e12 / FP64_VALU_PEAK_TFLOPS, 'flops_per_traj_step': flops228,
                      'traffic': measured_traffic('qgs_spec_rklds16'), 'traffic_source': TRAFFIC_SOURCE,
                      'algorithmic_bytes_per_launch': 2 * 8 * nd3 * n * steps,
-                     'hbm_algorithmic_frac': rate * 2 * 8 * nd3 / 1e9 / HBM_PEAK_GBS},
+                     'hbm_algorithmic_frac': rate * 2 * 8 * nd3 / 1e9 / HBM_PEAK_GBS,
+                     # a plateau, reported as one: the instruction floor of THIS formulation -- the generator's own count of fp64
+                     # instructions per workgroup-stage at full issue rate, no LDS or coefficient waits (profiles/r05_lds228.md)
+                     'floor_ms': LDS228_FLOOR_MS, 'frac_of_floor': LDS228_FLOOR_MS / ms,
+                     'effective_clock_ghz': clk3[0] if clk3 else None,
+                     'frac_at_effective_clock': (rate * flops228 / 1e12 / (FP64_VALU_PEAK_TFLOPS * clk3[0] / PEAK_CLOCK_GHZ)) if clk3 else None},
         'parity_check': pc}
     m3.close()
     return out
@@ -820,6 +879,20 @@ def main():
 
     kern_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in engine.kern_events])) if engine.kern_events else float('nan')
     kinfo = model.last_kernel_info()
+    clock = None
+    try:
+        clock = model.kernel_clock()                     # of the last timed pass's stepper launch (in-kernel probe, qgs_kernel_clock)
+    except Exception:
+        clock = None
+    # A short timed region (the driver's --steps 20 is 90 ms) is invisible to an smi sampler: the same passes are run on, untimed
+    # and outside every statistic above, until this process has kept the GPU busy for about 1.2 s.
+    busy_fill_passes = 0
+    if args.steps > 0 and elapsed < 1.0:
+        per_pass = elapsed / args.steps
+        busy_fill_passes = int(min(2000, max(1, (1.2 - elapsed) / max(per_pass, 1e-5))))
+        for k in range(busy_fill_passes):
+            engine.compute(k % 2, False)
+        engine.synchronize()
 
     result = None
     if rank == 0:
@@ -848,9 +921,15 @@ def main():
                        'parallelism': 'members sharded x%d, RCCL gather of final states onto rank 0 (async, overlapped)' % world,
                        'kernel': kinfo},
             'mode_updates_per_s': value * ndim,
+            'untimed_busy_fill_passes': busy_fill_passes,   # extra passes after the timed region so that a 1 Hz smi sampler sees the GPU busy
             'gather_ms': gather_ms,        # one RCCL gather of the final states onto rank 0, start to completion (None without a process group)
             'roofline': {'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_VALU_PEAK_TFLOPS,
+                         # the clock the timed launch ran at (in-kernel probe: shader-clock counter over the 100 MHz counter of
+                         # workgroup 0, which lives for the whole launch) and the fraction of the FP64 peak AT that clock
+                         'effective_clock_ghz': clock[0] if clock else None,
+                         'frac_at_effective_clock': (tflops / (FP64_VALU_PEAK_TFLOPS * clock[0] / PEAK_CLOCK_GHZ)) if clock else None,
+                         'clock_probe_ms': clock[1] if clock else None, 'peak_clock_ghz': PEAK_CLOCK_GHZ,
                          'kernel': kinfo['name'], 'kernel_ms': kern_ms,
                          'algorithmic_flops_per_launch': alg_flops, 'flops_per_traj_step': flops_per_traj_step,
                          'traffic': traffic,                                  # HBM bytes per launch from the PMC counters (profiles/)

@@ -175,12 +175,28 @@ int qgs_contraction_create(int device, int n_slots, int rank, int n_out_axes, in
 int qgs_contraction_apply(qgs_contraction *c, const double *vecs, double *res);
 int qgs_contraction_destroy(qgs_contraction *c);
 
-/* Page-lock (and later release) a caller-owned host block that receives large results, so that the device-to-host copies
- * of the host-layout entry points run at the pinned PCIe rate (measured 57 instead of 50 GB/s for a 1.9 GB record, and
- * without first-touch page faults inside the copy).  Optional: every entry point also accepts pageable memory.  The Python
- * binding registers its recycled result blocks (qgs_amd/_lib.py _ResultPool).  Replaces nothing in the reference: its
- * results travel between processes through pickling queues (qgs/integrators/integrator.py:388-395). */
+/* Host memory and the GPU (round 5).  The GPU -- kernels and copy engines alike -- only ever touches host memory that this
+ * library allocated itself (qgs_host_alloc below, its own bounce blocks) or that the caller handed over explicitly with
+ * qgs_host_register.  Every other host pointer an entry point is given (initial conditions, result blocks, tensors) is pageable
+ * as far as the library knows: it is read and written by CPU threads only, through page-locked bounce blocks
+ * (qgs_amd/csrc/host_bridge.h; 45 GB/s for a 189 GB record with 16 host threads, profiles/r05_big_record.txt), and the runtime
+ * is never asked to pin it.
+ *
+ * qgs_host_register page-locks and maps a caller-owned block so that the unpack kernels store into it directly (51 GB/s for the
+ * same record, after 0.04 s per GB of page-locking).  By calling it the caller guarantees, until qgs_host_unregister:
+ *   - the block is a mapping of its own (mmap, a page-aligned allocation of whole pages) -- not a piece of an allocator's
+ *     heap that shares pages with other objects or that the allocator may remap, trim or hand out again;
+ *   - it is not freed, moved (realloc, mremap) or protected (mprotect), and no other thread forks while kernels write to it;
+ *   - nothing else registers or unregisters overlapping ranges.
+ * Registered heap memory that did not keep these promises is where every GPU write fault of round 4 was found.
+ * Replaces nothing in the reference: its results travel between processes through pickling queues
+ * (qgs/integrators/integrator.py:388-395). */
 int qgs_host_register(void *ptr, int64_t bytes);
+/* Blocking copies between device memory of GPU `device` and ANY host memory (pageable: through the bounce blocks; a block of
+ * qgs_host_alloc / qgs_host_register: one DMA copy).  Work queued on `stream` (may be NULL) is waited for first.  For host
+ * programs that would otherwise hand pageable pointers to hipMemcpy themselves (the Python layer's uploads and downloads). */
+int qgs_memcpy_h2d(int device, void *d_dst, const void *h_src, int64_t bytes, void *stream);
+int qgs_memcpy_d2h(int device, void *h_dst, const void *d_src, int64_t bytes, void *stream);
 /* Page-locked host memory allocated by the runtime itself (portable, mapped): what result blocks should live in when the kernels
  * are to store into them.  Unlike a registered block of the caller's it shares no pages with the C library's heap
  * (every GPU write fault seen in round 4 hit registered heap memory). */
@@ -211,10 +227,17 @@ int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner
  * R[w][n_inner][ld]; dst is the (n_traj, n_inner, n_records) block in the reference's layout (the host array the reference's
  * loops fill record by record, qgs/toolbox/lyapunov.py:232-358, qgs/integrators/integrate.py:196-223) and receives records
  * [first_record, first_record + n_window).  dst may be device memory or page-locked host memory (qgs_host_register: written
- * by the kernel's own stores) or pageable host memory (staged on the device, then copied).  Enqueued on `stream`: the
- * window may be overwritten by work enqueued behind it. */
+ * by the kernel's own stores) or pageable host memory (staged on the device, then brought over by the bounce ring of
+ * qgs_amd/csrc/host_bridge.h: the library never page-locks memory it did not allocate).  Enqueued on `stream`: the window may
+ * be overwritten by work enqueued behind it.  With a pageable dst, qgs_unpack_window returns when the records are in dst;
+ * qgs_unpack_window_enqueue hands the window to the device's drain thread and returns (the host is only held while the
+ * previous window of this model is still being read from its staging block), and qgs_drain_wait blocks until every window
+ * enqueued for the model has arrived -- dst must stay valid until then.  For any other dst the two calls are the same. */
 int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
                       int64_t first_record, const double *d_window, double *dst, void *stream);
+int qgs_unpack_window_enqueue(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
+                              int64_t first_record, const double *d_window, double *dst, void *stream);
+int qgs_drain_wait(qgs_model *m);
 
 int qgs_tendencies_device(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x, double *d_dx, void *stream);
 

@@ -54,12 +54,16 @@ SIGNATURES = {
     'qgs_host_alloc': (_int, [_i64, ctypes.POINTER(_vp)]),
     'qgs_host_free': (_int, [_vp]),
     'qgs_host_register': (_int, [_vp, _i64]),
+    'qgs_memcpy_h2d': (_int, [_int, _vp, _vp, _i64, _vp]),
+    'qgs_memcpy_d2h': (_int, [_int, _vp, _vp, _i64, _vp]),
     'qgs_host_unregister': (_int, [_vp]),
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_pack_tangent': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_records': (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_window': (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_unpack_window_enqueue': (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_drain_wait': (_int, [_vp]),
     'qgs_tendencies_device': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_rk_integrate_device': (_int, [_vp, _i64, _i64, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p, _f64p, _vp, _vp]),
     'qgs_rk_tgls_integrate_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _f64p, _i64, _int, _i64, _int, _f64p, _f64p,
@@ -150,24 +154,40 @@ def _ptr(a):
     return a.ctypes.data_as(_vp) if a is not None else None
 
 
-class _Store(object):
-    """One block of host memory of the result pool, page-locked while it lives: device-to-host copies into it run at the pinned
-    PCIe rate, the kernels can store into it, and the page faults of a fresh allocation are taken once, not inside a copy.
-    The block is allocated by the runtime (qgs_host_alloc = hipHostMalloc, portable + mapped), not carved out of the C
-    library's heap and registered: registered heap memory is where every GPU write fault of round 4 happened."""
+def _advise_huge_pages(arr):
+    """Ask for transparent huge pages behind a large fresh array (madvise MADV_HUGEPAGE on its whole 2 MiB blocks): the first
+    touch of a 2 MiB page costs one fault instead of 512, which is what a result of tens of GB spends its first fill on."""
+    try:
+        addr, n = arr.ctypes.data, arr.nbytes
+        lo = -(-addr // (2 << 20)) * (2 << 20)
+        hi = (addr + n) // (2 << 20) * (2 << 20)
+        if hi > lo:
+            libc = ctypes.CDLL(None, use_errno=True)
+            libc.madvise.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+            libc.madvise(ctypes.c_void_p(lo), ctypes.c_size_t(hi - lo), 14)            # MADV_HUGEPAGE
+    except Exception:
+        pass
 
-    #: blocks above this size are not page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB): they are ordinary NumPy memory and
-    #: are filled through staged copies.  Page-locking takes the pages out of the kernel's hands for good; the largest blocks
-    #: measured page-locked are 170 GB (profiles/r04_lyap_big_1000.json) and 189 GB (profiles/r03_big_record_10000.txt), and a
-    #: 0.85 TB one was being set up when a box of the pool went down (DESIGN 3.6) -- nothing of that size is handed to the driver
-    #: any more.
+
+class _Store(object):
+    """One block of host memory of the result pool.
+
+    A block the pool can keep (`pinned=True`) is page-locked while it lives: device-to-host copies into it run at the pinned PCIe
+    rate, the kernels can store into it, and the page faults of a fresh allocation are taken once, not inside a copy.  It is
+    allocated by the runtime (qgs_host_alloc = hipHostMalloc, portable + mapped), not carved out of the C library's heap and
+    registered: registered heap memory is where every GPU write fault of round 4 happened.
+    A block too large for the pool to keep is used once; page-locking it (0.04 s per GB: 8 s for 189 GB, 3 s of the 6 s the
+    72 GB estimator record of profiles/r04_lyap_big.json took) buys nothing.  It is ordinary NumPy memory, huge pages
+    requested, and is filled through the page-locked bounce ring of csrc/host_bridge.cpp while the next window is computed."""
+
+    #: blocks above this size are never page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB)
     PIN_MAX_BYTES = int(os.environ.get('QGS_HOST_PIN_MAX_BYTES', str(256 << 30)))
 
-    def __init__(self, n_doubles):
+    def __init__(self, n_doubles, pinned=True):
         self.size = n_doubles
         self.nbytes = 8 * n_doubles
         self._ptr = None
-        if self.nbytes <= self.PIN_MAX_BYTES:
+        if pinned and self.nbytes <= self.PIN_MAX_BYTES:
             p = _vp()
             try:
                 if lib().qgs_host_alloc(self.nbytes, ctypes.byref(p)) == 0 and p.value:
@@ -178,6 +198,8 @@ class _Store(object):
             self.array = np.frombuffer((ctypes.c_char * self.nbytes).from_address(self._ptr), dtype=np.float64)
         else:
             self.array = np.empty(n_doubles)
+            if self.nbytes >= (64 << 20):
+                _advise_huge_pages(self.array)
         self._pinned = self._ptr is not None
 
     def __del__(self):
@@ -236,7 +258,7 @@ class _ResultPool(object):
                 store = lst.pop()
                 self._held -= store.nbytes
         if store is None:
-            store = _Store(size)
+            store = _Store(size, pinned=size * 8 <= self._cap)          # (a block the pool could never keep is not page-locked)
         return np.asarray(_PooledBlock(self, store, shape))
 
     def _give_back(self, store):
@@ -250,14 +272,38 @@ _RESULTS = _ResultPool()
 
 
 def to_host(d_tensor):
-    """A device tensor (torch) as a NumPy array in a block of the page-locked result pool: one DMA copy at the PCIe rate instead
-    of a copy into fresh pageable memory (1.9 GB: 35 ms instead of ~0.3 s)."""
+    """A device tensor (torch) as a NumPy array.  The copy is made by the library (qgs_memcpy_d2h), which never shows the
+    runtime a pageable pointer: small results arrive through its bounce blocks in ordinary NumPy memory, large ones (>= 512 MB)
+    in a block of the result pool -- page-locked, one DMA copy at the PCIe rate (1.9 GB: 35 ms instead of ~0.3 s) -- or, beyond
+    what the pool keeps, in huge-page NumPy memory through the bounce ring."""
     import torch
-    if d_tensor.numel() * d_tensor.element_size() < (512 << 20):
-        return d_tensor.cpu().numpy()              # page-locking a fresh block costs more than it saves below a few hundred MB
-    out = _RESULTS.empty(tuple(d_tensor.shape))
-    torch.from_numpy(out).copy_(d_tensor, non_blocking=False)
+    if d_tensor.device.type != 'cuda':
+        return d_tensor.detach().cpu().numpy()
+    d_tensor = d_tensor.contiguous()
+    nbytes = d_tensor.numel() * d_tensor.element_size()
+    if d_tensor.dtype == torch.float64 and nbytes >= (512 << 20):
+        out = _RESULTS.empty(tuple(d_tensor.shape))
+    else:
+        out = np.empty(tuple(d_tensor.shape), dtype=torch.empty(0, dtype=d_tensor.dtype).numpy().dtype)
+    if nbytes:
+        st = torch.cuda.current_stream(d_tensor.device).cuda_stream
+        _check(lib().qgs_memcpy_d2h(d_tensor.device.index or 0, out.ctypes.data, d_tensor.data_ptr(), nbytes, st or None))
     return out
+
+
+def to_device(array, device):
+    """A NumPy array as a new tensor on `device` (torch).  On a GPU the copy is made by the library (qgs_memcpy_h2d: through its
+    page-locked bounce blocks, one pageable transfer at a time per device), not by handing the runtime the caller's pages."""
+    import torch
+    a = np.ascontiguousarray(array)
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return torch.from_numpy(a).to(device)
+    t = torch.empty(a.shape, dtype=torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype, device=device)
+    if a.nbytes:
+        st = torch.cuda.current_stream(device).cuda_stream
+        _check(lib().qgs_memcpy_h2d(device.index or 0, t.data_ptr(), a.ctypes.data, a.nbytes, st or None))
+    return t
 
 
 def _tensor_rank(coo, jcoo=None):
@@ -437,6 +483,15 @@ class HipModel(object):
         pointer -- page-locked or pageable) from a mode-major window of records on the device."""
         _check(lib().qgs_unpack_window(self._h, n_traj, ld, int(n_inner), int(n_window), int(nrec), int(first_record), d_window, dst,
                                        stream or None))
+
+    def unpack_window_enqueue(self, n_traj, ld, n_inner, n_window, nrec, first_record, d_window, dst, stream=0):
+        """`unpack_window` that does not wait for a pageable `dst` to be filled: the window is handed to the device's drain thread
+        (page-locked bounce blocks + host threads); `drain_wait()` blocks until every such window has arrived."""
+        _check(lib().qgs_unpack_window_enqueue(self._h, n_traj, ld, int(n_inner), int(n_window), int(nrec), int(first_record), d_window,
+                                               dst, stream or None))
+
+    def drain_wait(self):
+        _check(lib().qgs_drain_wait(self._h))
 
     def tendencies_device(self, n_traj, ld, d_x, d_dx, stream=0):
         _check(lib().qgs_tendencies_device(self._h, n_traj, ld, d_x, d_dx, stream or None))

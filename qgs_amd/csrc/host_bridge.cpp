@@ -106,7 +106,7 @@ public:
 private:
     CpuPool()
     {
-        int n = std::min(8, available_cpus());
+        int n = std::min(16, available_cpus());
         if (const char *e = std::getenv("QGS_HIP_HOST_THREADS")) n = std::atoi(e);
         n_threads_ = std::max(1, std::min(64, n));
     }

@@ -18,7 +18,7 @@
 
 namespace qgs {
 
-// host threads the gather / scatter uses (QGS_HIP_HOST_THREADS; default min(8, CPUs this process may run on))
+// host threads the gather / scatter uses (QGS_HIP_HOST_THREADS; default min(16, CPUs this process may run on))
 int host_copy_threads();
 
 // Blocking copies of `bytes` contiguous bytes; work already queued on `st` is waited for first, the copy has completed on return.

@@ -974,6 +974,7 @@ struct qgs_model {
     int magnitude_ulp = qgs::DEFAULT_MAGNITUDE_ULP;     // coefficient classes of the specialised kernels (QGS_HIP_MAGNITUDE_ULP, codegen.h Canonical)
     std::vector<int64_t> drain_tickets;                // windows on their way into pageable host memory (host_bridge.h), oldest first
     std::map<const Buffer *, DrainSlot> drain_slots;   // per staging block: its window in flight, the event that marks its unpack
+    std::map<uintptr_t, std::unique_ptr<Buffer>> drain_staging;   // qgs_unpack_window_enqueue: one staging block per destination array
     unsigned *d_one_counter = nullptr;                 // "workgroups finished" word of the single-state kernels
     unsigned long long one_seq = 0;                    // sequence number of the last single-state call (the kernel echoes it into h_pin[0])
     // Jacobian tensor grouped by output element (generic_kernels.h OnePairs), models of up to 1024 variables
@@ -1687,7 +1688,9 @@ int qgs_model_destroy(qgs_model *m)
         if (m->ev_comp[i]) (void)hipEventDestroy(m->ev_comp[i]);
         if (m->ev_copy[i]) (void)hipEventDestroy(m->ev_copy[i]);
     }
+    for (int64_t t : m->drain_tickets) (void)qgs::bridge_wait_done(t, nullptr);
     for (auto &kv : m->drain_slots) if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
+    for (auto &kv : m->drain_staging) kv.second->release();
     m->uploads.release();
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
@@ -2463,6 +2466,20 @@ static int drain_finish(qgs_model *m)
     return rc ? fail(first) : 0;
 }
 
+// staging blocks of qgs_unpack_window_enqueue (nothing of them in flight any more)
+static void release_drain_staging(qgs_model *m)
+{
+    for (auto &kv : m->drain_staging) {
+        auto it = m->drain_slots.find(kv.second.get());
+        if (it != m->drain_slots.end()) {
+            if (it->second.ev) (void)hipEventDestroy(it->second.ev);
+            m->drain_slots.erase(it);
+        }
+        kv.second->release();
+    }
+    m->drain_staging.clear();
+}
+
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging, then
 // either one copy (page-locked destination, or a single window) or the bounce ring of host_bridge.h (pageable destination)
 static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t ld, int64_t Wk, int64_t n_records, int64_t lo_s,
@@ -2574,18 +2591,43 @@ int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, i
     return (int)std::min<int64_t>(p.n_windows, 0x7fffffff);
 }
 
-int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
-                      int64_t first_record, const double *d_window, double *dst, void *stream)
+int qgs_unpack_window_enqueue(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
+                              int64_t first_record, const double *d_window, double *dst, void *stream)
 {
     if (check_common(m, n_traj, ld)) return -1;
     if (n_inner < 1 || n_inner > (int64_t)65535 * 64 || n_window < 1 || n_records < 1 || first_record < 0 ||
         first_record + n_window > n_records || !d_window || !dst) return fail("bad window arguments");
     HIPCHK(hipSetDevice(m->device));
     double *alias = device_alias(m, dst, sizeof(double) * (size_t)n_traj * (size_t)n_inner * (size_t)n_records);
-    if (drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream)) {
-        (void)drain_finish(m);
-        return -1;
+    if (alias) return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream);
+    // one staging block per destination array: the caller's windows (vectors, states, exponents of one record window) are then
+    // staged without one waiting for the DMA of the other -- with a single block the host sat through the vectors' transfer
+    // inside this call and enqueued the next window's kernels only afterwards (no overlap of compute and transfer at all)
+    auto it = m->drain_staging.find((uintptr_t)dst);
+    if (it == m->drain_staging.end()) {
+        if (m->drain_staging.size() >= 8) {                       // (a caller that never calls qgs_drain_wait)
+            if (drain_finish(m)) return -1;
+            release_drain_staging(m);
+        }
+        it = m->drain_staging.emplace((uintptr_t)dst, std::make_unique<Buffer>()).first;
     }
+    return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, *it->second, (hipStream_t)stream);
+}
+
+int qgs_drain_wait(qgs_model *m)
+{
+    if (!m) return fail("null model");
+    const int rc = drain_finish(m);
+    release_drain_staging(m);          // the run is over: its staging blocks (a window of records each) go back to the device
+    return rc;
+}
+
+int qgs_unpack_window(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_window, int64_t n_records,
+                      int64_t first_record, const double *d_window, double *dst, void *stream)
+{
+    const int rc = qgs_unpack_window_enqueue(m, n_traj, ld, n_inner, n_window, n_records, first_record, d_window, dst, stream);
+    if (!m) return rc;
+    if (rc) { const std::string e = g_err; (void)drain_finish(m); return fail(e); }
     return drain_finish(m);          // (a pageable destination: the window has arrived when the call returns)
 }
 
@@ -2837,6 +2879,24 @@ int qgs_host_register(void *ptr, int64_t bytes)
     // portable + mapped: every GPU of the node can store into the block (the unpack kernels of all shards write their slices)
     HIPCHK(hipHostRegister(ptr, (size_t)bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     registry_add(ptr, (size_t)bytes);
+    return 0;
+}
+
+int qgs_memcpy_h2d(int device, void *d_dst, const void *h_src, int64_t bytes, void *stream)
+{
+    if (bytes < 0 || (bytes > 0 && (!d_dst || !h_src))) return fail("bad arguments");
+    HIPCHK(hipSetDevice(device));
+    if (copy_h2d(d_dst, h_src, (size_t)bytes, (hipStream_t)stream)) return -1;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int qgs_memcpy_d2h(int device, void *h_dst, const void *d_src, int64_t bytes, void *stream)
+{
+    if (bytes < 0 || (bytes > 0 && (!h_dst || !d_src))) return fail("bad arguments");
+    HIPCHK(hipSetDevice(device));
+    if (copy_d2h(h_dst, d_src, (size_t)bytes, (hipStream_t)stream)) return -1;
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

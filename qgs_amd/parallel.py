@@ -10,6 +10,11 @@ PyTorch is used for process-group plumbing and device buffers only.
 """
 import numpy as np
 
+from qgs_amd import _lib
+
+# host <-> device transfers go through the library (its bounce blocks; plain torch copies for CPU tensors, e.g. the gloo tests)
+_to_host, _to_device = _lib.to_host, _lib.to_device
+
 
 def shard_bounds(n_total, world_size):
     """Contiguous blocks of members per rank, remainder to the first ranks: list of (start, stop)."""
@@ -82,12 +87,12 @@ def gather_to_host(ens, local, max_bytes=None):
     n_rec = int(local.shape[2])
     per_record = ens.n_total * int(local.shape[1]) * local.element_size()
     if not ens.distributed or per_record * n_rec <= max_bytes or n_rec <= 1:
-        return ens.gather(local).cpu().numpy()
+        return _to_host(ens.gather(local))
     chunk = max(1, int(max_bytes // max(1, per_record)))
     out = np.empty((ens.n_total, int(local.shape[1]), n_rec))
     for r0 in range(0, n_rec, chunk):
         r1 = min(n_rec, r0 + chunk)
-        out[:, :, r0:r1] = ens.gather(local[:, :, r0:r1].contiguous()).cpu().numpy()
+        out[:, :, r0:r1] = _to_host(ens.gather(local[:, :, r0:r1].contiguous()))
     return out
 
 
@@ -127,7 +132,7 @@ def _integrate_shard_on_device(f, device, local_ic, time, forward, write_steps, 
     n, ndim = local_ic.shape
     nrec = _lib.n_records(time, write_steps)
     with torch.cuda.device(device):
-        d_rows = torch.from_numpy(local_ic).to(device)
+        d_rows = _lib.to_device(local_ic, device)
         d_out = torch.empty((n, ndim, nrec), dtype=torch.float64, device=device)
         torch.cuda.current_stream(device).synchronize()          # the library works on its own streams
         model.rk_integrate_rows_device(n, d_rows.data_ptr(), time, 1 if forward else -1, write_steps, b, c, a, d_out.data_ptr())
@@ -215,4 +220,4 @@ def integrate_ensemble(f, t0, t, dt, ic, forward=True, write_steps=0, b=None, c=
     ens._dist.all_reduce(nrec, op=ens._dist.ReduceOp.MAX, group=process_group)
     if ens.n_local == 0:
         local = np.zeros((0, ic.shape[1], int(nrec.item())))
-    return time, gather_to_host(ens, torch.from_numpy(np.ascontiguousarray(local)).to(device))
+    return time, gather_to_host(ens, _to_device(local, device))

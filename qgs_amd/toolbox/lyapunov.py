@@ -36,14 +36,9 @@ import threading
 
 import numpy as np
 
+from qgs_amd import _lib
 from qgs_amd.integrators import integrate as _fn
 from qgs_amd.functions.util import normalize_matrix_columns as _normalize_columns, reverse, solve_triangular_matrix as _solve_triangular
-
-
-#: Uploads from pageable NumPy memory are made one at a time across the shard threads of a device list: for a pageable operand
-#: the runtime pins the caller's pages in place, and several threads doing that at once (slices of one array, neighbouring small
-#: arrays) is what produced GPU write faults in round 4 (qgs_hip_api.hip copy_with_host).
-_UPLOAD_LOCK = threading.Lock()
 
 
 def _window_budget_bytes():
@@ -55,9 +50,25 @@ def _window_budget_bytes():
     return int(max(1.0, mb * 1048576.0))
 
 
+def _stat_sum(stat_path, keys):
+    """Sum of the named counters of a cgroup memory.stat file (0 when it cannot be read)."""
+    total = 0
+    try:
+        with open(stat_path) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) == 2 and parts[0] in keys:
+                    total += int(parts[1])
+    except (OSError, ValueError):
+        return 0
+    return total
+
+
 def _cgroup_memory_room(proc_cgroup='/proc/self/cgroup', sys_root='/sys/fs/cgroup'):
     """Bytes this process' control groups still allow (limit - usage, the tightest of the groups found), or None when no
-    group sets a limit.  /proc/meminfo describes the machine, not the container: a container limit is only visible here."""
+    group sets a limit.  /proc/meminfo describes the machine, not the container: a container limit is only visible here.
+    Usage is counted without the group's file cache (memory.stat: active_file + inactive_file): after reading goldens, the
+    kernel cache or earlier large results a container reports little room while nearly all of it can be had back."""
     rooms = []
 
     def read(path):
@@ -94,7 +105,13 @@ def _cgroup_memory_room(proc_cgroup='/proc/self/cgroup', sys_root='/sys/fs/cgrou
         if limit is None or limit >= (1 << 60):                   # "max" / the v1 spelling of no limit
             continue
         used = read(cur_path) or 0
-        rooms.append(max(0, limit - used))
+        stat = os.path.join(os.path.dirname(cur_path), 'memory.stat')
+        # (v1 lists both `inactive_file` and `total_inactive_file`: the hierarchical totals are the ones that match usage_in_bytes)
+        if os.path.basename(cur_path) == 'memory.usage_in_bytes':
+            cache = _stat_sum(stat, ('total_inactive_file', 'total_active_file')) or _stat_sum(stat, ('inactive_file', 'active_file'))
+        else:
+            cache = _stat_sum(stat, ('inactive_file', 'active_file'))
+        rooms.append(max(0, limit - max(0, used - cache)))
     return min(rooms) if rooms else None
 
 
@@ -220,8 +237,10 @@ class _RecordWindows(object):
             ready.record(self.compute)
             self.copy.wait_event(ready)
         for t, q, host in zip(self.bufs[self.which], self.inner, self.hosts):
-            self.m.unpack_window(self.n, self.ld, q, count, self.n_records, first, t[first - self.j * self.W].data_ptr(),
-                                 host.ctypes.data, self.copy.cuda_stream)
+            # (a pageable host block: staged on the device, then brought over by the library's drain thread while the next
+            # window is computed -- `finish` waits for it)
+            self.m.unpack_window_enqueue(self.n, self.ld, q, count, self.n_records, first, t[first - self.j * self.W].data_ptr(),
+                                         host.ctypes.data, self.copy.cuda_stream)
         ev = torch.cuda.Event()
         ev.record(self.copy)
         self.done[self.which] = ev
@@ -232,6 +251,7 @@ class _RecordWindows(object):
         self._flush()
         self.copy.synchronize()
         self.compute.synchronize()
+        self.m.drain_wait()
 
 
 def _in_threads(work, count):
@@ -374,7 +394,6 @@ class LyapunovsEstimator(object):
 
         # the result blocks of the WHOLE ensemble, in host memory and in the reference's layouts; every shard fills its slice.
         # Their size is what bounds a run -- checked before anything is allocated or computed.
-        from qgs_amd import _lib
         nt, nd, nv, nr = self.n_traj, self.n_dim, self.n_vec, self.n_records
         need = 8 * nt * nr * (nd * nv * (2 if pre_qr else 1) + nd + nv)
         avail = _host_memory_available()
@@ -449,9 +468,9 @@ class LyapunovsEstimator(object):
                 at[i + 1] = at[i] + len(pieces[-1])
             full_grid = np.concatenate(pieces + [full_grid[-1:]])
         ic_modes = torch.zeros((ndim, ld), dtype=f64, device=dev)
-        with _UPLOAD_LOCK:
-            ic_modes[:, :n] = torch.from_numpy(np.ascontiguousarray(ic.T)).to(dev)
-            torch.cuda.current_stream(dev).synchronize()
+        # (host -> device through the library's bounce blocks: `_lib.to_device`; no pageable pointer ever reaches the runtime, which
+        # is what made concurrent uploads of shard threads unsafe in round 4)
+        ic_modes[:, :n] = _lib.to_device(ic.T, dev)
         base = _BaseTrajectory(torch, m, n, ld, full_grid, ic_modes, budget // 4, forward, (self.b, self.c, self.a), stream)
         n_pre = len(self._pretime)
 
@@ -460,9 +479,7 @@ class LyapunovsEstimator(object):
         # (the drawn matrices go up as they are, (n, n_dim, n_vec), and are brought into the device layout F[mode][vector][member]
         # by the pack kernel: the host-side transpose of 170 MB at config-4 size took longer than the whole spin-up)
         q = torch.zeros((ndim, nv, ld), dtype=f64, device=dev)
-        with _UPLOAD_LOCK:
-            a0_rows = torch.from_numpy(np.ascontiguousarray(a0)).to(dev)
-            torch.cuda.current_stream(dev).synchronize()
+        a0_rows = _lib.to_device(a0, dev)
         m.pack_tangent(n, ld, nv, a0_rows.data_ptr(), q.data_ptr(), stream)
         torch.cuda.current_stream(dev).synchronize()
         del a0_rows
@@ -476,8 +493,16 @@ class LyapunovsEstimator(object):
         q_new = torch.empty((1, ndim, nv, ld), dtype=f64, device=dev)
         y_end = torch.empty((1, ndim, ld), dtype=f64, device=dev)
         # records on their way to the host: vectors F[record][mode * vector][member], states, diag(R) of the QR before the interval
+        # Their windows want to be long: a window of W records reaches the host block (records innermost) as runs of 8 W bytes, and
+        # at config-4 size half of the default budget gives W = 11 -- 88-byte runs, a page apart.  Unless the budget was set by hand,
+        # the record windows take up to a sixteenth of the GPU's free memory, at most 12 GiB (W = 36 there; measured over budgets
+        # of 8 / 16 / 32 / 64 GiB in profiles/r05_lyap_big.md: longer windows cost more start-up and tail than their runs gain).
+        rec_budget = budget // 2
+        if 'QGS_HIP_RECORD_WINDOW_MB' not in os.environ:
+            free, _total = torch.cuda.mem_get_info(dev)
+            rec_budget = max(rec_budget, min(free // 16, 12 << 30))
         rec = _RecordWindows(torch, m, n, ld, (ndim * nv, ndim, nv) + ((ndim * nv,) if out_pre is not None else ()),
-                             (out_vec, out_traj, out_exp) + ((out_pre,) if out_pre is not None else ()), self.n_records, budget // 2, dev)
+                             (out_vec, out_traj, out_exp) + ((out_pre,) if out_pre is not None else ()), self.n_records, rec_budget, dev)
         rec_dt = np.ones(self.n_records)                             # interval length behind each record's exponents
 
         def propagate(y_index, subtime, direction, pre=None):
@@ -521,8 +546,7 @@ class LyapunovsEstimator(object):
             if rdiag is None:       # no spin-up interval
                 rdiag = rdiag0
             if out_junction is not None:
-                with _UPLOAD_LOCK:
-                    out_junction[...] = base.state(at[n_pre - 1])[:, :n].t().cpu().numpy()
+                out_junction[...] = _lib.to_host(base.state(at[n_pre - 1])[:, :n].t())
             iw, last = 0, None
             for ti in range(len(tim) - 1):
                 tt, d = tim[ti], tim[ti + 1] - tim[ti]
@@ -800,7 +824,6 @@ class CovariantLyapunovsEstimator(object):
         record does not fit the free device memory of a shard's GPU (the host path has no such limit)."""
         import time as _clock
         import torch
-        from qgs_amd import _lib
         nt, nd, nv = self.n_traj, self.n_dim, self.n_vec
         tw = len(self._time) - 1
         tew = len(self._time) + len(self._aftertime) - 2
@@ -852,11 +875,8 @@ class CovariantLyapunovsEstimator(object):
         n_pre = len(self._pretime)
         t_start = _clock.perf_counter()
 
-        def upload(host):                                   # (n, ...) host rows -> device tensor, one pageable copy at a time
-            with _UPLOAD_LOCK:
-                t = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
-                torch.cuda.current_stream(dev).synchronize()
-            return t
+        def upload(host):                                   # (n, ...) host rows -> device tensor, through the library's bounce blocks
+            return _lib.to_device(host, dev)
 
         def basis(rows):
             """(n, nd, nv) host matrices -> (Q[mode][vector][member] of their QR, R[nv][nv][member] = Q^T A)"""

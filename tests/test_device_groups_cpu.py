@@ -109,6 +109,12 @@ def test_host_memory_guard_reads_the_container_limits(tmp_path):
     (root / 'a' / 'b' / 'memory.max').write_text('%d\n' % (16 << 30))
     (root / 'a' / 'b' / 'memory.current').write_text('%d\n' % (1 << 30))
     assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 15 << 30
+    # usage counts the group's page cache, which the kernel gives back: 10 GB "used" of which 9 GB are file pages leave 15 GB of 16
+    (root / 'a' / 'b' / 'memory.current').write_text('%d\n' % (10 << 30))
+    (root / 'a' / 'b' / 'memory.stat').write_text('anon %d\ninactive_file %d\nactive_file %d\nshmem 0\n' % (1 << 30, 6 << 30, 3 << 30))
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 15 << 30
+    (root / 'a' / 'b' / 'memory.stat').unlink()
+    (root / 'a' / 'b' / 'memory.current').write_text('%d\n' % (1 << 30))
     # cgroup v1 memory controller; 2^63-ish = no limit
     proc.write_text('4:memory:/jobs/x\n0::/\n')
     (root / 'memory' / 'jobs' / 'x').mkdir(parents=True)
@@ -117,6 +123,9 @@ def test_host_memory_guard_reads_the_container_limits(tmp_path):
     (root / 'memory' / 'jobs' / 'x' / 'memory.usage_in_bytes').write_text('%d\n' % (2 << 30))
     (root / 'a' / 'memory.max').write_text('max\n')
     (root / 'a' / 'b' / 'memory.max').write_text('max\n')
+    assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 30 << 30
+    (root / 'memory' / 'jobs' / 'x' / 'memory.usage_in_bytes').write_text('%d\n' % (12 << 30))
+    (root / 'memory' / 'jobs' / 'x' / 'memory.stat').write_text('cache 0\ninactive_file 1\ntotal_inactive_file %d\ntotal_active_file %d\n' % (7 << 30, 3 << 30))
     assert lyapunov._cgroup_memory_room(str(proc), str(root)) == 30 << 30
     # no limit anywhere
     (root / 'memory' / 'jobs' / 'x' / 'memory.limit_in_bytes').write_text('9223372036854771712\n')

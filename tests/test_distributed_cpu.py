@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the multi-GPU path (member sharding + final gather) with the per-rank engine
+"""CPU, world_size 2 and 8, gloo: the multi-GPU path (member sharding + final gather) with the per-rank engine
 replaced by an oracle-backed stand-in (the HIP engine needs a GPU; sharding / gathering does not)."""
 import os
 import socket
@@ -75,6 +75,28 @@ def test_sharded_ensemble_gloo_world2(tmp_path, n_traj, write_steps, gather_byte
         z = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
         assert z['traj'].shape == ref.shape
         assert np.array_equal(z['traj'], ref)              # every rank holds the full, ordered ensemble
+
+
+@pytest.mark.parametrize('n_traj,write_steps,gather_bytes', [(19, 2, None), (5, 1, None), (21, 1, 9000)])
+def test_sharded_ensemble_gloo_world8(tmp_path, n_traj, write_steps, gather_bytes):
+    """The rank count of BASELINE configs[4] (8 ranks, here on gloo with the oracle as the per-rank engine): ragged shards (19
+    members: 3, 3, 3, 2, ...), EMPTY shards (5 members over 8 ranks: ranks 5-7 integrate nothing and still take part in the
+    gather), and the record-chunked gather (`gather_to_host` under a byte budget smaller than one rank's block)."""
+    import torch.multiprocessing as mp
+    from oracle.oracle import OracleModel
+    from qgs_amd.parallel import shard_bounds
+    world = 8
+    counts = [b - a for a, b in shard_bounds(n_traj, world)]
+    assert sum(counts) == n_traj and (n_traj >= world or counts.count(0) == world - n_traj)
+    mp.spawn(_worker, args=(world, _free_port(), n_traj, write_steps, str(tmp_path), gather_bytes), nprocs=world, join=True)
+    g = load_golden('a36')
+    ic = np.random.RandomState(0).rand(n_traj, g.ndim) * 0.01
+    from qgs_amd.integrators.integrate import time_grid
+    ref = OracleModel(g.ndim, g['coo'], g['val']).integrate_runge_kutta_jit(time_grid(0., 1., 0.1), ic, 1, write_steps,
+                                                                            RK4['b'], RK4['c'], RK4['a'])
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'r%d.npz' % r))
+        assert z['traj'].shape == ref.shape and np.array_equal(z['traj'], ref)      # every rank: the full, ordered ensemble
 
 
 def _root_worker(rank, world, port, out_dir):

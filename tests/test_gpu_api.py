@@ -358,3 +358,27 @@ def test_initialize_vs_the_reference_classes():
     big.initialize(1.0, 0.1, number_of_trajectories=20000)
     assert big.get_ic().shape == (20000, g.ndim) and np.isfinite(big.get_ic()).all()
     f.operands.release()
+
+
+def test_host_transfers_go_through_the_library():
+    """`_lib.to_device` / `_lib.to_host` (qgs_memcpy_h2d / qgs_memcpy_d2h): pageable NumPy memory reaches the GPU through the
+    library's page-locked bounce blocks (qgs_amd/csrc/host_bridge.cpp), never as an operand of the runtime's own copies.  Round
+    trips of sizes around the block boundaries (8 MiB blocks), other dtypes, non-contiguous sources, an empty array."""
+    import torch
+    from qgs_amd import _lib
+    dev = torch.device('cuda', 0)
+    rng = np.random.RandomState(12)
+    for n in (0, 1, 7, (8 << 20) // 8 - 1, (8 << 20) // 8, (8 << 20) // 8 + 1, (24 << 20) // 8 + 5, 5000017):
+        a = rng.rand(n)
+        t = _lib.to_device(a, dev)
+        assert t.device.type == 'cuda' and tuple(t.shape) == a.shape and t.dtype == torch.float64
+        assert np.array_equal(t.cpu().numpy(), a)
+        assert np.array_equal(_lib.to_host(t * 1.0), a)
+    m = rng.rand(300, 17, 5)
+    assert np.array_equal(_lib.to_host(_lib.to_device(m.transpose(2, 0, 1), dev)), m.transpose(2, 0, 1))     # non-contiguous source
+    idx = np.arange(100000, dtype=np.int32)[::-1]
+    assert np.array_equal(_lib.to_host(_lib.to_device(idx, dev)), idx)                                        # another dtype
+    big = _lib.to_host(torch.arange(0, (520 << 20) // 8, dtype=torch.float64, device=dev))                    # >= 512 MB: result pool block
+    assert big[0] == 0. and big[-1] == (520 << 20) // 8 - 1 and np.array_equal(big[::1000003], np.arange(0, len(big), 1000003, dtype=float))
+    # the raw entry points refuse null pointers
+    assert _lib.lib().qgs_memcpy_d2h(0, None, None, 8, None) != 0 and _lib.last_error()

@@ -73,12 +73,12 @@ def test_windowed_run_on_a_device_list(monkeypatch):
     f1.operands.release()
 
 
-def test_record_larger_than_the_default_budget_reaches_the_host():
+def test_record_larger_than_the_default_budget_reaches_the_host(monkeypatch):
     """Config-4 size (16 384 members x 36 vectors), every interval recorded: 179 MB per record, 3.8 GB of records against the
     default 8 GB budget (half of it for the two record windows) -- the record crosses in several windows.  The first members
     agree with a small run of the same members (other kernels at that size: tolerance, not bitwise)."""
     est, f, ndim = _estimator()
-    os.environ.pop('QGS_HIP_RECORD_WINDOW_MB', None)
+    monkeypatch.setenv('QGS_HIP_RECORD_WINDOW_MB', '8192')          # (set by hand: the estimator then keeps to it, see _compute_shard)
     ic = np.random.RandomState(5).rand(16384, ndim) * 0.01
     tt, traj, exps, vecs, windows = _run(est, ic, False, 1, 36, seed=21, t=4.0)
     assert vecs.shape == (16384, ndim, 36, 21) and windows[0][1] >= 2, windows

@@ -1,6 +1,10 @@
 """GPU box: a record larger than the device budget (or than HBM) through the host-pointer API.
 
-    python tools/big_record.py [n_records-1 = steps, default 1000] [members, default 65536]
+    python tools/big_record.py [n_records-1 = steps, default 1000] [members, default 65536] [registered|pageable, default registered]
+
+`registered`: the caller page-locks its block with qgs_host_register and the unpack kernel stores into it (round 3-4 route).
+`pageable`: a plain NumPy block; the records arrive through the bounce ring of host_bridge.cpp (round 5: the library never
+page-locks memory it did not allocate unless asked to).
 
 BASELINE config 2 with write_steps=1 over `steps` RK4 steps: the (members, 36, steps + 1) record goes to a page-locked host
 block window by window while the next window is computed.  10 000 steps at 65 536 members is 189 GB of records -- more than the
@@ -20,6 +24,7 @@ from bench import load_model_tensors, rk4_tableau, grid                      # n
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+mode = sys.argv[3] if len(sys.argv) > 3 else 'registered'
 ndim, coo, val, jcoo, jval, _ = load_model_tensors()
 nbytes = n * ndim * (steps + 1) * 8
 avail = 0
@@ -39,10 +44,14 @@ out = np.empty((n, ndim, steps + 1))
 L = _lib.lib()
 import ctypes                                                                  # noqa: E402
 t1 = time.perf_counter()
-pinned = L.qgs_host_register(out.ctypes.data_as(ctypes.c_void_p), out.nbytes) == 0
+pinned = mode == 'registered' and L.qgs_host_register(out.ctypes.data_as(ctypes.c_void_p), out.nbytes) == 0
 t2 = time.perf_counter()
-print('allocation %.2f s, page-locking %.2f s (%s)' % (t1 - t0, t2 - t1, 'ok' if pinned else _lib.last_error()))
-for rep in range(2):
+if mode == 'registered':
+    print('allocation %.2f s, page-locking %.2f s (%s)' % (t1 - t0, t2 - t1, 'ok' if pinned else _lib.last_error()))
+else:
+    print('allocation %.2f s, pageable block (first run takes the first-touch page faults), host copy threads: %s'
+          % (t1 - t0, os.environ.get('QGS_HIP_HOST_THREADS', 'default')))
+for rep in range(3 if mode == 'pageable' else 2):
     t3 = time.perf_counter()
     rc = L.qgs_rk_integrate(m._h, n, ic, t, len(t), 1, 1, 4, b, c, a, out)
     el = time.perf_counter() - t3

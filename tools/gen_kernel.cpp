@@ -40,6 +40,6 @@ int main(int argc, char **argv)
     std::vector<qgs::Term> J;                       // Jacobian tensor = T + T.swapaxes(1, 2) (qgtensor.py:700-722)
     if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds || k == qgs::Kernel::Tgl)
         for (const qgs::Term &t : T) { J.push_back(t); J.push_back({t.i, t.k, t.j, t.v}); }
-    std::cout << qgs::generate_kernel(ndim, T, J, k, S, opt);
+    std::cout << qgs::generate_kernel(ndim, T, J, k, S, opt).source;
     return 0;
 }
