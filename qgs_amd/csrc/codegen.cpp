@@ -1719,6 +1719,15 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
         return 2 * n_rows * (p.slots + 1) + 30 <= cap;
     };
     QrPlan p;
+    // one wavefront = 4 members x 16 column lanes, every column of a member in that wavefront: no LDS, no barriers (generate_qr_row_kernel)
+    const int row_slots = (n_cols + 15) / 16;
+    const bool row_fits = 2 * n_rows * row_slots + 24 <= 256;          // (36 x 36: 216 + 12 registers)
+    // (by default where at least 70 % of its 16 column lanes x slots hold a column: 36 x 36 runs in 0.163 ms against the tile
+    // design's 0.215, 36 x 10 in 0.039 against 0.034 -- profiles/r05_qr.md)
+    if (row_fits && (members == 4 || (members == 0 && 10 * n_cols >= 7 * 16 * row_slots))) {
+        p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1; p.lookahead = false;
+        return p;
+    }
     const int m_lo = (members == 8 || members == 16) ? members : 16, m_hi = (members == 8 || members == 16) ? members : 8;
     for (int M = m_lo; M >= m_hi; M -= 8)
         for (int P = slots > 0 ? slots : 4; P >= (slots > 0 ? slots : 1); --P)
@@ -1736,8 +1745,260 @@ std::string qr_plan_signature(const QrPlan &p)
     return s.str();
 }
 
+// Batched Householder QR, ROW design (plan.members == 4): lane = (member = lane / 16, column lane cc = lane % 16), and a lane keeps
+// the columns c = 16 s + cc (s < P = ceil(n_cols / 16)) of its member: ONE wavefront holds four whole matrices.  The 16 lanes
+// of a member are one DPP row, so the pivot column never leaves the registers: every product with v_i takes it from the pivot
+// lane with `v_fmac_f64_dpp ... row_newbcast:cc_j` (full-rate on gfx950, profiles/r01_dpp_coefficients.txt), and tau / 1 / (alpha
+// - beta) travel the same way.  No LDS, no barrier, no wait inside the factorisation: a straight line of fp64 VALU instructions.
+// The tile design needs a barrier, an LDS round trip and 64 lanes x 8 bytes of LDS reads per wavefront and row in every one of
+// its 2 (n_cols - 1) steps, and those -- not the arithmetic -- are its time (profiles/r05_qr.md).
+// Four wavefronts (16 consecutive members) form a workgroup, and the matrices enter and leave through an LDS tile of `rc` rows
+// at a time: towards global memory the workgroup is laid out like the tile design (lane = (member of 16, column group)), so every
+// global access is whole 128-byte lines; towards the registers each wavefront reads / writes its own (4 members x 16 columns)
+// view of the tile (row pitch 17 doubles: conflict-free both ways).
+// Per step the slots are processed one after the other, the pivot's own slot last (its registers are the v of the others): one
+// dot chain and one update in flight, which is what keeps the kernel inside 256 registers with 216 of them holding the matrices.
+// Arithmetic: statement for statement that of the tile design (same sums in the same order, fused the same way).
+static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPlan &plan)
+{
+    const int R = n_rows, C = n_cols, K = std::min(R, C), P = plan.slots;
+    if (16 * P < C || P < 1) throw std::runtime_error("batched QR: the row plan does not cover the columns");
+    // Which columns a slot holds.  When n_cols is not a multiple of 16 the short slot takes the FIRST n_cols % 16 columns, not the
+    // last: a column is done with the first phase after its own step and enters the second phase only below its own index, so a
+    // slot of low columns is live for a few steps (36 x 36: columns 0 .. 3 for 3 + 3 steps instead of columns 32 .. 35 for 34 +
+    // 35) -- a quarter fewer dot / update instructions for the same work.
+    const int rem = C % 16;
+    std::vector<int> base(P), width(P);
+    for (int s = 0; s < P; ++s) {
+        if (rem && s == P - 1) { base[s] = 0; width[s] = rem; }
+        else { base[s] = rem + 16 * s; width[s] = 16; }
+    }
+    auto slot_of = [&](int c) { return c < rem ? P - 1 : (c - rem) / 16; };
+    auto lane_of = [&](int c) { return c < rem ? c : (c - rem) % 16; };
+    std::ostringstream o;
+    const std::string I1 = "    ", I2 = "        ", I3 = "            ";
+    auto q = [](int s, int i) { return "q" + std::to_string(s) + "_" + std::to_string(i); };
+    // acc += (lane `cc` of the member's row of `src`) * y
+    auto fmac_b = [&](const std::string &ind, const std::string &acc, const std::string &src, const std::string &y, int cc, bool nop = false) {
+        o << ind << "asm volatile(\"" << (nop ? "s_nop 1\\n\\t" : "") << "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" << cc
+          << " row_mask:0xf bank_mask:0xf\" : \"+v\"(" << acc << ") : \"v\"(" << src << "), \"v\"(" << y << "));\n";
+    };
+    // sd = sum_{i > j} v_i q_i with v_i from lane cc_j: one chain, or plan.chains partial sums over interleaved rows
+    const int NCH = std::max(1, std::min(4, plan.chains));
+    auto dot_b = [&](int s, int sj, int j, int ccj, bool &first) {
+        const int n = R - j - 1, nch = std::max(1, std::min(NCH, n));
+        if (nch == 1) {
+            o << I3 << "f64 sd = 0.0;\n";
+            for (int i = j + 1; i < R; ++i) { fmac_b(I3, "sd", q(sj, i), q(s, i), ccj, first); first = false; }
+            return;
+        }
+        o << I3 << "f64 sd = 0.0";
+        for (int k = 1; k < nch; ++k) o << ", sd" << k << " = 0.0";
+        o << ";\n";
+        for (int i = j + 1; i < R; ++i) {
+            const int k = (i - j - 1) % nch;
+            fmac_b(I3, k ? "sd" + std::to_string(k) : std::string("sd"), q(sj, i), q(s, i), ccj, first);
+            first = false;
+        }
+        if (nch == 2) o << I3 << "sd += sd1;\n";
+        else if (nch == 3) o << I3 << "sd = (sd + sd1) + sd2;\n";
+        else o << I3 << "sd = (sd + sd1) + (sd2 + sd3);\n";
+    };
+    auto live_slots = [&](int j, int sj) {              // slots with a column > j, the pivot's own slot last
+        std::vector<int> v;
+        for (int s = 0; s < P; ++s) if (base[s] + width[s] - 1 > j && s != sj) v.push_back(s);
+        if (base[sj] + width[sj] - 1 > j) v.push_back(sj);
+        return v;
+    };
+    // "this lane's column of slot s is > j": a comparison of the column lane with a constant (empty: always)
+    // (`QGS_CC` re-derives the column lane from threadIdx.x behind an opaque copy every time: compared as a plain `cc`, the 2 x 36
+    // lane masks are loop-invariant for the compiler, which keeps them in SGPR pairs, runs out of SGPRs and spills them into lanes
+    // of VGPRs the matrices need)
+    auto right_of = [&](int s, int j) -> std::string {
+        if (base[s] > j) return "";
+        return "(QGS_CC() > " + std::to_string(j - base[s]) + ")";
+    };
+    // rows per LDS tile: (row, column) pairs of a tile x 17 doubles, within 32 KB
+    const int RC = std::max(1, std::min(R, (32 * 1024) / (C * 17 * 8)));
+    o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
+    o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << ", four members per wavefront,\n"
+      << "// lane = (member, column lane of 16), " << P << " column(s) per lane (" << qr_plan_signature(plan) << "); in and out through an LDS tile of "
+      << RC << " rows\n";
+    o << "#ifdef QGS_QR_PROFILE\n#define QGS_QR_MARK(k) if (threadIdx.x == 0) prof[(i64)blockIdx.x * 160 + (k)] = (k) < 8 ? wall_clock64() : __builtin_amdgcn_s_memtime();\n"
+      << "#define QGS_QR_PROF_ARG , unsigned long long* prof\n#else\n#define QGS_QR_MARK(k)\n#define QGS_QR_PROF_ARG\n#endif\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(256, 2) qgs_spec_qr_" << R << "x" << C
+      << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld QGS_QR_PROF_ARG)\n{\n";
+    o << "    __shared__ f64 tile[" << RC * C << "][17];          // [(row in the tile) * " << C << " + column][member of the workgroup's 16]\n";
+    o << "    QGS_CLOCK_MARK(0)\n";
+    o << "#define QGS_TID() ({ unsigned t_ = threadIdx.x; asm volatile(\"\" : \"+v\"(t_)); t_; })\n"
+      << "#define QGS_CC() ((int)(QGS_TID() & 15u))\n";
+    o << "    const i64 m0 = (i64)blockIdx.x * 16;\n    QGS_QR_MARK(0)\n";
+    for (int s = 0; s < P; ++s) {
+        o << "    f64";
+        for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << q(s, i);
+        o << ";\n";
+    }
+    const std::string idx = std::string("        // column lane, member of the workgroup's 16 whose columns this lane keeps; global side: lane = (member tm of 16,\n")
+                            + "        // pair group tg of 16): pass k moves the (row, column) pairs 16 k + tg of a tile\n"
+                            + "        const int cc = QGS_CC(), ml = QGS_TID() >> 4, tm = cc, tg = ml;\n"
+                            + "        const bool tlive = m0 + tm < n_traj;\n"
+                            + "        // (the leading dimension behind an opaque copy per tile: the 84 row addresses are otherwise common to the way\n"
+                            + "        // in and the way out, and the compiler keeps them in registers across the whole factorisation)\n"
+                            + "        i64 ldw = ld; asm volatile(\"\" : \"+s\"(ldw));\n"
+                            + "        f64* const gp = a + (i64)tg * ldw + m0 + (tlive ? tm : 0);\n";
+    // way in: the global loads of tile k + 1 are issued before tile k goes through LDS (their values wait in registers that the
+    // matrices do not need yet), so that the memory system always has a tile's worth of lines in flight per workgroup
+    {
+        o << "    {   // the matrices come in\n" << idx;
+        auto issue = [&](int r0) {
+            const int rows = std::min(RC, R - r0), pairs = rows * C, passes = (pairs + 15) / 16;
+            for (int k = 0; k < passes; ++k) {
+                const bool guard = 16 * k + 15 >= pairs;
+                o << I2 << "const f64 g" << r0 << "_" << k << " = (tlive" << (guard ? " && tg < " + std::to_string(pairs - 16 * k) : "") << ") ? gp[(i64)"
+                  << (r0 * C + 16 * k) << " * ldw] : 0.0;\n";
+            }
+        };
+        issue(0);
+        for (int r0 = 0; r0 < R; r0 += RC) {
+            const int rows = std::min(RC, R - r0), pairs = rows * C, passes = (pairs + 15) / 16;
+            if (r0 + RC < R) issue(r0 + RC);
+            o << I2 << "// rows " << r0 << " .. " << r0 + rows - 1 << "\n";
+            for (int k = 0; k < passes; ++k) {
+                const bool guard = 16 * k + 15 >= pairs;
+                o << I2 << (guard ? "if (tg < " + std::to_string(pairs - 16 * k) + ") " : "") << "tile[" << 16 * k << " + tg][tm] = g" << r0 << "_" << k << ";\n";
+            }
+            o << I2 << "__syncthreads();\n";
+            for (int s = 0; s < P; ++s) {
+                const bool guard = width[s] < 16;
+                for (int i = 0; i < rows; ++i) {
+                    o << I2 << q(s, r0 + i) << " = ";
+                    if (guard) o << "(cc < " << width[s] << ") ? tile[" << i * C + base[s] << " + cc][ml] : 0.0;\n";
+                    else o << "tile[" << i * C + base[s] << " + cc][ml];\n";
+                }
+            }
+            o << I2 << "__syncthreads();\n";
+        }
+        o << "    }\n";
+    }
+    o << "    QGS_QR_MARK(1)\n";
+    int step = 0;
+    for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
+        const int sj = slot_of(j), ccj = lane_of(j);
+        o << "    {   // column " << j << "\n";
+        if (j + 1 < C) o << I2 << "QGS_QR_MARK(" << 8 + step++ << ")\n";
+        // norm / beta / tau in every lane for its own column of slot sj: the values of lane cc_j are the ones that get used
+        o << I2 << "f64 xn2 = 0.0;\n";
+        for (int i = j + 1; i < R; ++i) o << I2 << "xn2 = __builtin_fma(" << q(sj, i) << ", " << q(sj, i) << ", xn2);\n";
+        // beta = -sign(alpha) ||x||, tau = (beta - alpha) / beta = 1 + |alpha| / ||x||, scale = 1 / (alpha - beta), from ONE reciprocal
+        // square root and ONE reciprocal, each a hardware estimate refined by two Newton steps (the IEEE-exact sqrt and two
+        // divisions of the tile design cost 40 instructions and two dozen temporary registers per pivot: here the registers
+        // are the bound)
+        o << I2 << "f64 t = 0.0, scale = 0.0;\n"
+          << I2 << "{\n"
+          << I2 << "    const f64 alpha = " << q(sj, j) << ";\n"
+          << I2 << "    f64 beta = alpha;\n"
+          << I2 << "    if (xn2 != 0.0) {\n"
+          << I2 << "        const f64 n2 = __builtin_fma(alpha, alpha, xn2);\n"
+          << I2 << "        f64 r = __builtin_amdgcn_rsq(n2);\n"
+          << I2 << "        r = __builtin_fma(0.5 * r, __builtin_fma(-n2 * r, r, 1.0), r);\n"
+          << I2 << "        r = __builtin_fma(0.5 * r, __builtin_fma(-n2 * r, r, 1.0), r);\n"
+          << I2 << "        f64 nrm = n2 * r;\n"
+          << I2 << "        nrm = __builtin_fma(0.5 * r, __builtin_fma(-nrm, nrm, n2), nrm);\n"
+          << I2 << "        beta = -__builtin_copysign(nrm, alpha);\n"
+          << I2 << "        t = __builtin_fma(__builtin_fabs(alpha), r, 1.0);\n"
+          << I2 << "        const f64 d = alpha - beta;\n"
+          << I2 << "        f64 s = __builtin_amdgcn_rcp(d);\n"
+          << I2 << "        s = __builtin_fma(s, __builtin_fma(-d, s, 1.0), s);\n"
+          << I2 << "        scale = __builtin_fma(s, __builtin_fma(-d, s, 1.0), s);\n"
+          << I2 << "    }\n"
+          // diag(R) leaves at once (uniform row pointer + the member's byte offset); the pivot lanes' diagonal register is free from
+          // here on (q_j enters this step only for columns > j, the upper triangle of R is not an output) and keeps tau_j
+          << I2 << "    if (QGS_CC() == " << ccj << ") {\n"
+          << I2 << "        if (m0 + (QGS_TID() >> 4) < n_traj) qgs_store_row(rdiag + (i64)" << j << " * ld + m0, (QGS_TID() >> 4) * 8u, beta);\n"
+          << I2 << "        " << q(sj, j) << " = t;\n"
+          << I2 << "    }\n"
+          << I2 << "}\n";
+        bool first = true;
+        for (int s : live_slots(j, sj)) {
+            const std::string ro = right_of(s, j);
+            o << I2 << "{   // slot " << s << "\n";
+            dot_b(s, sj, j, ccj, first);
+            o << I3 << "f64 tm = " << q(s, j) << ", wv = 0.0, nw = 0.0;\n";
+            fmac_b(I3, "tm", "scale", "sd", ccj);                                    // q_j + scale (v.q)
+            fmac_b(I3, "wv", "t", "tm", ccj);                                        // t (...)
+            if (!ro.empty()) o << I3 << "wv = " << ro << " ? wv : 0.0;\n";
+            o << I3 << q(s, j) << " -= wv;\n";
+            fmac_b(I3, "nw", "scale", "wv", ccj);                                    // w scale
+            o << I3 << "nw = -nw;\n";
+            for (int i = j + 1; i < R; ++i) fmac_b(I3, q(s, i), q(sj, i), "nw", ccj);    // q -= (w scale) v
+            o << I2 << "}\n";
+        }
+        if (j + 1 < R) {
+            o << I2 << "if (QGS_CC() == " << ccj << ") {            // the pivot lanes keep the reflector u = v * scale\n";
+            for (int i = j + 1; i < R; ++i) o << I2 << "    " << q(sj, i) << " *= scale;\n";
+            o << I2 << "}\n";
+        }
+        // Row j is final now.  In a slot whose columns are all right of j it holds entries of R's upper triangle, which nobody reads
+        // again (diag(R) has left); the second phase wants zeros there (column c of Q is (0 .. 0, 1 - t, -t u) before the reflectors
+        // left of c act on it, and they act on rows >= their own index).  Written as zeros HERE, unconditionally, the registers are
+        // dead for the compiler from now until the second phase comes back to row j: that slack, growing by one row per step, is
+        // what lets the kernel hold 3 x 36 doubles per lane within 256 registers without spilling.
+        for (int s = 0; s < P; ++s)
+            if (base[s] > j) o << I2 << q(s, j) << " = 0.0;\n";
+        o << "    }\n";
+    }
+    o << "    QGS_QR_MARK(" << 8 + step << ")\n    QGS_QR_MARK(2)\n";
+    for (int j = K - 1; j >= 0; --j) {              // ---- dorg2r: tau_j sits in the pivot lanes' q_j
+        const int sj = slot_of(j), ccj = lane_of(j);
+        o << "    {   // Q: reflector " << j << "\n";
+        const std::vector<int> slots = live_slots(j, sj);
+        if (!slots.empty()) o << I2 << "QGS_QR_MARK(" << 8 + ++step << ")\n";
+        bool first = true;
+        for (int s : slots) {
+            const std::string ro = right_of(s, j);
+            o << I2 << "{   // slot " << s << "\n";
+            dot_b(s, sj, j, ccj, first);
+            o << I3 << "const f64 tm = " << q(s, j) << " + sd;\n" << I3 << "f64 wv = 0.0;\n";
+            fmac_b(I3, "wv", q(sj, j), "tm", ccj);                                   // t (q_j + u.q)
+            if (!ro.empty()) o << I3 << "wv = " << ro << " ? wv : 0.0;\n";
+            o << I3 << q(s, j) << " -= wv;\n" << I3 << "const f64 nw = -wv;\n";
+            for (int i = j + 1; i < R; ++i) fmac_b(I3, q(s, i), q(sj, i), "nw", ccj);
+            o << I2 << "}\n";
+        }
+        o << I2 << "if (QGS_CC() == " << ccj << ") {            // column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u)\n"
+          << I2 << "    const f64 tj = " << q(sj, j) << ";\n";
+        for (int i = base[sj]; i < j; ++i) o << I2 << "    " << q(sj, i) << " = 0.0;\n";      // (rows above the slot's first column: zeroed in the first phase)
+        o << I2 << "    " << q(sj, j) << " = 1.0 - tj;\n";
+        for (int i = j + 1; i < R; ++i) o << I2 << "    " << q(sj, i) << " *= -tj;\n";
+        o << I2 << "}\n    }\n";
+    }
+    o << "    QGS_QR_MARK(" << 8 + step + 1 << ")\n    QGS_QR_MARK(3)\n";
+    for (int r0 = 0; r0 < R; r0 += RC) {
+        const int rows = std::min(RC, R - r0), pairs = rows * C, passes = (pairs + 15) / 16;
+        o << "    {   // rows " << r0 << " .. " << r0 + rows - 1 << " out\n" << idx;
+        for (int s = 0; s < P; ++s) {
+            const bool guard = width[s] < 16;
+            for (int i = 0; i < rows; ++i)
+                o << I2 << (guard ? "if (cc < " + std::to_string(width[s]) + ") " : "") << "tile[" << i * C + base[s] << " + cc][ml] = " << q(s, r0 + i) << ";\n";
+        }
+        o << I2 << "__syncthreads();\n";
+        for (int k = 0; k < passes; ++k) {
+            const bool guard = 16 * k + 15 >= pairs;
+            o << I2 << "if (tlive" << (guard ? " && tg < " + std::to_string(pairs - 16 * k) : "") << ") gp[(i64)" << (r0 * C + 16 * k)
+              << " * ldw] = tile[" << 16 * k << " + tg][tm];\n";
+        }
+        o << I2 << "__syncthreads();\n    }\n";
+    }
+    o << "    QGS_QR_MARK(4)\n    QGS_QR_MARK(5)\n";
+    o << "    QGS_CLOCK_MARK(2)\n}\n";
+    GeneratedKernel g;
+    g.source = o.str();
+    return g;
+}
+
 GeneratedKernel generate_qr_kernel(int n_rows, int n_cols, const QrPlan &plan)
 {
+    if (plan.members == 4) return generate_qr_row_kernel(n_rows, n_cols, plan);
     const int R = n_rows, C = n_cols, K = std::min(R, C), P = plan.slots, W = plan.waves, NCH = std::max(1, plan.chains);
     const int M = plan.members, L = 64 / std::max(1, M);
     if ((M != 8 && M != 16) || P < 1 || W < 1 || W > 16 || L * P * W < C) throw std::runtime_error("batched QR: plan does not cover the columns");

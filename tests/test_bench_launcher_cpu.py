@@ -45,6 +45,10 @@ def test_cache_key_separates_compilers(tmp_path):
 def test_launcher_starts_one_child_per_rank_and_reports_their_failure():
     """`launch_ranks` with the GPU count faked to 2 (none here): both children start as ranks (RANK / WORLD_SIZE set, so they do
     not try to launch again), find no GPU, exit 1 -- and the parent says which ranks failed instead of hanging or exiting 2."""
+    import pytest
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip('the premise of this test is a host without GPUs (the build container)')
     code = ("import sys\n"
             "sys.path.insert(0, %r)\n"
             "import bench\n"
