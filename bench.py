@@ -151,7 +151,11 @@ def launch_ranks(n, argv):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        # dmabuf IPC: the host driver of this pool supports no other kind, and RCCL's intra-node transport (and any sharing of
+        # device tensors across processes) fails with `hipIpcGetMemHandle: invalid argument` under the legacy mode.  The pool
+        # exports the variable already; it is set here only when the operator's environment does not say otherwise.
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that dies would leave the others waiting in a collective: watch all of them, stop the rest (exactly the
@@ -318,7 +322,7 @@ def event_ms(torch, fn, n, warm=1):
 
 LDS228_FLOOR_MS = 30.0         # qgs_spec_rklds16, 65 536 members x 100 steps: 44 996 fp64 instructions per workgroup-stage x 4 cycles / 4 SIMDs x 1 600 workgroup-stages per CU / 2.4 GHz (profiles/r05_lds228.md)
 
-TRAFFIC_SOURCE = 'profiles/hbm_traffic.json (rocprofv3 PMC passes of round 4, tools/r04_profiles.sh, committed; a constant attached by kernel name, not measured in this run)'
+TRAFFIC_SOURCE = 'profiles/hbm_traffic.json (rocprofv3 PMC passes of round 5, tools/r05_profiles.sh, one row per kernel / grid / duration class in profiles/r05_pmc_by_class.csv; a committed constant attached by kernel name, not measured in this run)'
 
 
 def measured_traffic(kernel):

@@ -962,7 +962,9 @@ struct qgs_model {
     Buffer d_time, d_tab;
     std::vector<double> h_time, h_tab;
     UploadRing uploads;
-    hipStream_t tab_stream = nullptr;
+    hipStream_t tab_stream = nullptr, time_stream = nullptr, tab_reader = nullptr;   // streams of the tables' last uploads / last readers
+    int time_slot = -1, tab_slot = -1;                  // ring slots (events) of those uploads
+    bool tab_reader_valid = false;
     // scratch
     Buffer work, stages, b_in_rows, b_in_modes, b_rec_modes, b_rec_rows, b_tg_rows, b_tg_modes, b_fm_modes, b_fm_rows, b_state2, b_tg2, b_ywork, b_vwork, b_mom_part, b_mom_out, b_unit, b_carry, b_win[2], b_fwin[2], b_drain;
     // host-layout pipeline: compute stream, copy stream, "window k computed" / "window k drained" events (created on first use)
@@ -1299,21 +1301,32 @@ int stage_time_tab(qgs_model *m, const double *time, int64_t n_time, int directi
     tab.insert(tab.end(), b, b + s);
     tab.insert(tab.end(), a, a + (size_t)s * s);
     const bool new_time = dt != m->h_time, new_tab = tab != m->h_tab;
+    // Two streams may use the cached tables (the compute stream of the host-layout calls, a caller's stream of the *_device calls).
+    // A table is overwritten only after the kernels of the stream that read it last have finished (they may still be running on
+    // another stream than this call's), and a stream that did not stage a table itself waits for that table's upload: each table
+    // keeps the ring slot (event) and the stream of its last upload.  (An event of a ring slot that has been reused since is
+    // harmless to wait for: the ring reuses a slot only after the host has seen its previous upload complete.)
+    if ((new_time || new_tab) && m->tab_reader_valid && m->tab_reader != st) HIPCHK(hipStreamSynchronize(m->tab_reader));
     if (new_time) {
         if (m->d_time.ensure(sizeof(double) * (size_t)n_time)) return -1;
         if (m->uploads.stage(dt.data(), sizeof(double) * (size_t)n_time, m->d_time.p, st)) return -1;
         m->h_time.swap(dt);
+        m->time_slot = m->uploads.last;
+        m->time_stream = st;
+    } else if (m->time_slot >= 0 && st != m->time_stream) {
+        HIPCHK(hipStreamWaitEvent(st, m->uploads.ev[m->time_slot], 0));
     }
     if (new_tab) {
         if (m->d_tab.ensure(sizeof(double) * tab.size())) return -1;
         if (m->uploads.stage(tab.data(), sizeof(double) * tab.size(), m->d_tab.p, st)) return -1;
         m->h_tab.swap(tab);
+        m->tab_slot = m->uploads.last;
+        m->tab_stream = st;
+    } else if (m->tab_slot >= 0 && st != m->tab_stream) {
+        HIPCHK(hipStreamWaitEvent(st, m->uploads.ev[m->tab_slot], 0));
     }
-    if (new_time || new_tab) m->tab_stream = st;
-    else if (m->uploads.last >= 0 && st != m->tab_stream) {
-        // cached tables, another stream than the one that staged them: its kernels must not start before that copy has landed
-        HIPCHK(hipStreamWaitEvent(st, m->uploads.ev[m->uploads.last], 0));
-    }
+    m->tab_reader = st;                     // the kernels of this call read both tables on st
+    m->tab_reader_valid = true;
     *d_time = m->d_time.f64();
     *d_tab_spec = m->d_tab.f64();
     *d_tab_full = m->d_tab.f64() + (2 * s - 1);

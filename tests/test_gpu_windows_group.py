@@ -300,8 +300,9 @@ def test_group_equals_its_shards_bitwise():
 
 
 def test_group_into_a_pageable_block_of_a_c_caller(monkeypatch):
-    """A plain C caller hands `qgs_group_rk_integrate` an ordinary (pageable) result block: it is page-locked once for the call,
-    as a whole (the shards' slices share boundary pages), and every shard stores its slice itself -- also window by window."""
+    """A plain C caller hands `qgs_group_rk_integrate` an ordinary (pageable) result block: the library never page-locks it (round 5);
+    every shard's windows reach its slice through the device's drain thread and the page-locked bounce ring (csrc/host_bridge.cpp),
+    three shards on one device queueing there at once -- also window by window."""
     from qgs_amd import _lib
     g, m = _model('m36')
     grp = _lib.HipModelGroup(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'], devices=[0, 0, 0])
@@ -638,4 +639,67 @@ def test_record_windows_into_pageable_blocks_that_end_with_their_mapping():
             want = win[:, :, :n].cpu().numpy().transpose(2, 1, 0)
             assert np.array_equal(host[:, :, first:first + w], want)
         assert np.all(host[:, :, 0] == -1.0)
+    m.close()
+
+
+def test_enqueued_windows_drain_while_the_caller_goes_on():
+    """`qgs_unpack_window_enqueue` + `qgs_drain_wait` (what the Lyapunov estimator's record windows use): several windows into three
+    pageable destination arrays are handed over back to back -- each destination has its own staging block, so the host is not held
+    for the transfer of the large one -- then one wait; every record is where the blocking `qgs_unpack_window` puts it.  Also a
+    window whose rows are longer than a bounce block (one member, many records), and the bridge's transfer counters."""
+    import torch
+    from qgs_amd import _lib
+    L = _lib.lib()
+    g, m = _model('m36')
+    nd = g.ndim
+    rng = np.random.RandomState(7)
+    n, nrec, w = 3000, 40, 8
+    ld = (n + 63) // 64 * 64
+    inner = (nd * 5, nd, 5)
+    hosts = [np.full((n, q, nrec), -2.0) for q in inner]
+    wins = []
+    for first in range(0, nrec, w):
+        ws = [torch.from_numpy(rng.rand(w, q, ld)).cuda() for q in inner]
+        wins.append((first, ws))
+        for t, q, host in zip(ws, inner, hosts):
+            m.unpack_window_enqueue(n, ld, q, w, nrec, first, t.data_ptr(), host.ctypes.data)
+    m.drain_wait()
+    for first, ws in wins:
+        for t, q, host in zip(ws, inner, hosts):
+            assert np.array_equal(host[:, :, first:first + w], t[:, :, :n].cpu().numpy().transpose(2, 1, 0))
+    # rows longer than a 16 MiB bounce block: 1 member x 36 variables x 2.2 M records in one window
+    n1, nrec1 = 1, 2200000
+    win = torch.from_numpy(rng.rand(nrec1, nd, 64)).cuda()
+    host1 = np.zeros((n1, nd, nrec1))
+    m.unpack_window_enqueue(n1, 64, nd, nrec1, nrec1, 0, win.data_ptr(), host1.ctypes.data)
+    m.drain_wait()
+    assert np.array_equal(host1[0], win[:, :, 0].cpu().numpy().T)
+    m.close()
+
+
+def test_kernel_clock_probe():
+    """`qgs_kernel_clock`: the generated kernels note the shader-clock and the 100 MHz counters in workgroup 0; the last launch's
+    clock lies in the range this GPU can run at and its interval is about the launch's duration.  Generic kernels carry no probe."""
+    import torch
+    from qgs_amd import _lib
+    g, m = _model('m36')
+    n, steps = 65536, 200
+    ic = torch.from_numpy(np.random.RandomState(2).rand(g.ndim, n) * 0.01).cuda()
+    rec = torch.empty((1, g.ndim, n), dtype=torch.float64, device='cuda')
+    t = _grid(steps)
+    m.set_kernel(2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, B, C, A, rec.data_ptr())
+    e0.record()
+    m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, B, C, A, rec.data_ptr())
+    e1.record()
+    e1.synchronize()
+    ghz, ms = m.kernel_clock()
+    assert m.last_kernel_info()['name'] == 'qgs_spec_rk_s4'
+    assert 0.8 < ghz < 2.6, ghz
+    assert 0.5 * e0.elapsed_time(e1) < ms <= 1.05 * e0.elapsed_time(e1), (ms, e0.elapsed_time(e1))
+    m.set_kernel(1)
+    m.rk_integrate_device(n, n, ic.data_ptr(), t[:3], 1, 0, B, C, A, rec.data_ptr())
+    torch.cuda.synchronize()
+    assert m.kernel_clock() is None
     m.close()
