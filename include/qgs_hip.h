@@ -309,7 +309,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
                       int64_t jnnz, const int32_t *jcoo, const double *jval,
                       int n_stage_counts, const int *stage_counts, const char *arch);
 
-/* Same for the shape-specialised batched QR kernel of qgs_batched_qr_device (n_cols <= n_rows <= 64). */
+/* Same for the shape-specialised batched QR kernel of qgs_batched_qr_device (n_cols <= n_rows <= 300, n_cols <= 64). */
 int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch);
 
 /* Generated HIP source of the specialised kernels of this model (debugging / inspection); value-free: the coefficient

@@ -1705,6 +1705,17 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 // not emitted.
 QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
 {
+    if (n_rows > 64 || members == 2) {          // (members == 2: a developer build's way to ask for the grid design at any shape)
+        // grid design: W wavefronts per member (4 W row groups), as few as keep the local rows x slots within ~110 registers
+        QrPlan p;
+        p.slots = (n_cols + 15) / 16;
+        p.waves = 1;
+        while (p.waves < 16 && 2 * ((n_rows + 4 * p.waves - 1) / (4 * p.waves)) * p.slots > 110) p.waves *= 2;
+        p.row_groups = 4 * p.waves;
+        p.members = std::max(1, std::min(4, 16 / p.waves));
+        p.reload = false; p.chains = 1; p.lookahead = false;
+        return p;
+    }
     // registers a lane needs: 2 R per slot for the columns + 2 R for the reflector + temporaries; what it may use: the 512 of a
     // SIMD lane shared by the wavefronts of one workgroup on that SIMD, at most 256
     auto make = [&](int M, int P, QrPlan &p) {
@@ -1742,7 +1753,237 @@ std::string qr_plan_signature(const QrPlan &p)
 {
     std::ostringstream s;
     s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0) << "a" << (p.lookahead ? 1 : 0);
+    if (p.row_groups > 0) s << "g" << p.row_groups;
     return s.str();
+}
+
+// Batched Householder QR, GRID design (plan.row_groups > 0): matrices too tall for the registers of one wavefront (rows > 64 ... 300,
+// e.g. the 228 x n_vec bases of MAOOAM 6x6).  A member's matrix is spread over W wavefronts: lane = (row group g = 4 (wavefront % W) +
+// lane / 16, column lane cc = lane % 16); group g keeps the rows g, g + NG, g + 2 NG, ... (NG = 4 W groups, dealt cyclically so that
+// every group stays busy as the factorisation moves down) of the columns base_s + cc of every slot s.  Inside a group the pivot
+// column reaches the other columns' lanes as in the row design (`v_fmac_f64_dpp row_newbcast`); what crosses groups is one number
+// per column and step -- the dot product v.a_c -- summed across the four groups of a wavefront with two `__shfl_xor` and across the
+// W wavefronts through a small LDS block, together with row j itself and the pivot's norm: one barrier per step, two LDS buffers.
+// beta, tau and 1 / (alpha - beta) are formed by every lane from the same numbers in the same order, so they need no broadcast.
+// (The round-1 kernel it replaces kept the whole matrix in LDS with ONE wavefront per member -- one wavefront per CU at 228 rows:
+// 17 ms for 4 096 matrices of 228 x 40.)
+// MW members share a workgroup (W MW <= 16 wavefronts); the matrices enter and leave through an LDS tile of NG rows at a time,
+// towards global memory in runs of MW members per (row, column).
+static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrPlan &plan)
+{
+    const int R = n_rows, C = n_cols, K = std::min(R, C), P = plan.slots, W = plan.waves, MW = plan.members, NG = plan.row_groups;
+    if (NG != 4 * W || 16 * P < C || P < 1 || W < 1 || MW < 1 || W * MW > 16) throw std::runtime_error("batched QR: bad grid plan");
+    const int L = (R + NG - 1) / NG;                  // local rows per group
+    const int rem = C % 16;
+    std::vector<int> base(P), width(P);
+    for (int s = 0; s < P; ++s) {
+        if (rem && s == P - 1) { base[s] = 0; width[s] = rem; }
+        else { base[s] = rem + 16 * s; width[s] = 16; }
+    }
+    auto slot_of = [&](int c) { return c < rem ? P - 1 : (c - rem) / 16; };
+    auto lane_of = [&](int c) { return c < rem ? c : (c - rem) % 16; };
+    std::ostringstream o;
+    const std::string I2 = "        ", I3 = "            ";
+    auto q = [](int s, int l) { return "q" + std::to_string(s) + "_" + std::to_string(l); };
+    bool first = true;
+    auto fmac_b = [&](const std::string &ind, const std::string &acc, const std::string &src, const std::string &y, int cc) {
+        o << ind << "asm volatile(\"" << (first ? "s_nop 1\\n\\t" : "") << "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" << cc
+          << " row_mask:0xf bank_mask:0xf\" : \"+v\"(" << acc << ") : \"v\"(" << src << "), \"v\"(" << y << "));\n";
+        first = false;
+    };
+    auto live_slots = [&](int j, int sj) {
+        std::vector<int> v;
+        for (int s = 0; s < P; ++s) if (base[s] + width[s] - 1 > j && s != sj) v.push_back(s);
+        if (base[sj] + width[sj] - 1 > j) v.push_back(sj);
+        return v;
+    };
+    auto right_of = [&](int s, int j) -> std::string {
+        if (base[s] > j) return "";
+        return "(cc > " + std::to_string(j - base[s]) + ")";
+    };
+    const int TP = MW + 1;                            // member pitch of the tile (odd: conflict-free for MW = 4)
+    o << "#ifndef QGS_SPEC_PRELUDE\n#define QGS_SPEC_PRELUDE\n" << PRELUDE << RECORD_HELPERS << "#endif\n";
+    o << "// A[row][col][member] -> Q in place, diag(R) -> rdiag[col][member]; " << R << " x " << C << ": " << W << " wavefronts per member, " << NG
+      << " row groups of " << L << " rows,\n// " << P << " column(s) per lane, " << MW << " member(s) per workgroup (" << qr_plan_signature(plan) << ")\n";
+    o << "__device__ __forceinline__ f64 qgs_sum4(f64 x)      // sum over the four row groups of a wavefront, the same bits in all of them\n{\n"
+      << "    x += __shfl_xor(x, 16);\n    x += __shfl_xor(x, 32);\n    return x;\n}\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W * MW << ") qgs_spec_qr_" << R << "x" << C
+      << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld)\n{\n";
+    o << "    __shared__ f64 red[2][" << MW << "][" << W << "][" << P + 1 << "][16];   // per wavefront: partial v.a_c per slot and column lane; [P][0]: partial |x|^2\n"
+      << "    __shared__ f64 piv[2][" << MW << "][" << P << "][16];            // row j of every slot (the pivot lane's entry: alpha, or tau in phase two)\n"
+      << "    __shared__ f64 tile[" << NG * C << "][" << TP << "];\n";
+    o << "    QGS_CLOCK_MARK(0)\n";
+    o << "    const int tid = threadIdx.x, cc = tid & 15;\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);\n"
+      << "    const int mw = wave / " << W << ", ww = wave % " << W << ";           // member of the workgroup, wavefront of the member\n"
+      << "    const int g = 4 * ww + ((tid >> 4) & 3);                         // row group: rows g, g + " << NG << ", ...\n"
+      << "    const i64 m0 = (i64)blockIdx.x * " << MW << ";\n"
+      << "    const bool live = m0 + mw < n_traj;\n"
+      << "    // global side: lane = (member tm, pair tp): pass k moves the (row, column) pairs " << (64 * W) << " k + tp of a tile\n"
+      << "    const int tm = tid % " << MW << ", tp = tid / " << MW << ";\n"
+      << "    const bool tlive = m0 + tm < n_traj;\n";
+    for (int s = 0; s < P; ++s) {
+        o << "    f64";
+        for (int l = 0; l < L; ++l) o << (l ? ", " : " ") << q(s, l);
+        o << ";\n";
+    }
+    const int PASS = 64 * W;                          // pairs per pass (threads / MW)
+    for (int l = 0; l < L; ++l) {                     // ---- in: local row l = the NG rows l NG .. of every group
+        const int rows = std::min(NG, R - l * NG), pairs = rows * C, passes = (pairs + PASS - 1) / PASS;
+        o << "    {   // rows " << l * NG << " .. " << l * NG + rows - 1 << " in\n"
+          << I2 << "i64 ldw = ld; asm volatile(\"\" : \"+s\"(ldw));\n"
+          << I2 << "const f64* const gp = a + (i64)tp * ldw + m0 + (tlive ? tm : 0);\n";
+        for (int k = 0; k < passes; ++k) {
+            const bool guard = PASS * k + PASS - 1 >= pairs;
+            o << I2 << (guard ? "if (tp < " + std::to_string(pairs - PASS * k) + ") " : "") << "tile[" << PASS * k << " + tp][tm] = tlive ? gp[(i64)"
+              << (l * NG * C + PASS * k) << " * ldw] : 0.0;\n";
+        }
+        o << I2 << "__syncthreads();\n";
+        for (int s = 0; s < P; ++s) {
+            o << I2 << q(s, l) << " = (" << (rows < NG ? "g < " + std::to_string(rows) + " && " : std::string())
+              << (width[s] < 16 ? "cc < " + std::to_string(width[s]) : std::string("true")) << ") ? tile[g * " << C << " + " << base[s] << " + cc][mw] : 0.0;\n";
+        }
+        o << I2 << "__syncthreads();\n    }\n";
+    }
+    int step = 0;
+    // the partial sums of step (j, slots): own rows below j of the pivot column times own rows of slot s
+    auto partial_dots = [&](int j, int sj, int ccj, const std::vector<int> &slots, bool with_norm) {
+        const int l0 = j / NG, gj = j % NG;
+        o << I2 << "const bool below = g > " << gj << ";              // this group's row " << l0 << " is below row " << j << "\n";
+        if (with_norm) {
+            o << I2 << "f64 xn2 = 0.0;\n" << I2 << "{\n" << I3 << "const f64 e = below ? " << q(sj, l0) << " : 0.0;\n" << I3 << "xn2 = e * e;\n" << I2 << "}\n";
+            for (int l = l0 + 1; l < L; ++l) o << I2 << "xn2 = __builtin_fma(" << q(sj, l) << ", " << q(sj, l) << ", xn2);\n";
+        }
+        for (int s : slots) {
+            o << I2 << "f64 sd" << s << " = 0.0;\n";
+            // (row l0 counts for the groups below the pivot row only)
+            o << I2 << "{\n" << I3 << "f64 e = 0.0;\n";
+            fmac_b(I3, "e", q(sj, l0), q(s, l0), ccj);
+            o << I3 << "sd" << s << " = below ? e : 0.0;\n" << I2 << "}\n";
+            for (int l = l0 + 1; l < L; ++l) fmac_b(I2, "sd" + std::to_string(s), q(sj, l), q(s, l), ccj);
+        }
+    };
+    auto publish = [&](int j, int sj, int ccj, const std::vector<int> &slots, int B, bool with_norm) {
+        const int l0 = j / NG, gj = j % NG;
+        if (with_norm) o << I2 << "xn2 = qgs_sum4(xn2);\n";
+        for (int s : slots) o << I2 << "sd" << s << " = qgs_sum4(sd" << s << ");\n";
+        o << I2 << "if ((tid & 48) == 0) {                    // the wavefront's sums, once\n";
+        for (int s : slots) o << I3 << "red[" << B << "][mw][ww][" << s << "][cc] = sd" << s << ";\n";
+        if (with_norm) o << I3 << "if (cc == " << ccj << ") red[" << B << "][mw][ww][" << P << "][0] = xn2;\n";
+        o << I2 << "}\n";
+        o << I2 << "if (g == " << gj << ") {                     // row " << j << "\n";
+        for (int s = 0; s < P; ++s) {
+            const bool needed = std::find(slots.begin(), slots.end(), s) != slots.end() || s == sj;
+            if (needed) o << I3 << "piv[" << B << "][mw][" << s << "][cc] = " << q(s, l0) << ";\n";
+        }
+        o << I2 << "}\n" << I2 << "__syncthreads();\n";
+    };
+    auto gather = [&](const std::string &name, int B, int s) {       // sum of the W wavefronts' partials, fixed order
+        o << I2 << "f64 " << name << " = red[" << B << "][mw][0][" << s << "][cc];\n";
+        for (int w = 1; w < W; ++w) o << I2 << name << " += red[" << B << "][mw][" << w << "][" << s << "][cc];\n";
+    };
+    // q -= (...) v on own rows below j, the pivot row itself in its group
+    auto update = [&](int j, int sj, int ccj, int s, const std::string &nw, const std::string &wv) {
+        const int l0 = j / NG, gj = j % NG;
+        o << I2 << "{\n" << I3 << "f64 e = " << q(s, l0) << ";\n";
+        fmac_b(I3, "e", q(sj, l0), nw, ccj);
+        o << I3 << q(s, l0) << " = below ? e : ((g == " << gj << ") ? " << q(s, l0) << " - " << wv << " : " << q(s, l0) << ");\n" << I2 << "}\n";
+        for (int l = l0 + 1; l < L; ++l) fmac_b(I2, q(s, l), q(sj, l), nw, ccj);
+    };
+    for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
+        const int sj = slot_of(j), ccj = lane_of(j), l0 = j / NG, gj = j % NG, B = step & 1;
+        const std::vector<int> slots = (j + 1 < C) ? live_slots(j, sj) : std::vector<int>();
+        o << "    {   // column " << j << "\n";
+        first = true;
+        partial_dots(j, sj, ccj, slots, true);
+        publish(j, sj, ccj, slots, B, true);
+        o << I2 << "f64 xs = red[" << B << "][mw][0][" << P << "][0];\n";
+        for (int w = 1; w < W; ++w) o << I2 << "xs += red[" << B << "][mw][" << w << "][" << P << "][0];\n";
+        o << I2 << "const f64 alpha = piv[" << B << "][mw][" << sj << "][" << ccj << "];\n"
+          << I2 << "f64 t = 0.0, beta = alpha, scale = 0.0;\n"
+          << I2 << "if (xs != 0.0) {\n"
+          << I2 << "    beta = -__builtin_copysign(__builtin_sqrt(__builtin_fma(alpha, alpha, xs)), alpha);\n"
+          << I2 << "    t = (beta - alpha) / beta;\n"
+          << I2 << "    scale = 1.0 / (alpha - beta);\n"
+          << I2 << "}\n";
+        for (int s : slots) {
+            const std::string S = std::to_string(s), ro = right_of(s, j);
+            gather("sum" + S, B, s);
+            o << I2 << "f64 wv" << S << " = t * __builtin_fma(scale, sum" << S << ", piv[" << B << "][mw][" << s << "][cc]);\n";
+            if (!ro.empty()) o << I2 << "wv" << S << " = " << ro << " ? wv" << S << " : 0.0;\n";
+            o << I2 << "f64 nw" << S << " = -(wv" << S << " * scale);\n";
+        }
+        first = true;
+        for (int s : slots) update(j, sj, ccj, s, "nw" + std::to_string(s), "wv" + std::to_string(s));
+        // the pivot lanes keep u = v * scale below the diagonal, tau on it; diag(R) leaves
+        o << I2 << "if (cc == " << ccj << ") {\n"
+          << I3 << q(sj, l0) << " = below ? " << q(sj, l0) << " * scale : ((g == " << gj << ") ? t : " << q(sj, l0) << ");\n";
+        for (int l = l0 + 1; l < L; ++l) o << I3 << q(sj, l) << " *= scale;\n";
+        o << I3 << "if (g == " << gj << " && live) rdiag[(i64)" << j << " * ld + m0 + mw] = beta;\n";
+        o << I2 << "}\n    }\n";
+        ++step;
+    }
+    for (int j = K - 1; j >= 0; --j) {              // ---- dorg2r: tau_j sits on the diagonal of the pivot lanes
+        const int sj = slot_of(j), ccj = lane_of(j), l0 = j / NG, gj = j % NG, B = step & 1;
+        const std::vector<int> slots = live_slots(j, sj);
+        o << "    {   // Q: reflector " << j << "\n";
+        first = true;
+        o << I2 << "const bool below = g > " << gj << ";\n";
+        if (!slots.empty()) {
+            // (partial_dots declares `below` itself: emit its body without the declaration)
+            for (int s : slots) {
+                o << I2 << "f64 sd" << s << " = 0.0;\n" << I2 << "{\n" << I3 << "f64 e = 0.0;\n";
+                fmac_b(I3, "e", q(sj, l0), q(s, l0), ccj);
+                o << I3 << "sd" << s << " = below ? e : 0.0;\n" << I2 << "}\n";
+                for (int l = l0 + 1; l < L; ++l) fmac_b(I2, "sd" + std::to_string(s), q(sj, l), q(s, l), ccj);
+            }
+            publish(j, sj, ccj, slots, B, false);
+            o << I2 << "const f64 t = piv[" << B << "][mw][" << sj << "][" << ccj << "];\n";
+            for (int s : slots) {
+                const std::string S = std::to_string(s), ro = right_of(s, j);
+                gather("sum" + S, B, s);
+                o << I2 << "f64 wv" << S << " = t * (piv[" << B << "][mw][" << s << "][cc] + sum" << S << ");\n";
+                if (!ro.empty()) o << I2 << "wv" << S << " = " << ro << " ? wv" << S << " : 0.0;\n";
+                o << I2 << "const f64 nw" << S << " = -wv" << S << ";\n";
+            }
+            first = true;
+            for (int s : slots) update(j, sj, ccj, s, "nw" + std::to_string(s), "wv" + std::to_string(s));
+            ++step;
+        }
+        // column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u); tau is read from the pivot lane of the pivot row's group by DPP + shuffle-free:
+        // every group needs it, so it travels through LDS when the step had no broadcast of its own
+        if (slots.empty()) {
+            o << I2 << "if (g == " << gj << " && cc == " << ccj << ") piv[" << B << "][mw][" << sj << "][" << ccj << "] = " << q(sj, l0) << ";\n"
+              << I2 << "__syncthreads();\n"
+              << I2 << "const f64 t = piv[" << B << "][mw][" << sj << "][" << ccj << "];\n";
+            ++step;
+        }
+        o << I2 << "if (cc == " << ccj << ") {\n";
+        for (int l = 0; l < l0; ++l) o << I3 << q(sj, l) << " = 0.0;\n";
+        o << I3 << q(sj, l0) << " = below ? " << q(sj, l0) << " * -t : ((g == " << gj << ") ? 1.0 - t : 0.0);\n";
+        for (int l = l0 + 1; l < L; ++l) o << I3 << q(sj, l) << " *= -t;\n";
+        o << I2 << "}\n    }\n";
+    }
+    for (int l = 0; l < L; ++l) {                     // ---- out
+        const int rows = std::min(NG, R - l * NG), pairs = rows * C, passes = (pairs + PASS - 1) / PASS;
+        o << "    {   // rows " << l * NG << " .. " << l * NG + rows - 1 << " out\n"
+          << I2 << "i64 ldw = ld; asm volatile(\"\" : \"+s\"(ldw));\n"
+          << I2 << "f64* const gp = a + (i64)tp * ldw + m0 + (tlive ? tm : 0);\n";
+        for (int s = 0; s < P; ++s)
+            o << I2 << "if (" << (rows < NG ? "g < " + std::to_string(rows) + " && " : std::string())
+              << (width[s] < 16 ? "cc < " + std::to_string(width[s]) : std::string("true")) << ") tile[g * " << C << " + " << base[s] << " + cc][mw] = " << q(s, l) << ";\n";
+        o << I2 << "__syncthreads();\n";
+        for (int k = 0; k < passes; ++k) {
+            const bool guard = PASS * k + PASS - 1 >= pairs;
+            o << I2 << "if (tlive" << (guard ? " && tp < " + std::to_string(pairs - PASS * k) : "") << ") gp[(i64)" << (l * NG * C + PASS * k)
+              << " * ldw] = tile[" << PASS * k << " + tp][tm];\n";
+        }
+        o << I2 << "__syncthreads();\n    }\n";
+    }
+    o << "    QGS_CLOCK_MARK(2)\n}\n";
+    GeneratedKernel gk;
+    gk.source = o.str();
+    return gk;
 }
 
 // Batched Householder QR, ROW design (plan.members == 4): lane = (member = lane / 16, column lane cc = lane % 16), and a lane keeps
@@ -1998,6 +2239,7 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
 
 GeneratedKernel generate_qr_kernel(int n_rows, int n_cols, const QrPlan &plan)
 {
+    if (plan.row_groups > 0) return generate_qr_grid_kernel(n_rows, n_cols, plan);
     if (plan.members == 4) return generate_qr_row_kernel(n_rows, n_cols, plan);
     const int R = n_rows, C = n_cols, K = std::min(R, C), P = plan.slots, W = plan.waves, NCH = std::max(1, plan.chains);
     const int M = plan.members, L = 64 / std::max(1, M);

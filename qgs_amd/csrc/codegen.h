@@ -142,11 +142,19 @@ std::vector<std::pair<Kernel, int>> kernel_list(int ndim, bool have_jac, const s
 std::string generate_source(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor,
                             const std::vector<int> &stages, const CodegenOptions &opt, const Derived &der = Derived());
 
-// Batched Householder QR fully unrolled for one matrix shape (n_cols <= n_rows <= 64): kernel `qgs_spec_qr_<rows>x<cols>`
-// (a, rdiag, n_traj, ld), workgroups of 64 * plan.waves threads, plan.members consecutive members per workgroup,
-// lane = (member, column lane), plan.slots columns per lane in registers, the reflector broadcast through LDS (codegen.cpp).
-// grid: members == 16: ceil(n_traj / 16) workgroups; members == 8: ceil(n_traj / 8) rounded up to a multiple of 16.
-// Replaces np.linalg.qr in the Benettin loops (qgs/toolbox/lyapunov.py:540-547, 599-628).
+// Batched Householder QR (dgeqr2 + dorg2r) fully unrolled for one matrix shape: kernel `qgs_spec_qr_<rows>x<cols>` (a, rdiag, n_traj,
+// ld), n_cols <= n_rows <= 300, n_cols <= 64.  Replaces np.linalg.qr in the Benettin loops (qgs/toolbox/lyapunov.py:540-547, 599-628).
+// Three layouts, chosen per shape by qr_plan (codegen.cpp has the reasons and profiles/r05_qr.md the measurements):
+//   row design  (plan.members == 4): one wavefront = 4 members x 16 column lanes, all columns of a member in its lanes' registers,
+//                the pivot column through DPP row broadcasts; no LDS or barrier in the factorisation.  Where 2 * rows * ceil(cols / 16)
+//                registers fit one lane and >= 70 % of the column lanes are used (36 x 36, 38 x 38, 32 x 32 ...).
+//                grid = ceil(n_traj / 16) workgroups of 256 threads.
+//   tile design (plan.members == 16 | 8): 16 (8) members per workgroup, lane = (member, column lane), plan.slots columns per lane,
+//                the reflector broadcast through LDS, one barrier per step.  Small and thin shapes, and 38 < rows <= 64.
+//                grid = ceil(n_traj / 16) workgroups (members == 8: ceil(n_traj / 8) rounded up to a multiple of 16) of 64 * plan.waves threads.
+//   grid design (plan.row_groups > 0): rows > 64: a member over plan.waves wavefronts = 4 * waves row groups (rows dealt cyclically),
+//                DPP broadcast inside a group, one number per column and step across groups (shuffles + LDS), plan.members members
+//                per workgroup.  grid = ceil(n_traj / plan.members) workgroups of 64 * plan.waves * plan.members threads.
 struct QrPlan {
     int members = 16;     // members per workgroup (16: whole 128-byte lines; 8: half lines, two workgroups per line on one XCD)
     int slots = 1;        // columns per lane
@@ -154,6 +162,8 @@ struct QrPlan {
     int chains = 1;       // partial sums per dot product (1 = one left-to-right chain)
     bool reload = false;  // read the reflector from LDS once for the dot products and again for the update (large n_rows)
     bool lookahead = false; // the owner of column j + 1 forms pivot j + 1 between the updates of its slots (else: after them)
+    int row_groups = 0;   // > 0: grid design for tall matrices (rows > 64): a member over `waves` wavefronts = 4 * waves row groups,
+                          //      `members` members per workgroup
 };
 QrPlan qr_plan(int n_rows, int n_cols, int members = 0, int slots = 0);      // 0: the default choice
 std::string qr_plan_signature(const QrPlan &plan);     // (part of the cache key)

@@ -2175,7 +2175,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         HIPCHK(hipGetLastError());
         return 0;
     }
-    if (m->kernel_kind != 1 && n_rows <= 64) {
+    if (m->kernel_kind != 1) {          // (rows <= 300, cols <= 64 here)
         // shape-specialised kernel, 16 members per workgroup, columns in registers (codegen generate_qr_kernel), compiled once per shape
         const qgs::QrPlan plan = qr_plan_for(n_rows, n_cols);
         const std::string fname = "qgs_spec_qr_" + std::to_string(n_rows) + "x" + std::to_string(n_cols);
@@ -2194,9 +2194,16 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
         void *args[] = {(void *)&d_a, (void *)&d_rdiag, &nt, &l};
         note_kernel(m, fname, f);
         // workgroups: 16 members each (row design: 4 wavefronts x 4 members; tile design with 16-member tiles), or 8-member tiles in pairs
-        const int64_t tiles = (n_traj + (plan.members == 8 ? 8 : 16) - 1) / (plan.members == 8 ? 8 : 16);
-        const unsigned grid = (unsigned)(plan.members == 8 ? (tiles + 15) / 16 * 16 : tiles);
-        HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, 64u * (unsigned)plan.waves, 1, 1, 0, (hipStream_t)stream, args, nullptr));
+        unsigned grid, block;
+        if (plan.row_groups > 0) {          // grid design (rows > 64): plan.members members per workgroup, plan.waves wavefronts each
+            grid = (unsigned)((n_traj + plan.members - 1) / plan.members);
+            block = 64u * (unsigned)(plan.waves * plan.members);
+        } else {
+            const int64_t tiles = (n_traj + (plan.members == 8 ? 8 : 16) - 1) / (plan.members == 8 ? 8 : 16);
+            grid = (unsigned)(plan.members == 8 ? (tiles + 15) / 16 * 16 : tiles);
+            block = 64u * (unsigned)plan.waves;
+        }
+        HIPCHK(hipModuleLaunchKernel(f, grid, 1, 1, block, 1, 1, 0, (hipStream_t)stream, args, nullptr));
         return 0;
     }
     qgs::launch_batched_qr(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, (hipStream_t)stream);
@@ -3107,7 +3114,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
 
 int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
 {
-    if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 64");
+    if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 300 || n_cols > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 300, n_cols <= 64");
     if (!prebuild_mine()) return 0;
     std::shared_ptr<const KernelBlob> blob;
     bool cached;

@@ -19,7 +19,14 @@ def test_batched_qr_matches_lapack():
     m = f.hip_model()
     rng = np.random.RandomState(0)
     # shapes: register-resident generated kernels (rows <= 64), the LDS kernel (cols <= 64, rows <= 300), the global-memory kernel
-    for n_rows, n_cols, n in ((36, 36, 70), (20, 5, 3), (7, 1, 64), (64, 64, 2), (228, 40, 3), (100, 80, 2), (228, 228, 2), (320, 10, 2)):
+    # (round 5: two generated designs -- four matrices per wavefront with DPP broadcasts where 2 * rows * ceil(cols / 16) registers
+    # fit, 16- / 8-member tiles with an LDS broadcast otherwise; member counts around the 4 / 16 / 64 boundaries; column counts that
+    # are and are not multiples of 16)
+    shapes = ((36, 36, 70), (20, 5, 3), (7, 1, 64), (64, 64, 2), (228, 40, 3), (100, 80, 2), (228, 228, 2), (320, 10, 2),
+              (36, 36, 1), (36, 36, 17), (32, 32, 33), (16, 16, 5), (38, 38, 20), (36, 12, 19), (24, 24, 9), (36, 20, 7), (48, 48, 4),
+              (40, 40, 18), (12, 12, 130), (33, 17, 6), (2, 2, 4), (1, 1, 3), (228, 40, 9), (100, 36, 70), (228, 64, 3), (300, 64, 2), (65, 1, 5),
+              (130, 50, 6), (70, 70, 3), (228, 10, 17))
+    for n_rows, n_cols, n in shapes:
         a = rng.randn(n, n_rows, n_cols)
         ld = (n + 63) // 64 * 64
         d = torch.zeros((n_rows, n_cols, ld), dtype=torch.float64, device='cuda')
@@ -27,7 +34,7 @@ def test_batched_qr_matches_lapack():
         rd = torch.zeros((n_cols, ld), dtype=torch.float64, device='cuda')
         m.batched_qr_device(n, ld, n_rows, n_cols, d.data_ptr(), rd.data_ptr())
         torch.cuda.synchronize()
-        expect = 'qgs_spec_qr_%dx%d' % (n_rows, n_cols) if n_rows <= 64 else ('' if (n_cols <= 64 and n_rows <= 300) else 'batched_qr_global_kernel')
+        expect = 'qgs_spec_qr_%dx%d' % (n_rows, n_cols) if (n_cols <= 64 and n_rows <= 300) else 'batched_qr_global_kernel'
         if expect:
             assert m.last_kernel_info()['name'] == expect
         q = d[:, :, :n].cpu().numpy().transpose(2, 0, 1)

@@ -6,7 +6,7 @@ g = np.load('/root/repo/tests/golden/t228.npz'); ndim = 228
 m = _lib.HipModel(ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
 c = np.array([0., .5, .5, 1.]); b = np.array([1 / 6, 1 / 3, 1 / 3, 1 / 6]); a = np.zeros((4, 4)); a[1, 0] = .5; a[2, 1] = .5; a[3, 2] = 1.
 dev = torch.device('cuda', 0); st = torch.cuda.current_stream().cuda_stream
-for n, nv in ((1, 228), (1, 64), (64, 228), (64, 64)):
+for n, nv in ((1, 228), (64, 64), (1024, 40), (4096, 40), (4096, 10), (1024, 228)):
     ld = (n + 63) // 64 * 64
     ic = torch.from_numpy(np.random.RandomState(2).rand(ndim, ld) * 0.01).to(dev)
     q = torch.randn((ndim, nv, ld), dtype=torch.float64, device=dev)
