@@ -1713,7 +1713,7 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
         while (p.waves < 16 && 2 * ((n_rows + 4 * p.waves - 1) / (4 * p.waves)) * p.slots > 110) p.waves *= 2;
         p.row_groups = 4 * p.waves;
         p.members = std::max(1, std::min(4, 16 / p.waves));
-        p.reload = false; p.chains = 1; p.lookahead = false;
+        p.reload = false; p.chains = 1;
         return p;
     }
     // registers a lane needs: 2 R per slot for the columns + 2 R for the reflector + temporaries; what it may use: the 512 of a
@@ -1736,7 +1736,7 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
     // (by default where at least 70 % of its 16 column lanes x slots hold a column: 36 x 36 runs in 0.163 ms against the tile
     // design's 0.215, 36 x 10 in 0.039 against 0.034 -- profiles/r05_qr.md)
     if (row_fits && (members == 4 || (members == 0 && 10 * n_cols >= 7 * 16 * row_slots))) {
-        p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1; p.lookahead = false;
+        p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1;
         return p;
     }
     const int m_lo = (members == 8 || members == 16) ? members : 16, m_hi = (members == 8 || members == 16) ? members : 8;
@@ -1752,7 +1752,7 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
 std::string qr_plan_signature(const QrPlan &p)
 {
     std::ostringstream s;
-    s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0) << "a" << (p.lookahead ? 1 : 0);
+    s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0);
     if (p.row_groups > 0) s << "g" << p.row_groups;
     return s.str();
 }
@@ -2414,24 +2414,14 @@ GeneratedKernel generate_qr_kernel(int n_rows, int n_cols, const QrPlan &plan)
                 update(ind, s, j, B, qr_phase);
             }
         };
-        if (ahead_w >= 0 && !plan.lookahead) {
-            others(I3, -1);
-            o << I2 << "}\n";
+        others(I3, -1);
+        o << I2 << "}\n";
+        // (Forming pivot j + 1 BETWEEN the owner's slot updates, in one basic block with them, was measured: the interleaved form wants
+        // more than 256 registers and spills, 0.46 instead of 0.22 ms at 36 x 36 -- profiles/r05_qr.md section 4.)
+        if (ahead_w >= 0) {
             o << I2 << "if (w == " << ahead_w << ")\n";
             ahead(I2);
-            ++step;
-            return;
         }
-        if (ahead_w >= 0) {
-            o << I3 << "if (w == " << ahead_w << ") {\n";
-            if (std::find(slots.begin(), slots.end(), ahead_s) != slots.end()) update(I4, ahead_s, j, B, qr_phase);
-            ahead(I4);
-            others(I4, ahead_s);
-            o << I3 << "} else {\n";
-            others(I4, -1);
-            o << I3 << "}\n";
-        } else others(I3, -1);
-        o << I2 << "}\n";
         ++step;
     };
     // ---- dgeqr2: columns > j exist for j < C - 1; pivot j + 1 is formed during step j

@@ -1381,7 +1381,6 @@ qgs::QrPlan qr_plan_for(int n_rows, int n_cols)
 #ifdef QGS_HIP_DEV_KNOBS
     if (const char *e = std::getenv("QGS_HIP_QR_CHAINS")) p.chains = std::max(1, std::min(8, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_QR_RELOAD")) p.reload = (*e == '1');
-    if (const char *e = std::getenv("QGS_HIP_QR_LOOKAHEAD")) p.lookahead = (*e == '1');
 #endif
     return p;
 }
