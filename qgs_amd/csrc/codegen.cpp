@@ -1705,7 +1705,9 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 // not emitted.
 QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
 {
-    if (n_rows > 64 || members == 2) {          // (members == 2: a developer build's way to ask for the grid design at any shape)
+    // (members == 2: a developer build's way to ask for the grid design at any shape.  Between 39 and 64 rows it beats the tile
+    // design only for thin matrices: 64 x 20 0.27 vs 0.49 ms, 64 x 64 0.56 vs 0.38, 48 x 48 0.60 vs 0.60 -- profiles/r05_qr.md)
+    if (n_rows > 64 || members == 2 || (members == 0 && n_rows > 38 && n_cols <= 32)) {
         // grid design: W wavefronts per member (4 W row groups), as few as keep the local rows x slots within ~110 registers
         QrPlan p;
         p.slots = (n_cols + 15) / 16;
