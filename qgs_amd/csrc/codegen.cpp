@@ -1734,11 +1734,16 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
     QrPlan p;
     // one wavefront = 4 members x 16 column lanes, every column of a member in that wavefront: no LDS, no barriers (generate_qr_row_kernel)
     const int row_slots = (n_cols + 15) / 16;
-    const bool row_fits = 2 * n_rows * row_slots + 24 <= 256;          // (36 x 36: 216 + 12 registers)
+    // (36 x 36: 216 + 12 registers: two wavefronts per SIMD.  Up to 384 the matrices still fit one wavefront per SIMD with part of
+    // them in accumulation registers -- slower per instruction, but 40 x 40 ... 52 x 52 have no better home: the tile design runs
+    // 40 x 40 in 0.42 ms, 48 x 48 in 0.60)
+    const int row_regs = 2 * n_rows * row_slots + 24;
+    const bool row_fits = row_regs <= 384 && (row_regs <= 256 || n_cols > 32);
     // (by default where at least 70 % of its 16 column lanes x slots hold a column: 36 x 36 runs in 0.163 ms against the tile
     // design's 0.215, 36 x 10 in 0.039 against 0.034 -- profiles/r05_qr.md)
     if (row_fits && (members == 4 || (members == 0 && 10 * n_cols >= 7 * 16 * row_slots))) {
         p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1;
+        p.one_wave_per_simd = row_regs > 256;
         return p;
     }
     const int m_lo = (members == 8 || members == 16) ? members : 16, m_hi = (members == 8 || members == 16) ? members : 8;
@@ -1756,6 +1761,7 @@ std::string qr_plan_signature(const QrPlan &p)
     std::ostringstream s;
     s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0);
     if (p.row_groups > 0) s << "g" << p.row_groups;
+    if (p.one_wave_per_simd) s << "o1";
     return s.str();
 }
 
@@ -2069,7 +2075,7 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
       << RC << " rows\n";
     o << "#ifdef QGS_QR_PROFILE\n#define QGS_QR_MARK(k) if (threadIdx.x == 0) prof[(i64)blockIdx.x * 160 + (k)] = (k) < 8 ? wall_clock64() : __builtin_amdgcn_s_memtime();\n"
       << "#define QGS_QR_PROF_ARG , unsigned long long* prof\n#else\n#define QGS_QR_MARK(k)\n#define QGS_QR_PROF_ARG\n#endif\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(256, 2) qgs_spec_qr_" << R << "x" << C
+    o << "extern \"C\" __global__ void __launch_bounds__(256, " << (plan.one_wave_per_simd ? 1 : 2) << ") qgs_spec_qr_" << R << "x" << C
       << "(f64* __restrict__ a, f64* __restrict__ rdiag, i64 n_traj, i64 ld QGS_QR_PROF_ARG)\n{\n";
     o << "    __shared__ f64 tile[" << RC * C << "][17];          // [(row in the tile) * " << C << " + column][member of the workgroup's 16]\n";
     o << "    QGS_CLOCK_MARK(0)\n";
