@@ -312,6 +312,11 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
 /* Same for the shape-specialised batched QR kernel of qgs_batched_qr_device (n_cols <= n_rows <= 300, n_cols <= 64). */
 int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch);
 
+/* Generated HIP source of that kernel, first line "// plan <signature>" (inspection, and the build-host test that compiles it and
+ * checks the instruction stream around every DPP instruction: tests/test_qr_codegen_cpu.py).  Returns the length, or -1; copies at
+ * most buflen-1 bytes. */
+int64_t qgs_qr_kernel_source(int n_rows, int n_cols, char *buf, int64_t buflen);
+
 /* Generated HIP source of the specialised kernels of this model (debugging / inspection); value-free: the coefficient
  * tables are declared without initialisers.
  * Returns the length; copies at most buflen-1 bytes. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     'qgs_prebuild': (_int, [_int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
     'qgs_prebuild_rank': (_int, [_int, _int, _i64, _vp, _vp, _i64, _vp, _vp, _int, ctypes.POINTER(_int), ctypes.c_char_p]),
     'qgs_prebuild_qr': (_int, [_int, _int, ctypes.c_char_p]),
+    'qgs_qr_kernel_source': (_i64, [_int, _int, ctypes.c_char_p, _i64]),
     'qgs_model_kernel_source': (_i64, [_vp, ctypes.c_char_p, _i64]),
 }
 
@@ -328,6 +329,16 @@ def prebuild(ndim, coo, val, jcoo, jval, stage_counts=(4,), arch=None):
 def prebuild_qr(n_rows, n_cols, arch=None):
     """Compile + cache the batched-QR kernel of one matrix shape without a GPU (see qgs_prebuild_qr)."""
     _check(lib().qgs_prebuild_qr(int(n_rows), int(n_cols), arch.encode() if arch else None))
+
+
+def qr_kernel_source(n_rows, n_cols):
+    """Generated source of that kernel, first line `// plan <signature>` (qgs_qr_kernel_source); no GPU needed."""
+    n = lib().qgs_qr_kernel_source(int(n_rows), int(n_cols), None, 0)
+    if n < 0:
+        _check(-1)
+    buf = ctypes.create_string_buffer(int(n) + 1)
+    lib().qgs_qr_kernel_source(int(n_rows), int(n_cols), buf, int(n) + 1)
+    return buf.value.decode()
 
 
 class HipModel(object):

@@ -1705,21 +1705,47 @@ void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<st
 // not emitted.
 QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
 {
-    // (members == 2: a developer build's way to ask for the grid design at any shape.  Between 39 and 64 rows it beats the tile
-    // design only for thin matrices: 64 x 20 0.27 vs 0.49 ms, 64 x 64 0.56 vs 0.38, 48 x 48 0.60 vs 0.60 -- profiles/r05_qr.md)
-    if (n_rows > 64 || members == 2 || (members == 0 && n_rows > 38 && n_cols <= 32)) {
-        // grid design: W wavefronts per member (4 W row groups), as few as keep the local rows x slots within ~110 registers
+    // Which of the three layouts (codegen.h; measurements: profiles/r05_qr.md).  `members` / `slots` other than 0 are a developer
+    // build's requests: members 4 = row design, 2 = grid design, 16 / 8 = tile design with that tile.
+    const int row_slots = (n_cols + 15) / 16;
+    const int row_regs = 2 * n_rows * row_slots + 24;          // row design: the matrices + temporaries (36 x 36: 216 + 12)
+    auto row_plan = [&] {
         QrPlan p;
-        p.slots = (n_cols + 15) / 16;
+        p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1;
+        // (row_regs 241 ... 256, e.g. 56 x 20 or 38 x 34, leave the compiler 12 ... 68 bytes of scratch at two wavefronts per SIMD: still
+        // well ahead of one wavefront per SIMD, which has nothing to hide the latency of a dependent chain behind)
+        p.one_wave_per_simd = row_regs > 256;
+        return p;
+    };
+    auto grid_plan = [&] {
+        // W wavefronts per member (4 W row groups), as few as keep the local rows x slots within ~110 registers
+        QrPlan p;
+        p.slots = row_slots;
         p.waves = 1;
         while (p.waves < 16 && 2 * ((n_rows + 4 * p.waves - 1) / (4 * p.waves)) * p.slots > 110) p.waves *= 2;
         p.row_groups = 4 * p.waves;
         p.members = std::max(1, std::min(4, 16 / p.waves));
         p.reload = false; p.chains = 1;
         return p;
+    };
+    if (members == 4 && row_regs <= 384) return row_plan();
+    if (members == 2) return grid_plan();
+    if (members == 0) {
+        // 1. four matrices per wavefront from 13 columns on, while they fit the registers of a SIMD lane: two wavefronts per SIMD up to
+        //    256 registers (n_rows x ceil(n_cols / 16) <= 116), one wavefront up to 384 with part of the matrices in accumulation
+        //    registers (rows <= 64: beyond, the compiler's copies are the time).  16 384 matrices, against the next best design:
+        //    36 x 36 0.13 ms (tile 0.215), 20 x 20 0.041 (tile 0.057), 36 x 20 0.072 (tile 0.089), 48 x 20 0.092 (grid 0.186),
+        //    100 x 16 0.146 (grid 0.271), 40 x 40 0.24 (tile 0.42), 48 x 48 0.38 (tile 0.60), 64 x 20 0.19 (grid 0.27), 60 x 30 0.26
+        //    (grid 0.39), 56 x 40 0.41 (grid 0.60), 60 x 44 0.54 (grid 0.67).  Thinner ones stay with the tile design (36 x 10 0.039
+        //    against 0.034); 52 x 52 would want 440 registers and spills.
+        if (n_cols > 12 && (row_regs <= 256 || (row_regs <= 384 && n_rows <= 64))) return row_plan();
+        // 2. tall matrices, thin ones from 39 rows, and what is left up to 48 columns (64 x 40: 0.64 against the tile design's 0.97,
+        //    64 x 48: 0.86 against 1.15; from 49 columns on the tile design is ahead: 52 x 52 0.71 against 0.89, 64 x 64 1.50 against 2.22)
+        if (n_rows > 64 || (n_rows > 38 && n_cols <= 48)) return grid_plan();
     }
-    // registers a lane needs: 2 R per slot for the columns + 2 R for the reflector + temporaries; what it may use: the 512 of a
-    // SIMD lane shared by the wavefronts of one workgroup on that SIMD, at most 256
+    if (n_rows > 64) return grid_plan();
+    // 3. tile design.  Registers a lane needs: 2 R per slot for the columns + 2 R for the reflector + temporaries; what it may use: the
+    //    512 of a SIMD lane shared by the wavefronts of one workgroup on that SIMD, at most 256
     auto make = [&](int M, int P, QrPlan &p) {
         const int L = 64 / M;
         p.members = M;
@@ -1732,20 +1758,6 @@ QrPlan qr_plan(int n_rows, int n_cols, int members, int slots)
         return 2 * n_rows * (p.slots + 1) + 30 <= cap;
     };
     QrPlan p;
-    // one wavefront = 4 members x 16 column lanes, every column of a member in that wavefront: no LDS, no barriers (generate_qr_row_kernel)
-    const int row_slots = (n_cols + 15) / 16;
-    // (36 x 36: 216 + 12 registers: two wavefronts per SIMD.  Up to 384 the matrices still fit one wavefront per SIMD with part of
-    // them in accumulation registers -- slower per instruction, but 40 x 40 ... 52 x 52 have no better home: the tile design runs
-    // 40 x 40 in 0.42 ms, 48 x 48 in 0.60)
-    const int row_regs = 2 * n_rows * row_slots + 24;
-    const bool row_fits = row_regs <= 384 && (row_regs <= 256 || n_cols > 32);
-    // (by default where at least 70 % of its 16 column lanes x slots hold a column: 36 x 36 runs in 0.163 ms against the tile
-    // design's 0.215, 36 x 10 in 0.039 against 0.034 -- profiles/r05_qr.md)
-    if (row_fits && (members == 4 || (members == 0 && 10 * n_cols >= 7 * 16 * row_slots))) {
-        p.members = 4; p.slots = row_slots; p.waves = 4; p.reload = false; p.chains = 1;
-        p.one_wave_per_simd = row_regs > 256;
-        return p;
-    }
     const int m_lo = (members == 8 || members == 16) ? members : 16, m_hi = (members == 8 || members == 16) ? members : 8;
     for (int M = m_lo; M >= m_hi; M -= 8)
         for (int P = slots > 0 ? slots : 4; P >= (slots > 0 ? slots : 1); --P)
@@ -1763,6 +1775,51 @@ std::string qr_plan_signature(const QrPlan &p)
     if (p.row_groups > 0) s << "g" << p.row_groups;
     if (p.one_wave_per_simd) s << "o1";
     return s.str();
+}
+
+// `acc += (lane cc of the 16-lane row of src) * y` as `v_fmac_f64_dpp ... row_newbcast:cc` (full rate on gfx950), for the row and grid
+// designs of the batched QR.  The compiler has no DPP form of the fp64 FMA to offer (`__builtin_amdgcn_update_dpp` on a double becomes
+// a v_mov_b64_dpp in front of a plain FMA: twice the instructions), so these are inline assembly -- and the compiler does not look
+// inside inline assembly for the hazard every DPP instruction has: a VGPR written by a VALU instruction must not be read as the DPP
+// operand within the next two wait states.  Our own instructions never do that (checked below), but the register allocator may put
+// a copy of `src` right in front of a statement (v_accvgpr_read_b32 out of the accumulation registers in the one-wavefront-per-SIMD
+// kernels, a v_mov where it splits a live range): seen as wrong factors in a 64 x 20 developer plan, 113 such places.  So every
+// statement starts with `s_nop 1`, whatever the allocator did before it, and holds a RUN of up to eight instructions, which makes that
+// one wait per run instead of one per instruction: all operands of a statement are in their registers when it starts, and nothing of
+// the compiler's comes between its instructions.
+struct DppOp {
+    std::string acc, src, y;
+};
+static void emit_dpp_fmacs(std::ostream &o, const std::string &ind, const std::vector<DppOp> &ops, int cc, size_t run = 8)
+{
+    for (size_t b = 0; b < ops.size(); b += run) {
+        const size_t e = std::min(ops.size(), b + run);
+        std::vector<std::string> outs, ins;
+        auto index_of = [](const std::vector<std::string> &v, const std::string &n) {
+            for (size_t k = 0; k < v.size(); ++k) if (v[k] == n) return (int)k;
+            return -1;
+        };
+        for (size_t k = b; k < e; ++k) if (index_of(outs, ops[k].acc) < 0) outs.push_back(ops[k].acc);
+        for (size_t k = b; k < e; ++k)
+            for (const std::string *n : {&ops[k].src, &ops[k].y})
+                if (index_of(outs, *n) < 0 && index_of(ins, *n) < 0) ins.push_back(*n);
+        auto ref = [&](const std::string &n) {
+            const int a = index_of(outs, n);
+            return "%" + std::to_string(a >= 0 ? a : (int)outs.size() + index_of(ins, n));
+        };
+        o << ind << "asm volatile(\"s_nop 1";
+        for (size_t k = b; k < e; ++k) {
+            // (our own hazard: the DPP operand written by one of the two instructions before it)
+            if ((k > b && ops[k - 1].acc == ops[k].src) || (k > b + 1 && ops[k - 2].acc == ops[k].src)) o << "\\n\\ts_nop 1";
+            o << "\\n\\tv_fmac_f64_dpp " << ref(ops[k].acc) << ", " << ref(ops[k].src) << ", " << ref(ops[k].y) << " row_newbcast:" << cc
+              << " row_mask:0xf bank_mask:0xf";
+        }
+        o << "\" :";
+        for (size_t k = 0; k < outs.size(); ++k) o << (k ? ", " : " ") << "\"+v\"(" << outs[k] << ")";
+        o << " :";
+        for (size_t k = 0; k < ins.size(); ++k) o << (k ? ", " : " ") << "\"v\"(" << ins[k] << ")";
+        o << ");\n";
+    }
 }
 
 // Batched Householder QR, GRID design (plan.row_groups > 0): matrices too tall for the registers of one wavefront (rows > 64 ... 300,
@@ -1793,11 +1850,14 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
     std::ostringstream o;
     const std::string I2 = "        ", I3 = "            ";
     auto q = [](int s, int l) { return "q" + std::to_string(s) + "_" + std::to_string(l); };
-    bool first = true;
     auto fmac_b = [&](const std::string &ind, const std::string &acc, const std::string &src, const std::string &y, int cc) {
-        o << ind << "asm volatile(\"" << (first ? "s_nop 1\\n\\t" : "") << "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" << cc
-          << " row_mask:0xf bank_mask:0xf\" : \"+v\"(" << acc << ") : \"v\"(" << src << "), \"v\"(" << y << "));\n";
-        first = false;
+        emit_dpp_fmacs(o, ind, {{acc, src, y}}, cc);
+    };
+    // the same over the local rows l0 + 1 .. L - 1: acc(l) += (pivot lane of src(l)) * y(l)
+    auto fmac_rows = [&](const std::string &ind, int l0, int cc, const std::function<DppOp(int)> &op) {
+        std::vector<DppOp> ops;
+        for (int l = l0 + 1; l < L; ++l) ops.push_back(op(l));
+        emit_dpp_fmacs(o, ind, ops, cc);
     };
     auto live_slots = [&](int j, int sj) {
         std::vector<int> v;
@@ -1868,7 +1928,7 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
             o << I2 << "{\n" << I3 << "f64 e = 0.0;\n";
             fmac_b(I3, "e", q(sj, l0), q(s, l0), ccj);
             o << I3 << "sd" << s << " = below ? e : 0.0;\n" << I2 << "}\n";
-            for (int l = l0 + 1; l < L; ++l) fmac_b(I2, "sd" + std::to_string(s), q(sj, l), q(s, l), ccj);
+            fmac_rows(I2, l0, ccj, [&](int l) { return DppOp{"sd" + std::to_string(s), q(sj, l), q(s, l)}; });
         }
     };
     auto publish = [&](int j, int sj, int ccj, const std::vector<int> &slots, int B, bool with_norm) {
@@ -1896,13 +1956,12 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
         o << I2 << "{\n" << I3 << "f64 e = " << q(s, l0) << ";\n";
         fmac_b(I3, "e", q(sj, l0), nw, ccj);
         o << I3 << q(s, l0) << " = below ? e : ((g == " << gj << ") ? " << q(s, l0) << " - " << wv << " : " << q(s, l0) << ");\n" << I2 << "}\n";
-        for (int l = l0 + 1; l < L; ++l) fmac_b(I2, q(s, l), q(sj, l), nw, ccj);
+        fmac_rows(I2, l0, ccj, [&](int l) { return DppOp{q(s, l), q(sj, l), nw}; });
     };
     for (int j = 0; j < K; ++j) {                   // ---- dgeqr2
         const int sj = slot_of(j), ccj = lane_of(j), l0 = j / NG, gj = j % NG, B = step & 1;
         const std::vector<int> slots = (j + 1 < C) ? live_slots(j, sj) : std::vector<int>();
         o << "    {   // column " << j << "\n";
-        first = true;
         partial_dots(j, sj, ccj, slots, true);
         publish(j, sj, ccj, slots, B, true);
         o << I2 << "f64 xs = red[" << B << "][mw][0][" << P << "][0];\n";
@@ -1921,7 +1980,6 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
             if (!ro.empty()) o << I2 << "wv" << S << " = " << ro << " ? wv" << S << " : 0.0;\n";
             o << I2 << "f64 nw" << S << " = -(wv" << S << " * scale);\n";
         }
-        first = true;
         for (int s : slots) update(j, sj, ccj, s, "nw" + std::to_string(s), "wv" + std::to_string(s));
         // the pivot lanes keep u = v * scale below the diagonal, tau on it; diag(R) leaves
         o << I2 << "if (cc == " << ccj << ") {\n"
@@ -1935,7 +1993,6 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
         const int sj = slot_of(j), ccj = lane_of(j), l0 = j / NG, gj = j % NG, B = step & 1;
         const std::vector<int> slots = live_slots(j, sj);
         o << "    {   // Q: reflector " << j << "\n";
-        first = true;
         o << I2 << "const bool below = g > " << gj << ";\n";
         if (!slots.empty()) {
             // (partial_dots declares `below` itself: emit its body without the declaration)
@@ -1943,7 +2000,7 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
                 o << I2 << "f64 sd" << s << " = 0.0;\n" << I2 << "{\n" << I3 << "f64 e = 0.0;\n";
                 fmac_b(I3, "e", q(sj, l0), q(s, l0), ccj);
                 o << I3 << "sd" << s << " = below ? e : 0.0;\n" << I2 << "}\n";
-                for (int l = l0 + 1; l < L; ++l) fmac_b(I2, "sd" + std::to_string(s), q(sj, l), q(s, l), ccj);
+                fmac_rows(I2, l0, ccj, [&](int l) { return DppOp{"sd" + std::to_string(s), q(sj, l), q(s, l)}; });
             }
             publish(j, sj, ccj, slots, B, false);
             o << I2 << "const f64 t = piv[" << B << "][mw][" << sj << "][" << ccj << "];\n";
@@ -1954,7 +2011,6 @@ static GeneratedKernel generate_qr_grid_kernel(int n_rows, int n_cols, const QrP
                 if (!ro.empty()) o << I2 << "wv" << S << " = " << ro << " ? wv" << S << " : 0.0;\n";
                 o << I2 << "const f64 nw" << S << " = -wv" << S << ";\n";
             }
-            first = true;
             for (int s : slots) update(j, sj, ccj, s, "nw" + std::to_string(s), "wv" + std::to_string(s));
             ++step;
         }
@@ -2027,31 +2083,28 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
     std::ostringstream o;
     const std::string I1 = "    ", I2 = "        ", I3 = "            ";
     auto q = [](int s, int i) { return "q" + std::to_string(s) + "_" + std::to_string(i); };
-    // acc += (lane `cc` of the member's row of `src`) * y
-    auto fmac_b = [&](const std::string &ind, const std::string &acc, const std::string &src, const std::string &y, int cc, bool nop = false) {
-        o << ind << "asm volatile(\"" << (nop ? "s_nop 1\\n\\t" : "") << "v_fmac_f64_dpp %0, %1, %2 row_newbcast:" << cc
-          << " row_mask:0xf bank_mask:0xf\" : \"+v\"(" << acc << ") : \"v\"(" << src << "), \"v\"(" << y << "));\n";
-    };
     // sd = sum_{i > j} v_i q_i with v_i from lane cc_j: one chain, or plan.chains partial sums over interleaved rows
     const int NCH = std::max(1, std::min(4, plan.chains));
-    auto dot_b = [&](int s, int sj, int j, int ccj, bool &first) {
+    auto dot_b = [&](int s, int sj, int j, int ccj) {
         const int n = R - j - 1, nch = std::max(1, std::min(NCH, n));
-        if (nch == 1) {
-            o << I3 << "f64 sd = 0.0;\n";
-            for (int i = j + 1; i < R; ++i) { fmac_b(I3, "sd", q(sj, i), q(s, i), ccj, first); first = false; }
-            return;
-        }
         o << I3 << "f64 sd = 0.0";
         for (int k = 1; k < nch; ++k) o << ", sd" << k << " = 0.0";
         o << ";\n";
+        std::vector<DppOp> ops;
         for (int i = j + 1; i < R; ++i) {
             const int k = (i - j - 1) % nch;
-            fmac_b(I3, k ? "sd" + std::to_string(k) : std::string("sd"), q(sj, i), q(s, i), ccj, first);
-            first = false;
+            ops.push_back({k ? "sd" + std::to_string(k) : std::string("sd"), q(sj, i), q(s, i)});
         }
+        emit_dpp_fmacs(o, I3, ops, ccj);
         if (nch == 2) o << I3 << "sd += sd1;\n";
         else if (nch == 3) o << I3 << "sd = (sd + sd1) + sd2;\n";
-        else o << I3 << "sd = (sd + sd1) + (sd2 + sd3);\n";
+        else if (nch == 4) o << I3 << "sd = (sd + sd1) + (sd2 + sd3);\n";
+    };
+    // q_i += (v_i from lane cc_j) * nw on the rows below j
+    auto update_b = [&](int s, int sj, int j, int ccj) {
+        std::vector<DppOp> ops;
+        for (int i = j + 1; i < R; ++i) ops.push_back({q(s, i), q(sj, i), "nw"});
+        emit_dpp_fmacs(o, I3, ops, ccj);
     };
     auto live_slots = [&](int j, int sj) {              // slots with a column > j, the pivot's own slot last
         std::vector<int> v;
@@ -2167,19 +2220,17 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
           << I2 << "        " << q(sj, j) << " = t;\n"
           << I2 << "    }\n"
           << I2 << "}\n";
-        bool first = true;
         for (int s : live_slots(j, sj)) {
             const std::string ro = right_of(s, j);
             o << I2 << "{   // slot " << s << "\n";
-            dot_b(s, sj, j, ccj, first);
+            dot_b(s, sj, j, ccj);
             o << I3 << "f64 tm = " << q(s, j) << ", wv = 0.0, nw = 0.0;\n";
-            fmac_b(I3, "tm", "scale", "sd", ccj);                                    // q_j + scale (v.q)
-            fmac_b(I3, "wv", "t", "tm", ccj);                                        // t (...)
+            emit_dpp_fmacs(o, I3, {{"tm", "scale", "sd"}, {"wv", "t", "tm"}}, ccj);   // tm = q_j + scale (v.q), wv = t tm
             if (!ro.empty()) o << I3 << "wv = " << ro << " ? wv : 0.0;\n";
             o << I3 << q(s, j) << " -= wv;\n";
-            fmac_b(I3, "nw", "scale", "wv", ccj);                                    // w scale
+            emit_dpp_fmacs(o, I3, {{"nw", "scale", "wv"}}, ccj);                      // w scale
             o << I3 << "nw = -nw;\n";
-            for (int i = j + 1; i < R; ++i) fmac_b(I3, q(s, i), q(sj, i), "nw", ccj);    // q -= (w scale) v
+            update_b(s, sj, j, ccj);                                                   // q -= (w scale) v
             o << I2 << "}\n";
         }
         if (j + 1 < R) {
@@ -2202,16 +2253,15 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
         o << "    {   // Q: reflector " << j << "\n";
         const std::vector<int> slots = live_slots(j, sj);
         if (!slots.empty()) o << I2 << "QGS_QR_MARK(" << 8 + ++step << ")\n";
-        bool first = true;
         for (int s : slots) {
             const std::string ro = right_of(s, j);
             o << I2 << "{   // slot " << s << "\n";
-            dot_b(s, sj, j, ccj, first);
+            dot_b(s, sj, j, ccj);
             o << I3 << "const f64 tm = " << q(s, j) << " + sd;\n" << I3 << "f64 wv = 0.0;\n";
-            fmac_b(I3, "wv", q(sj, j), "tm", ccj);                                   // t (q_j + u.q)
+            emit_dpp_fmacs(o, I3, {{"wv", q(sj, j), "tm"}}, ccj);                     // t (q_j + u.q)
             if (!ro.empty()) o << I3 << "wv = " << ro << " ? wv : 0.0;\n";
             o << I3 << q(s, j) << " -= wv;\n" << I3 << "const f64 nw = -wv;\n";
-            for (int i = j + 1; i < R; ++i) fmac_b(I3, q(s, i), q(sj, i), "nw", ccj);
+            update_b(s, sj, j, ccj);
             o << I2 << "}\n";
         }
         o << I2 << "if (QGS_CC() == " << ccj << ") {            // column j of Q = H_j e_j: (0 .. 0, 1 - t, -t u)\n"

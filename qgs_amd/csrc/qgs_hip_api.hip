@@ -3123,6 +3123,24 @@ int qgs_prebuild_qr(int n_rows, int n_cols, const char *arch)
                        &cached, BlobMode::Publish);
 }
 
+int64_t qgs_qr_kernel_source(int n_rows, int n_cols, char *buf, int64_t buflen)
+{
+    if (n_rows < 1 || n_cols < 1 || n_cols > n_rows || n_rows > 300 || n_cols > 64) return fail("shape-specialised QR: 1 <= n_cols <= n_rows <= 300, n_cols <= 64");
+    std::string src;
+    try {
+        const qgs::QrPlan plan = qr_plan_for(n_rows, n_cols);
+        src = "// plan " + qgs::qr_plan_signature(plan) + "\n" + qgs::generate_qr_kernel(n_rows, n_cols, plan).source;
+    } catch (const std::exception &e) {
+        return fail(e.what());
+    }
+    if (buf && buflen > 0) {
+        const size_t n = std::min<size_t>(src.size(), (size_t)buflen - 1);
+        std::memcpy(buf, src.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)src.size();
+}
+
 int qgs_prebuild(int ndim, int64_t nnz, const int32_t *coo, const double *val, int64_t jnnz, const int32_t *jcoo,
                  const double *jval, int n_stage_counts, const int *stage_counts, const char *arch)
 {

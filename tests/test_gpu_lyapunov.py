@@ -25,7 +25,12 @@ def test_batched_qr_matches_lapack():
     shapes = ((36, 36, 70), (20, 5, 3), (7, 1, 64), (64, 64, 2), (228, 40, 3), (100, 80, 2), (228, 228, 2), (320, 10, 2),
               (36, 36, 1), (36, 36, 17), (32, 32, 33), (16, 16, 5), (38, 38, 20), (36, 12, 19), (24, 24, 9), (36, 20, 7), (48, 48, 4),
               (40, 40, 18), (12, 12, 130), (33, 17, 6), (2, 2, 4), (1, 1, 3), (228, 40, 9), (100, 36, 70), (228, 64, 3), (300, 64, 2), (65, 1, 5),
-              (130, 50, 6), (70, 70, 3), (228, 10, 17), (64, 20, 9), (48, 16, 33), (40, 3, 5))
+              (130, 50, 6), (70, 70, 3), (228, 10, 17), (64, 20, 9), (48, 16, 33), (40, 3, 5),
+              # row design with operands parked in accumulation registers or close to the register limit: where the register
+              # allocator's copies in front of the DPP instructions showed (44 x 40 was wrong in round 5 before those instructions came
+              # in runs behind a wait, tests/test_qr_codegen_cpu.py)
+              (44, 40, 37), (64, 20, 33), (60, 30, 37), (56, 20, 34), (38, 34, 35), (64, 32, 33), (64, 16, 21), (64, 40, 33),
+              (100, 16, 19), (52, 52, 9), (42, 37, 66))
     for n_rows, n_cols, n in shapes:
         a = rng.randn(n, n_rows, n_cols)
         ld = (n + 63) // 64 * 64

@@ -6,7 +6,8 @@ from qgs_amd import _lib
 if os.environ.get('RK_AB_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['RK_AB_LIB'])
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'm36.npz'))
 m = _lib.HipModel(int(g['ndim']), g['coo'], g['val'], g['jcoo'], g['jval'])
-for n, R, C in ((4096, 64, 64), (16384, 52, 52), (16384, 48, 48), (16384, 44, 44), (16384, 40, 40), (16384, 38, 38), (16384, 36, 36)):
+SHAPES = [tuple(int(v) for v in a.split('x')) for a in sys.argv[1:]] or [(20, 20), (24, 24), (28, 28), (20, 5), (36, 20), (36, 5), (30, 30)]
+for n, R, C in [(16384, r, c) for r, c in SHAPES]:
     a = torch.randn((R, C, n), dtype=torch.float64, device='cuda'); rd = torch.zeros((C, n), dtype=torch.float64, device='cuda'); w = a.clone()
     m.batched_qr_device(n, n, R, C, w.data_ptr(), rd.data_ptr()); torch.cuda.synchronize()
     q = w[:, :, :2].cpu().numpy().transpose(2, 0, 1); a2 = a[:, :, :2].cpu().numpy().transpose(2, 0, 1)
