@@ -569,8 +569,9 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                         'traffic_over_algorithmic': (qr_traffic / qr_bytes) if qr_traffic else None,
                         'effective_clock_ghz': clk_qr[0] if clk_qr else None,
                         'max_abs_err_vs_lapack': qr_err, 'lapack_tolerance': 1e-12, 'lapack_ok': bool(qr_err < 1e-12),
-                        'note': '16 384 matrices of 36 x 36 in, Q and diag(R) out; the time is the 70 dependent reflector steps '
-                                '(one barrier and one LDS broadcast each), not the memory system: profiles/r05_qr.md'},
+                        'note': '16 384 matrices of 36 x 36 in, Q and diag(R) out, four matrices per wavefront; the time is the fp64 '
+                                'instruction stream of the 70 dependent reflector steps at two wavefronts per SIMD (the matrices fill '
+                                'the registers), not the memory system: profiles/r05_qr.md'},
         'roofline': {'bound': 'fp64_valu', 'achieved': rate * flops_tgls / 1e12, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                      'frac': rate * flops_tgls / 1e12 / FP64_VALU_PEAK_TFLOPS,
                      'flops_per_traj_step': flops_tgls,

@@ -396,16 +396,24 @@ __device__ __forceinline__ f64 qgs_fma3(f64 a, f64 b, f64 c)
 // compiler forms a 64-bit vector address with one v_lshl_add_u64 per store instead (a VALU slot for a lone wavefront), also
 // when base and offset are handed to it separately; an opaque offset per store costs a v_mov_b32 each.  The store is not
 // tracked by the compiler's vmcnt bookkeeping, which only makes its own waits more conservative.
+// The compiler does not look inside inline assembly for the hazards of what is in it, so the two that a store has are closed here:
+//  * an SGPR written by a VALU instruction (v_readlane_b32 reloading a spilled SGPR, v_readfirstlane_b32) must not be the address
+//    of a vector-memory instruction within five wait states: the address goes through an s_mov_b64 inside the statement -- a
+//    scalar instruction may read such an SGPR at once, and what IT writes may be used at once;
+//  * the data registers of a store of more than 64 bits must not be written by the next VALU instructions (two wait states on
+//    gfx94x / gfx950): the 128-bit form ends with the wait.
 __device__ __forceinline__ void qgs_store_row(f64* row, unsigned lane8, f64 v)
 {
-    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"(lane8), "v"(v), "s"(row) : "memory");
+    f64* r;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx2 %1, %2, %0" : "=&s"(r) : "v"(lane8), "v"(v), "s"(row) : "memory");
 }
 typedef double qgs_d2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void qgs_store_row2(f64* row, unsigned lane16, f64 a, f64 b)
 {
     qgs_d2 pr;
     pr.x = a; pr.y = b;
-    asm volatile("global_store_dwordx4 %0, %1, %2" :: "v"(lane16), "v"(pr), "s"(row) : "memory");
+    f64* r;
+    asm volatile("s_mov_b64 %0, %3\n\tglobal_store_dwordx4 %1, %2, %0\n\ts_nop 1" : "=&s"(r) : "v"(lane16), "v"(pr), "s"(row) : "memory");
 }
 // a uniform double (SGPR pair) into a vector register with one v_mov_b64
 __device__ __forceinline__ f64 qgs_mov64(f64 c)

@@ -10,7 +10,7 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s tensor.txt tend|rk|rksplit|rkstages|rklds|tgllds|adjlds [S]\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s tensor.txt tend|rk|rksplit|rkstages|rkstagesp|rkrec|tgl|tglp|rklds|tgllds|adjlds [S]\n", argv[0]); return 2; }
     FILE *f = std::fopen(argv[1], "r");
     if (!f) { std::perror(argv[1]); return 1; }
     int ndim; long nnz;
@@ -33,12 +33,14 @@ int main(int argc, char **argv)
     else if (!std::strcmp(argv[2], "rksplit")) k = qgs::Kernel::RkSplit;
     else if (!std::strcmp(argv[2], "rkstages")) k = qgs::Kernel::RkStages;
     else if (!std::strcmp(argv[2], "rkrec")) k = qgs::Kernel::RkRec;
+    else if (!std::strcmp(argv[2], "rkstagesp")) k = qgs::Kernel::RkStagesPair;
+    else if (!std::strcmp(argv[2], "tglp")) k = qgs::Kernel::TglPair;
     else if (!std::strcmp(argv[2], "tgl")) k = qgs::Kernel::Tgl;
     else if (!std::strcmp(argv[2], "rklds")) k = qgs::Kernel::RkLds;
     else if (!std::strcmp(argv[2], "tgllds")) k = qgs::Kernel::TglLds;
     else if (!std::strcmp(argv[2], "adjlds")) k = qgs::Kernel::AdjLds;
     std::vector<qgs::Term> J;                       // Jacobian tensor = T + T.swapaxes(1, 2) (qgtensor.py:700-722)
-    if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds || k == qgs::Kernel::Tgl)
+    if (k == qgs::Kernel::TglLds || k == qgs::Kernel::AdjLds || k == qgs::Kernel::Tgl || k == qgs::Kernel::TglPair)
         for (const qgs::Term &t : T) { J.push_back(t); J.push_back({t.i, t.k, t.j, t.v}); }
     std::cout << qgs::generate_kernel(ndim, T, J, k, S, opt).source;
     return 0;
