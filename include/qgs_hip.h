@@ -220,6 +220,12 @@ int qgs_pack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_
 int qgs_unpack_states(qgs_model *m, int64_t n_traj, int64_t ld, const double *d_x_modes, double *d_x_rows, void *stream);
 /* tangent vectors / matrices: (n_traj, ndim, n_tg) host-layout device buffer -> F[ndim][n_tg][ld] */
 int qgs_pack_tangent(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, const double *d_rows, double *d_modes, void *stream);
+
+/* d_out[i] = log|d_rdiag[i]| / dt for i < n (device pointers; in place allowed): the local Lyapunov exponents of one Benettin
+ * interval from diag(R) of its QR step, `np.log(np.abs(np.diag(r))) / dt` of qgs/toolbox/lyapunov.py:531, 611 -- on the device, so
+ * that the exponents leave in the record windows as they are (the host pass over the finished block took as long as a third of
+ * the transfer of a 72 GB record). */
+int qgs_local_exponents_device(qgs_model *m, int64_t n, const double *d_rdiag, double dt, double *d_out, void *stream);
 /* R[n_records][ndim][ld]  ->  (n_traj, ndim, n_records) */
 int qgs_unpack_records(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_inner, int64_t n_records,
                        const double *d_rec_modes, double *d_rec_rows, void *stream);

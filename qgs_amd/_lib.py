@@ -60,6 +60,7 @@ SIGNATURES = {
     'qgs_pack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_states': (_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'qgs_pack_tangent': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'qgs_local_exponents_device': (_int, [_vp, _i64, _vp, ctypes.c_double, _vp, _vp]),
     'qgs_unpack_records': (_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_window': (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     'qgs_unpack_window_enqueue': (_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
@@ -184,7 +185,7 @@ class _Store(object):
     #: blocks above this size are never page-locked (QGS_HOST_PIN_MAX_BYTES, default 256 GiB)
     PIN_MAX_BYTES = int(os.environ.get('QGS_HOST_PIN_MAX_BYTES', str(256 << 30)))
 
-    def __init__(self, n_doubles, pinned=True):
+    def __init__(self, n_doubles, pinned=True, huge=True):
         self.size = n_doubles
         self.nbytes = 8 * n_doubles
         self._ptr = None
@@ -199,7 +200,10 @@ class _Store(object):
             self.array = np.frombuffer((ctypes.c_char * self.nbytes).from_address(self._ptr), dtype=np.float64)
         else:
             self.array = np.empty(n_doubles)
-            if self.nbytes >= (64 << 20):
+            # huge pages for a block that is filled in strided runs (a window of records at a time: every window reaches every
+            # page); a block filled front to back by the host threads is better off without them -- a 2 MiB fault under two
+            # threads' feet serialises them (72 GB estimator record: 1.8 - 2.1 s without, 2.0 - 3.1 s with, profiles/r05_lyap_big.md)
+            if huge and self.nbytes >= (64 << 20):
                 _advise_huge_pages(self.array)
         self._pinned = self._ptr is not None
 
@@ -247,7 +251,9 @@ class _ResultPool(object):
         self._cap = int(os.environ.get('QGS_HOST_POOL_BYTES', str(4 << 30)))
         self._lock = threading.Lock()          # the shards of a device group may ask for blocks from their own threads
 
-    def empty(self, shape):
+    def empty(self, shape, pinned=True, huge=True):
+        """`pinned=False`: a new block is not page-locked (a caller whose result is far larger than what the pool keeps, and reaches
+        the host through the bounce ring anyway: page-locking its small side blocks costs more than it saves, 0.12 s per 1.9 GB)."""
         n = int(np.prod(shape))
         if n * 8 < self.MIN_BYTES or self._cap <= 0:
             return np.empty(shape)
@@ -259,12 +265,16 @@ class _ResultPool(object):
                 store = lst.pop()
                 self._held -= store.nbytes
         if store is None:
-            store = _Store(size, pinned=size * 8 <= self._cap)          # (a block the pool could never keep is not page-locked)
+            store = _Store(size, pinned=pinned and size * 8 <= self._cap, huge=huge)      # (a block the pool could never keep is not page-locked)
         return np.asarray(_PooledBlock(self, store, shape))
+
+    @property
+    def cap(self):
+        return self._cap
 
     def _give_back(self, store):
         with self._lock:
-            if self._held + store.nbytes <= self._cap:
+            if store._pinned and self._held + store.nbytes <= self._cap:          # (only page-locked blocks are worth keeping)
                 self._free.setdefault(store.size, []).append(store)
                 self._held += store.nbytes
 
@@ -485,6 +495,10 @@ class HipModel(object):
 
     def pack_tangent(self, n_traj, ld, n_tg, d_rows, d_modes, stream=0):
         _check(lib().qgs_pack_tangent(self._h, n_traj, ld, int(n_tg), d_rows, d_modes, stream or None))
+
+    def local_exponents_device(self, n, d_rdiag, dt, d_out, stream=0):
+        """d_out[i] = log|d_rdiag[i]| / dt, i < n (qgs_local_exponents_device)."""
+        _check(lib().qgs_local_exponents_device(self._h, int(n), d_rdiag, float(dt), d_out, stream or None))
 
     def unpack_records(self, n_traj, ld, n_inner, nrec, d_in, d_out, stream=0):
         _check(lib().qgs_unpack_records(self._h, n_traj, ld, n_inner, nrec, d_in, d_out, stream or None))

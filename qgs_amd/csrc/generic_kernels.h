@@ -161,6 +161,8 @@ void launch_unpack_records(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t 
 // window's first record column of a (n_traj, n_inner, out_stride) array (device memory or device-accessible host memory)
 void launch_unpack_window(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W, int64_t out_stride, const double *in,
                           double *out, hipStream_t st);
+// out[i] = log|rdiag[i]| / dt, i < n: the local Lyapunov exponents of one Benettin interval from the diagonal of its R
+void launch_local_exponents(int64_t n, const double *rdiag, double dt, double *out, hipStream_t st);
 // tangent IC: host (n_traj, ndim, n_tg) -> F[ndim][n_tg][ld]
 void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st);
 // tangent records: F[n_records][ndim][n_tg][ld] -> (n_traj, ndim, n_tg, n_records): same as unpack_records with

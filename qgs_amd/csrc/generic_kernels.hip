@@ -1381,6 +1381,18 @@ void launch_unpack_window(int64_t n_inner, int64_t n_traj, int64_t ld, int64_t W
                        n_inner, n_traj, ld, W, out_stride, in, out);
 }
 
+// local Lyapunov exponents of one Benettin interval: out = log|diag R| / dt  (qgs/toolbox/lyapunov.py:531, 611)
+__global__ void __launch_bounds__(256) local_exponents_kernel(int64_t n, const double *__restrict__ rdiag, double dt, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = log(fabs(rdiag[i])) / dt;
+}
+
+void launch_local_exponents(int64_t n, const double *rdiag, double dt, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(local_exponents_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, n, rdiag, dt, out);
+}
+
 void launch_pack_tangent(int ndim, int64_t n_tg, int64_t n_traj, int64_t ld, const double *rows, double *modes, hipStream_t st)
 {
     const int64_t n_inner = (int64_t)ndim * n_tg;

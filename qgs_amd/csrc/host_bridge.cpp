@@ -409,6 +409,15 @@ static int wait_for(int64_t ticket, bool done, std::string *err)
     return set_err(err, msg);
 }
 
+int bridge_poll_copied(int64_t ticket)
+{
+    if (ticket <= 0) return 1;
+    Device *d = device_state((int)(ticket % MAX_DEVICES));
+    if (!d) return 1;
+    std::lock_guard<std::mutex> lock(d->mu);
+    return d->copied_upto >= ticket / MAX_DEVICES ? 1 : 0;
+}
+
 int bridge_wait_copied(int64_t ticket, std::string *err) { return wait_for(ticket, false, err); }
 int bridge_wait_done(int64_t ticket, std::string *err) { return wait_for(ticket, true, err); }
 

@@ -36,6 +36,7 @@ int bridge_d2h(void *dst_host, const void *src_dev, size_t bytes, hipStream_t st
 int64_t bridge_d2h_rows_async(char *dst_host, size_t dst_pitch, const char *src_dev, size_t row_bytes, size_t rows, hipEvent_t ready,
                               std::string *err);
 int bridge_wait_copied(int64_t ticket, std::string *err);
+int bridge_poll_copied(int64_t ticket);          // 1: the device block of that job has been read completely (or the job failed), 0: not yet
 int bridge_wait_done(int64_t ticket, std::string *err);
 
 // counters for tests and measurements (process-wide): bytes that went through bounce blocks in each direction, jobs queued

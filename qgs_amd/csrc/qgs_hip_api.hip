@@ -976,7 +976,7 @@ struct qgs_model {
     int magnitude_ulp = qgs::DEFAULT_MAGNITUDE_ULP;     // coefficient classes of the specialised kernels (QGS_HIP_MAGNITUDE_ULP, codegen.h Canonical)
     std::vector<int64_t> drain_tickets;                // windows on their way into pageable host memory (host_bridge.h), oldest first
     std::map<const Buffer *, DrainSlot> drain_slots;   // per staging block: its window in flight, the event that marks its unpack
-    std::map<uintptr_t, std::unique_ptr<Buffer>> drain_staging;   // qgs_unpack_window_enqueue: one staging block per destination array
+    std::vector<std::unique_ptr<Buffer>> drain_pool;   // qgs_unpack_window_enqueue: staging blocks, reused as their windows leave the device
     unsigned *d_one_counter = nullptr;                 // "workgroups finished" word of the single-state kernels
     unsigned long long one_seq = 0;                    // sequence number of the last single-state call (the kernel echoes it into h_pin[0])
     // Jacobian tensor grouped by output element (generic_kernels.h OnePairs), models of up to 1024 variables
@@ -1702,7 +1702,7 @@ int qgs_model_destroy(qgs_model *m)
     }
     for (int64_t t : m->drain_tickets) (void)qgs::bridge_wait_done(t, nullptr);
     for (auto &kv : m->drain_slots) if (kv.second.ev) (void)hipEventDestroy(kv.second.ev);
-    for (auto &kv : m->drain_staging) kv.second->release();
+    for (auto &b : m->drain_pool) b->release();
     m->uploads.release();
     if (m->st_comp) (void)hipStreamDestroy(m->st_comp);
     if (m->st_copy) (void)hipStreamDestroy(m->st_copy);
@@ -1822,6 +1822,17 @@ int qgs_pack_tangent(qgs_model *m, int64_t n_traj, int64_t ld, int64_t n_tg, con
     if (n_tg < 1 || (int64_t)m->ndim * n_tg > (int64_t)65535 * 64 || !d_rows || !d_modes) return fail("bad n_tg / null pointer");
     HIPCHK(hipSetDevice(m->device));
     qgs::launch_pack_tangent(m->ndim, n_tg, n_traj, ld, d_rows, d_modes, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int qgs_local_exponents_device(qgs_model *m, int64_t n, const double *d_rdiag, double dt, double *d_out, void *stream)
+{
+    if (!m) return fail("null model");
+    if (n < 1 || !d_rdiag || !d_out) return fail("bad n / null pointer");
+    if (!(dt != 0.0)) return fail("dt must not be zero");
+    HIPCHK(hipSetDevice(m->device));
+    qgs::launch_local_exponents(n, d_rdiag, dt, d_out, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -2488,15 +2499,51 @@ static int drain_finish(qgs_model *m)
 // staging blocks of qgs_unpack_window_enqueue (nothing of them in flight any more)
 static void release_drain_staging(qgs_model *m)
 {
-    for (auto &kv : m->drain_staging) {
-        auto it = m->drain_slots.find(kv.second.get());
+    for (auto &b : m->drain_pool) {
+        auto it = m->drain_slots.find(b.get());
         if (it != m->drain_slots.end()) {
             if (it->second.ev) (void)hipEventDestroy(it->second.ev);
             m->drain_slots.erase(it);
         }
-        kv.second->release();
+        b->release();
     }
-    m->drain_staging.clear();
+    m->drain_pool.clear();
+}
+
+// A staging block of `need` bytes for the next window of qgs_unpack_window_enqueue.  The windows of one flush (vectors, states,
+// exponents of a record window) and of consecutive flushes (the next record window, the next member group) want different blocks,
+// so that none of them waits for the DMA of another inside the call -- the host would sit through a transfer and enqueue the next
+// kernels only afterwards.  In this order: an idle block (its last window has left the device) of about the right size; a new
+// block while the pool stays within a quarter of the device's memory; any idle block (grown if too small); else the block whose
+// window was handed to the drain thread first (drain_window waits for that window to have left the device).
+static Buffer *acquire_drain_staging(qgs_model *m, size_t need)
+{
+    size_t pool_bytes = 0;
+    Buffer *fit = nullptr, *loose = nullptr, *small = nullptr, *oldest = nullptr;
+    int64_t oldest_ticket = 0;
+    for (auto &b : m->drain_pool) {
+        pool_bytes += b->cap;
+        const DrainSlot &s = m->drain_slots[b.get()];
+        if (s.ticket == 0 || qgs::bridge_poll_copied(s.ticket)) {
+            if (b->cap >= need && b->cap / 4 <= need) { if (!fit || b->cap < fit->cap) fit = b.get(); }
+            else if (b->cap >= need) { if (!loose || b->cap < loose->cap) loose = b.get(); }
+            else if (!small || b->cap > small->cap) small = b.get();
+        } else if (!oldest || s.ticket < oldest_ticket) {
+            oldest = b.get();
+            oldest_ticket = s.ticket;
+        }
+    }
+    if (fit) return fit;
+    size_t free_b = 0, total_b = 0;
+    const bool room = m->drain_pool.size() < 16 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && pool_bytes + need <= total_b / 4 &&
+                      need <= free_b / 2;
+    if (room || m->drain_pool.empty()) {
+        m->drain_pool.push_back(std::make_unique<Buffer>());
+        return m->drain_pool.back().get();
+    }
+    if (loose) return loose;
+    if (small) return small;
+    return oldest;
 }
 
 // one window of records leaves the device (enqueued on st): alias != null -> stores of the unpack kernel; else staging, then
@@ -2515,14 +2562,23 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
     std::string err;
     DrainSlot &slot = m->drain_slots[&staging];
     if (slot.ticket > 0 && qgs::bridge_wait_copied(slot.ticket, &err)) return fail(err);
+    // (and whatever a stream still does with the block -- the copy of a page-locked destination below, enqueued by a caller on
+    // another stream: the blocks of qgs_unpack_window_enqueue are shared by all callers of the model)
+    if (slot.ev) HIPCHK(hipStreamWaitEvent(st, slot.ev, 0));
+    if (staging.cap < sizeof(double) * rows * (size_t)Wk && slot.ev) HIPCHK(hipEventSynchronize(slot.ev));     // (about to be freed)
     if (staging.ensure(sizeof(double) * rows * (size_t)Wk)) return -1;
     qgs::launch_unpack_window(n_inner, n_traj, ld, Wk, Wk, d_win, staging.f64(), st);
     HIPCHK(hipGetLastError());
     if (pinned) {
         // page-locked destination (QGS_HIP_D2H=copy, or one window): one (strided) DMA copy
-        if (Wk == n_records) return copy_d2h(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, st);
-        HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
-                                sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
+        if (Wk == n_records) {
+            if (copy_d2h(dst_host, staging.p, sizeof(double) * rows * (size_t)Wk, st)) return -1;
+        } else {
+            HIPCHK(hipMemcpy2DAsync(dst_host + lo_s, sizeof(double) * (size_t)n_records, staging.p, sizeof(double) * (size_t)Wk,
+                                    sizeof(double) * (size_t)Wk, rows, hipMemcpyDeviceToHost, st));
+        }
+        if (!slot.ev) HIPCHK(hipEventCreateWithFlags(&slot.ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(slot.ev, st));
         return 0;
     }
     // pageable destination: rows of Wk doubles -> runs `n_records` doubles apart, by the device's drain thread.  The event marks
@@ -2619,18 +2675,8 @@ int qgs_unpack_window_enqueue(qgs_model *m, int64_t n_traj, int64_t ld, int64_t 
     HIPCHK(hipSetDevice(m->device));
     double *alias = device_alias(m, dst, sizeof(double) * (size_t)n_traj * (size_t)n_inner * (size_t)n_records);
     if (alias) return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, m->b_drain, (hipStream_t)stream);
-    // one staging block per destination array: the caller's windows (vectors, states, exponents of one record window) are then
-    // staged without one waiting for the DMA of the other -- with a single block the host sat through the vectors' transfer
-    // inside this call and enqueued the next window's kernels only afterwards (no overlap of compute and transfer at all)
-    auto it = m->drain_staging.find((uintptr_t)dst);
-    if (it == m->drain_staging.end()) {
-        if (m->drain_staging.size() >= 8) {                       // (a caller that never calls qgs_drain_wait)
-            if (drain_finish(m)) return -1;
-            release_drain_staging(m);
-        }
-        it = m->drain_staging.emplace((uintptr_t)dst, std::make_unique<Buffer>()).first;
-    }
-    return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, *it->second, (hipStream_t)stream);
+    Buffer *staging = acquire_drain_staging(m, sizeof(double) * (size_t)n_traj * (size_t)n_inner * (size_t)n_window);
+    return drain_window(m, n_inner, n_traj, ld, n_window, n_records, first_record, d_window, alias, dst, *staging, (hipStream_t)stream);
 }
 
 int qgs_drain_wait(qgs_model *m)

@@ -247,11 +247,14 @@ class _RecordWindows(object):
         self.used = None
         self.flushed += 1
 
-    def finish(self):
+    def finish(self, wait=True):
+        """Hand the last window over; `wait=False`: the caller waits for the drain itself (`HipModel.drain_wait`), after it has
+        enqueued more work -- the member groups of `LyapunovsEstimator._compute_shard`."""
         self._flush()
-        self.copy.synchronize()
-        self.compute.synchronize()
-        self.m.drain_wait()
+        if wait:
+            self.copy.synchronize()
+            self.compute.synchronize()
+            self.m.drain_wait()
 
 
 def _in_threads(work, count):
@@ -401,26 +404,30 @@ class LyapunovsEstimator(object):
             raise MemoryError('host memory: the records of this run (%d members x %d records x (%d x %d vectors + state + exponents)) '
                               'need %.1f GB, %.1f GB are available -- raise write_steps, or lower n_vec or the number of members'
                               % (nt, nr, nd, nv, need / 1e9, avail / 1e9))
+        model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
+        shards = getattr(model, 'models', None)
         try:
-            out_traj = _lib._RESULTS.empty((nt, nd, nr))
-            out_vec = _lib._RESULTS.empty((nt, nd, nv, nr))
-            out_exp = _lib._RESULTS.empty((nt, nv, nr))
-            out_pre = _lib._RESULTS.empty((nt, nd, nv, nr)) if pre_qr else None
+            pin = need <= _lib._RESULTS.cap          # (a record beyond what the pool keeps travels through the bounce ring: no page-locking)
+            # (member groups fill their pieces of the blocks front to back: no huge pages, `_lib._Store`)
+            import torch
+            huge = shards is not None or self._member_groups(torch, model, nt, pre_qr)[0] >= nt
+            out_traj = _lib._RESULTS.empty((nt, nd, nr), pin, huge)
+            out_vec = _lib._RESULTS.empty((nt, nd, nv, nr), pin, huge)
+            out_exp = _lib._RESULTS.empty((nt, nv, nr), pin, huge)
+            out_pre = _lib._RESULTS.empty((nt, nd, nv, nr), pin, huge) if pre_qr else None
         except MemoryError:
             raise MemoryError('host memory: could not allocate %.1f GB for the records of this run' % (need / 1e9))
 
         # random start bases: the matrices are drawn like the reference's (one draw per trajectory, in order:
         # `np.random.random((ndim, nv))` consumes the generator exactly as n such calls in a row do) -- for the WHOLE ensemble
         # before it is split over devices
-        if a0 is None:
-            a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))
+        if a0 is None and shards is not None:
+            a0 = np.random.random((self.n_traj, self.n_dim, self.n_vec))        # (one GPU: drawn by `_compute_shard`, possibly in pieces)
         self._junction = np.zeros((nt, nd)) if junction else None
         outs = (out_traj, out_vec, out_exp) + ((out_pre,) if pre_qr else ())
 
         def piece(a, cnt):
             return tuple(o[a:a + cnt] for o in outs) + ((self._junction[a:a + cnt],) if junction else (None,))
-        model = _fn.hip_model_of(self.func, device=_fn.resolve_device(self.device, self.n_traj))
-        shards = getattr(model, 'models', None)
         if shards is None:
             self.last_windows = [self._compute_shard(model, self.ic, a0, mdt, piece(0, nt))]
         else:
@@ -439,12 +446,63 @@ class LyapunovsEstimator(object):
     def _compute_shard(self, m, ic, a0, mdt, outs):
         """The Benettin loops for the members `ic` (n, n_dim) with start matrices `a0` (n, n_dim, n_vec) on model `m`'s GPU;
         fills the slices `outs` = (traj, vectors, exponents[, matrices before the QR], junction state or None) of the result
-        blocks (reference layouts)."""
+        blocks (reference layouts).
+
+        Records that do not fit the device window in one piece leave in MEMBER GROUPS where the ensemble is large enough: the
+        loops run group after group, each group's whole record is one window, and since the result blocks are member-major
+        (n_traj, ..., n_records) a group's window is ONE contiguous piece of each of them -- the drain thread streams it while
+        the next group is computed.  Windows of records (the route for few members, or a budget set by hand) reach every page of
+        the result blocks once per window in runs of 8 W bytes, which is what held the 72 GB run at 25 - 30 GB/s
+        (profiles/r05_lyap_big.md).  Members are independent: a group's results are those of a run of just these members (as for
+        the shards of a device list; kernels are chosen by ensemble size, so against one pass over all members they agree to
+        rounding, not bitwise)."""
         import torch
         with torch.cuda.device(torch.device('cuda', m.device)):       # this thread's current device for the duration of the call only
-            return self._compute_shard_on_current_device(m, ic, a0, mdt, outs)
+            n = ic.shape[0]
+            group, budget = self._member_groups(torch, m, n, len(outs) > 4)
+            if group >= n:
+                if a0 is None:
+                    a0 = np.random.random((n, self.n_dim, self.n_vec))
+                return self._compute_shard_on_current_device(m, ic, a0, mdt, outs)
+            info = []
+            try:
+                for lo in range(0, n, group):
+                    cnt = min(group, n - lo)
+                    part = tuple(None if o is None else o[lo:lo + cnt] for o in outs)
+                    # (start matrices not drawn yet -- `_run` on one GPU: drawn group by group, the same numbers in the same order,
+                    # while the previous group's record is on its way)
+                    a0g = a0[lo:lo + cnt] if a0 is not None else np.random.random((cnt, self.n_dim, self.n_vec))
+                    info.append(self._compute_shard_on_current_device(m, ic[lo:lo + cnt], a0g, mdt, part, budget, True))
+            finally:
+                torch.cuda.current_stream().synchronize()
+                m.drain_wait()                                         # nothing on its way into the result blocks when they are handed out
+            return max(i[0] for i in info), max(i[1] for i in info)
 
-    def _compute_shard_on_current_device(self, m, ic, a0, mdt, outs):
+    def _member_groups(self, torch, m, n, pre_qr):
+        """(members per group, record-window budget of a group); a group of `n` members or more: one pass, the default budget.
+        `QGS_HIP_RECORD_GROUP_MEMBERS` sets the group size by hand (tests); a record-window budget set by hand
+        (`QGS_HIP_RECORD_WINDOW_MB`) keeps the windows of records."""
+        nd, nv, nr = self.n_dim, self.n_vec, self.n_records
+        per_member = 8 * nr * (nd * nv * (2 if pre_qr else 1) + nd + nv)
+        forced = os.environ.get('QGS_HIP_RECORD_GROUP_MEMBERS')
+        if forced:
+            g = max(64, (int(forced) + 63) // 64 * 64)
+            return g, 2 * per_member * g + (1 << 20)
+        if 'QGS_HIP_RECORD_WINDOW_MB' in os.environ:
+            return n, None
+        free, _total = torch.cuda.mem_get_info(torch.device('cuda', m.device))
+        one_window = max(_window_budget_bytes() // 2, min(free // 16, 12 << 30)) // 2       # what one window of records may hold
+        if per_member * n <= one_window:
+            return n, None
+        # a group's window + its staging block, two groups in flight: within a third of the free memory; eight groups or more where
+        # that leaves 2 048 members per group (the tangent kernels fill the GPU from there), never fewer than 1 024
+        cap = (free // 3) // (4 * per_member) // 64 * 64
+        g = min(cap, max(2048, -(-n // 8 + 63) // 64 * 64))
+        if g < 1024 or g >= n:
+            return n, None
+        return int(g), 2 * per_member * int(g) + (1 << 20)
+
+    def _compute_shard_on_current_device(self, m, ic, a0, mdt, outs, rec_budget=None, grouped=False):
         import torch
         forward, adjoint, write_steps = self._forward == 1, self._adjoint, self.write_steps
         ndim, nv, n = self.n_dim, self.n_vec, ic.shape[0]
@@ -497,13 +555,13 @@ class LyapunovsEstimator(object):
         # at config-4 size half of the default budget gives W = 11 -- 88-byte runs, a page apart.  Unless the budget was set by hand,
         # the record windows take up to a sixteenth of the GPU's free memory, at most 12 GiB (W = 36 there; measured over budgets
         # of 8 / 16 / 32 / 64 GiB in profiles/r05_lyap_big.md: longer windows cost more start-up and tail than their runs gain).
-        rec_budget = budget // 2
-        if 'QGS_HIP_RECORD_WINDOW_MB' not in os.environ:
-            free, _total = torch.cuda.mem_get_info(dev)
-            rec_budget = max(rec_budget, min(free // 16, 12 << 30))
+        if rec_budget is None:
+            rec_budget = budget // 2
+            if 'QGS_HIP_RECORD_WINDOW_MB' not in os.environ:
+                free, _total = torch.cuda.mem_get_info(dev)
+                rec_budget = max(rec_budget, min(free // 16, 12 << 30))
         rec = _RecordWindows(torch, m, n, ld, (ndim * nv, ndim, nv) + ((ndim * nv,) if out_pre is not None else ()),
                              (out_vec, out_traj, out_exp) + ((out_pre,) if out_pre is not None else ()), self.n_records, rec_budget, dev)
-        rec_dt = np.ones(self.n_records)                             # interval length behind each record's exponents
 
         def propagate(y_index, subtime, direction, pre=None):
             """q <- Q of QR( TL_{subtime}(q) ) along the trajectory started at base[y_index]; returns diag(R).
@@ -526,10 +584,10 @@ class LyapunovsEstimator(object):
             s_traj.copy_(base.state(at[y_index]))
             s_vec.copy_(q.reshape(ndim * nv, ld))
             if rdiag is None:
-                s_rd.fill_(1.0)
+                s_rd.zero_()
             else:
-                s_rd.copy_(rdiag)
-                rec_dt[iw] = d
+                # log|diag R| / dt on the device (lyapunov.py:531, 611): the exponents leave in the window as they are
+                m.local_exponents_device(nv * ld, rdiag.data_ptr(), d, s_rd.data_ptr(), stream)
             if out_pre is not None:
                 slots[3].zero_()                   # (stays zero for a record no interval follows)
                 return slots[3]
@@ -582,11 +640,7 @@ class LyapunovsEstimator(object):
                 rdiag = propagate(y_idx, sub, -1)
             record(0, y_idx, last[0] if last else None, last[1] if last else 1.0)
 
-        rec.finish()
-        # exponents from the recorded diagonals, in place on the host block: log|diag R| / dt
-        np.abs(out_exp, out=out_exp)
-        np.log(out_exp, out=out_exp)
-        out_exp /= rec_dt
+        rec.finish(wait=not grouped)               # (a member group: the caller waits for the drain after the last group)
         return base.n_windows, rec.n_windows
 
     def get_lyapunovs(self):
@@ -956,14 +1010,13 @@ class CovariantLyapunovsEstimator(object):
         out_traj, out_vec, out_exp = outs
         rec = _RecordWindows(torch, m, n, ld, (nd * nv, nd, nv), (out_vec, out_traj, out_exp), self.n_records, budget // 2, dev)
         dte = np.concatenate((np.diff(self._time), np.full((1,), self._aftertime[1] - self._aftertime[0])))
-        rec_dt = np.ones(self.n_records)
 
         def record(index, ti):
             s_vec, s_traj, s_norm = rec.slot(index)
             m.batched_matmul_device(n, ld, nd, nv, nv, q_all[ti].data_ptr(), am.data_ptr(), s_vec.data_ptr(), triangular=2, stream=stream)
             s_traj.copy_(t_all[ti])
-            s_norm.copy_(norm)
-            rec_dt[index] = dte[ti]
+            # local exponents from the norms of the backward step, on the device: -log|norm| / dt   (lyapunov.py:1280, 1285)
+            m.local_exponents_device(nv * ld, norm.data_ptr(), -dte[ti], s_norm.data_ptr(), stream)
         iw = 1
         for k, ti in enumerate(range(tw, -1, -1)):
             m.clv_backstep_device(n, ld, nv, r_all[ti].data_ptr(), am.data_ptr(), am_new.data_ptr(), norm.data_ptr(),
@@ -974,10 +1027,6 @@ class CovariantLyapunovsEstimator(object):
                 iw += 1
         record(0, 0)
         rec.finish()
-        # local exponents from the recorded norms, in place on the host block: -log|norm| / dt
-        np.abs(out_exp, out=out_exp)
-        np.log(out_exp, out=out_exp)
-        out_exp /= -rec_dt
         return t_forward - t_start, _clock.perf_counter() - t_forward
 
     def _subspaces(self, mdt, backward_vectors, forward_vectors):

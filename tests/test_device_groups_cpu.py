@@ -173,3 +173,39 @@ def test_subspace_intersection_matches_the_plain_loops_on_any_number_of_threads(
             for j in range(nd):
                 u = np.linalg.svd(bvec[i, :, :j + 1, r].T @ fvec[i, :, :nd - j, r])[0]
                 assert np.abs(one[i, r, :, j] - (bvec[i, :, :j + 1, r] @ u)[:, 0]).max() < 1e-14
+
+
+def test_estimator_member_groups(monkeypatch):
+    """Records that do not fit one device window leave in member groups when the ensemble is large (lyapunov.py
+    `_member_groups`): a group's record is one contiguous piece of the member-major result blocks.  The rule, on a fake device."""
+    from qgs_amd.toolbox.lyapunov import LyapunovsEstimator
+
+    class FakeTorch(object):
+        class cuda(object):
+            mem_get_info = staticmethod(lambda dev: (280 << 30, 288 << 30))
+        device = staticmethod(lambda *a: None)
+
+    class FakeModel(object):
+        device = 0
+    for k in ('QGS_HIP_RECORD_WINDOW_MB', 'QGS_HIP_RECORD_GROUP_MEMBERS'):
+        monkeypatch.delenv(k, raising=False)
+    est = LyapunovsEstimator(num_threads=1)
+    est.n_dim, est.n_vec, est.n_records = 36, 36, 401
+    per_member = 8 * 401 * (36 * 36 + 36 + 36)
+    g, budget = est._member_groups(FakeTorch, FakeModel, 16384, False)
+    assert g == 2048 and budget >= 2 * per_member * g                     # 72 GB: eight groups, each one window of all records
+    est.n_records = 1001
+    g, budget = est._member_groups(FakeTorch, FakeModel, 16384, False)
+    assert g == 2048 and 4 * (budget // 2) <= (280 << 30) // 3            # 180 GB: window + staging of two groups within a third
+    g, _ = est._member_groups(FakeTorch, FakeModel, 16384, True)          # with the matrices before the QR: twice the record
+    assert g % 64 == 0 and 1024 <= g < 2048
+    est.n_records = 11
+    assert est._member_groups(FakeTorch, FakeModel, 16384, False) == (16384, None)     # fits one window: one pass
+    est.n_records = 100001
+    assert est._member_groups(FakeTorch, FakeModel, 16384, False) == (16384, None)     # groups would be < 1 024 members: windows of records
+    est.n_records = 401
+    assert est._member_groups(FakeTorch, FakeModel, 1500, False)[0] == 1500            # few members: windows of records
+    monkeypatch.setenv('QGS_HIP_RECORD_WINDOW_MB', '512')
+    assert est._member_groups(FakeTorch, FakeModel, 16384, False) == (16384, None)     # a budget set by hand keeps the windows
+    monkeypatch.setenv('QGS_HIP_RECORD_GROUP_MEMBERS', '100')
+    assert est._member_groups(FakeTorch, FakeModel, 16384, False)[0] == 128            # by hand: rounded up to whole wavefronts

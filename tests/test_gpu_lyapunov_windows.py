@@ -73,6 +73,32 @@ def test_windowed_run_on_a_device_list(monkeypatch):
     f1.operands.release()
 
 
+@pytest.mark.parametrize('forward', [False, True])
+def test_member_groups_fill_their_slices(monkeypatch, forward):
+    """Records too large for one window leave in member groups when the ensemble is large (round 5: a group's record is one
+    contiguous piece of each result block).  Forced here at a small size: 5 groups of 192 members + one of 64; every group's
+    slice is bitwise what a run of just those members gives, and the whole agrees with one pass to rounding."""
+    est, f, ndim = _estimator()
+    ic = np.random.RandomState(5).rand(1024, ndim) * 0.01
+    monkeypatch.delenv('QGS_HIP_RECORD_WINDOW_MB', raising=False)
+    monkeypatch.delenv('QGS_HIP_RECORD_GROUP_MEMBERS', raising=False)
+    whole = _run(est, ic, forward, 1, 12)
+    monkeypatch.setenv('QGS_HIP_RECORD_GROUP_MEMBERS', '192')
+    grouped = _run(est, ic, forward, 1, 12)
+    assert grouped[4] == [(1, 1)]
+    for a, b, tol in zip(whole[1:4], grouped[1:4], (1e-12, 1e-8, 1e-9)):
+        assert a.shape == b.shape and np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max())
+    # the third group alone (the same random draws: the start matrices are drawn for the whole ensemble, in member order)
+    monkeypatch.delenv('QGS_HIP_RECORD_GROUP_MEMBERS', raising=False)
+    np.random.seed(11)
+    a0 = np.random.random((1024, ndim, 12))
+    est._run(est._pretime, est._time, 0.05, ic[384:576], 1, 12, forward, False, False, a0=a0[384:576])
+    for got, want in ((est._recorded_traj, grouped[1][384:576]), (est._recorded_exp, grouped[2][384:576]), (est._recorded_vec, grouped[3][384:576])):
+        assert np.array_equal(np.squeeze(got), want)
+    est.terminate()
+    f.operands.release()
+
+
 def test_record_larger_than_the_default_budget_reaches_the_host(monkeypatch):
     """Config-4 size (16 384 members x 36 vectors), every interval recorded: 179 MB per record, 3.8 GB of records against the
     default 8 GB budget (half of it for the two record windows) -- the record crosses in several windows.  The first members

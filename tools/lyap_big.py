@@ -33,7 +33,37 @@ np.random.seed(0)
 est.compute_lyapunovs(0., 1., 1.5, 0.1, 0.01, ic=ic[:256], write_steps=1)          # warm-up (kernels, pools)
 out = {'members': n, 'vectors': nv, 'recorded_intervals': intervals, 'record_gb': per_record * (intervals + 1) / 1e9,
        'host_available_gb': avail / 1e9, 'device_window_budget_mb': lyapunov._window_budget_bytes() / 1048576.0}
+if os.environ.get('QGS_LYAP_BIG_NO_THP') == '1':               # experiment: result blocks without MADV_HUGEPAGE
+    from qgs_amd import _lib as _l0
+    _l0._advise_huge_pages = lambda a: None
 np.random.seed(1)
+# host-side time line of the run: when each member group was handed to `_compute_shard_on_current_device`, how long the final wait
+# for the drain thread took (QGS_LYAP_BIG_TIMELINE=1)
+marks = []
+if os.environ.get('QGS_LYAP_BIG_TIMELINE') == '1':
+    inner = est._compute_shard_on_current_device
+
+    def timed(m, ic_, *a, **k):
+        marks.append(('group of %d enqueue starts' % ic_.shape[0], time.perf_counter()))
+        r = inner(m, ic_, *a, **k)
+        marks.append(('group enqueued', time.perf_counter()))
+        return r
+    est._compute_shard_on_current_device = timed
+
+    def wrap(obj, name, label):
+        fn = getattr(obj, name)
+
+        def w(*a, **k):
+            marks.append((label + ' starts', time.perf_counter()))
+            r = fn(*a, **k)
+            marks.append((label + ' done', time.perf_counter()))
+            return r
+        setattr(obj, name, w)
+    from qgs_amd import _lib as _l
+    wrap(lyapunov, '_host_memory_available', 'host memory check')
+    wrap(_l._RESULTS, 'empty', 'result block')
+    wrap(lyapunov._fn, 'hip_model_of', 'model lookup')
+    wrap(est, '_member_groups', 'group rule')
 t0 = time.perf_counter()
 est.compute_lyapunovs(0., 2., 2. + 0.1 * intervals, 0.1, 0.01, ic=ic, write_steps=1, n_vec=nv)
 el = time.perf_counter() - t0
@@ -45,6 +75,8 @@ for i in (0, n // 2, n - 1):
     for r in (0, intervals // 2, intervals):
         q = vecs[i, :, :, r]
         dev = max(dev, float(np.abs(q.T @ q - np.eye(nv)).max()))
+if marks:
+    out['timeline_s'] = [[name, round(t - t0, 3)] for name, t in marks] + [['returned', round(el, 3)]]
 out['max_orthonormality_defect'] = dev
 out['lambda_1_mean'] = float(np.mean(exps[:, 0, :]))
 print(json.dumps(out, indent=1))
