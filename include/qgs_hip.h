@@ -272,8 +272,9 @@ int qgs_ensemble_moments_device(qgs_model *m, int64_t n_traj, int64_t ld, int64_
 /* Batched QR of one (n_rows x n_cols) matrix per member, device layout A[row][col][member]: A is replaced by Q
  * (LAPACK Householder sign convention), d_rdiag[col][member] receives diag(R).  Replaces the per-trajectory
  * `np.linalg.qr` of the Benettin loops, qgs/toolbox/lyapunov.py:540-547, 599-628. */
-/* (n_rows <= 64: a kernel generated and compiled for the shape, columns in registers; n_cols <= 64 and n_rows <= 300: one
- * matrix per wavefront in LDS; anything larger, e.g. 228 x 228: one workgroup per matrix on a scratch copy in global memory.) */
+/* (n_cols <= 64 and n_rows <= 300: a kernel generated and compiled for the shape, the matrices in registers -- three layouts, see
+ * qgs_amd/csrc/codegen.h QrPlan; anything larger, e.g. the 228 x 228 bases of a full spectrum: one workgroup per matrix on a scratch
+ * copy in global memory, blocked (dgeqrf + dorgqr with 16-column panels) up to 400 rows, column by column beyond.) */
 int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, int n_cols,
                           double *d_a, double *d_rdiag, void *stream);
 

@@ -143,7 +143,8 @@ void launch_batched_matmul(int n_rows, int n_inner, int n_cols, int trans_a, int
 // a_out = columns of R^-1 a_in (+ noise * pert on the diagonal) scaled to unit norm, norm[col][member] = the norms
 void launch_clv_backstep(int nv, int64_t n_traj, int64_t ld, const double *rm, const double *a_in, double *a_out, double *norm,
                          const double *noise, double pert, hipStream_t st);
-// any shape (n_cols > 64 or matrices beyond the LDS): matrix in a global scratch copy, scratch = n_traj * (n_rows + 1) * n_cols doubles
+// any shape (n_cols > 64 or matrices beyond the LDS): matrix in a global scratch copy, blocked (dgeqrf + dorgqr, 16-column panels) up to
+// 400 rows; scratch = n_traj * ((n_rows + 17) * n_cols + 256) doubles
 void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
                               hipStream_t st);
 // mean / variance over the members of every row of X[row][member]; `part` holds 2 * n_rows * moments_splits() doubles

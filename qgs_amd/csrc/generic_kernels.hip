@@ -1234,9 +1234,256 @@ __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_ro
     for (int64_t e = tid; e < (int64_t)n_rows * n_cols; e += QRG_THREADS) a[e * ld + m] = B[e];
 }
 
+// Blocked Householder QR for matrices beyond the generated kernels (cols > 64: the full 228 x 228 bases of MAOOAM 6x6, the
+// reference's default n_vec = n_dim): LAPACK's dgeqrf + dorgqr with panels of NB = 16 columns (np.linalg.qr is these two routines,
+// qgs/toolbox/lyapunov.py:524, 603).  The unblocked kernel above reads and writes the whole trailing matrix once per column --
+// (2/3) n^3 x 16 bytes = 126 MB per 228 x 228 member through the L2, 30 ms for 1 024 members; here it is touched once per PANEL.
+// One workgroup of 256 threads per member, the member's matrix in a contiguous scratch copy B[row][col] in global memory.  Per panel:
+//  * the panel (rows j0 .., 16 columns) is factored in LDS, row-major with pitch 18 (128-bit reads of a row's 16 entries; 4-way
+//    bank conflicts for the column sweeps of the factorisation, which are a few per cent of the work): every wavefront forms the
+//    pivot's norm by itself (the same bits in all four), the remaining panel columns are dealt to the wavefronts, one barrier per step;
+//  * T of the compact WY form (dlarft: H_1 .. H_nb = I - V T V^T) from the Gram matrix of the reflectors;
+//  * the trailing columns X (rows j0 ..) become X - V T^T (V^T X): a thread owns two columns, accumulates its 2 x 16 entries of V^T X
+//    over the rows with V's row broadcast from LDS (16 FMAs per loaded element), multiplies by T^T in registers and makes a second
+//    pass for the update.  Consecutive threads hold consecutive columns: every global access is whole lines.
+// dorgqr walks the panels backwards with H = I - V T V^T (T kept from the first phase in scratch): the rows of R above and inside a
+// panel count as zeros on the way in, the panel's own columns start from the identity.
+constexpr int QRB_THREADS = 256, QRB_NB = 16, QRB_PITCH = 18, QRB_AHEAD = 8;
+
+// X(rows j0 .., columns c_first .. c_end - 1) -= V (U^T X) with U = V op(T) formed once per panel (qrb_form_u): the product with
+// the 16 x 16 triangle is then part of the first pass instead of 272 FMAs per thread on 136 LDS operands (which the compiler
+// loads all at once: 426 registers).  VIRT 0: X as stored; 1: the first nbk rows of X count as zeros (dorgqr: they hold entries of R).
+template <int VIRT>
+__device__ __forceinline__ void qrb_apply(double *__restrict__ B, const double *__restrict__ Vr, const double *__restrict__ Ur, int j0, int nbk,
+                                           int c_first, int c_end, int n_rows, int n_cols)
+{
+    // A thread owns two columns and every S-th row of them: S = 1, 2, 4 or 8 lanes of a wavefront share a column pair (the fewer
+    // pairs are left, the more), their partial U^T X meet through shuffles.  Consecutive lanes hold consecutive pairs: whole lines.
+    // The loads of QRB_AHEAD rows are issued before their FMAs: at one or two wavefronts per SIMD the loop is bound by their latency.
+    const int RR = n_rows - j0, ncp = (c_end - c_first + 1) / 2;
+    int sb = 0;
+    while (sb < 3 && (ncp << (sb + 1)) <= QRB_THREADS) ++sb;
+    const int S = 1 << sb, lanes_cp = WAVE >> sb, per_pass = (QRB_THREADS / WAVE) * lanes_cp;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slice = lane / lanes_cp;
+    const int first = VIRT == 1 ? nbk : 0;
+    for (int cp0 = 0; cp0 < ncp; cp0 += per_pass) {
+        const int cp = cp0 + wave * lanes_cp + (lane % lanes_cp);
+        const bool on = cp < ncp;
+        const int c = c_first + 2 * cp;
+        const bool two = on && c + 1 < c_end;
+        double w0[QRB_NB], w1[QRB_NB];
+#pragma unroll
+        for (int k = 0; k < QRB_NB; ++k) { w0[k] = 0.0; w1[k] = 0.0; }
+        double *col = B + (int64_t)j0 * n_cols + (on ? c : c_first);
+        for (int r0 = first + slice; r0 < RR; r0 += QRB_AHEAD * S) {
+            double xa[QRB_AHEAD], xb[QRB_AHEAD];
+#pragma unroll
+            for (int qq = 0; qq < QRB_AHEAD; ++qq) {
+                const int r = r0 + qq * S;
+                xa[qq] = (on && r < RR) ? col[(int64_t)r * n_cols] : 0.0;
+                xb[qq] = (two && r < RR) ? col[(int64_t)r * n_cols + 1] : 0.0;
+            }
+#pragma unroll
+            for (int qq = 0; qq < QRB_AHEAD; ++qq) {
+                const double *u = Ur + min(r0 + qq * S, RR - 1) * QRB_PITCH;
+#pragma unroll
+                for (int k = 0; k < QRB_NB; ++k) { w0[k] = __builtin_fma(u[k], xa[qq], w0[k]); w1[k] = __builtin_fma(u[k], xb[qq], w1[k]); }
+            }
+        }
+        for (int off = lanes_cp; off < WAVE; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < QRB_NB; ++k) { w0[k] += __shfl_xor(w0[k], off); w1[k] += __shfl_xor(w1[k], off); }
+        }
+        for (int r0 = slice; r0 < RR; r0 += QRB_AHEAD * S) {
+            double xa[QRB_AHEAD], xb[QRB_AHEAD];
+#pragma unroll
+            for (int qq = 0; qq < QRB_AHEAD; ++qq) {
+                const int r = r0 + qq * S;
+                const bool ld_ = r < RR && !(VIRT == 1 && r < nbk);
+                xa[qq] = (on && ld_) ? col[(int64_t)r * n_cols] : 0.0;
+                xb[qq] = (two && ld_) ? col[(int64_t)r * n_cols + 1] : 0.0;
+            }
+#pragma unroll
+            for (int qq = 0; qq < QRB_AHEAD; ++qq) {
+                const int r = r0 + qq * S;
+                const double *v = Vr + min(r, RR - 1) * QRB_PITCH;
+                double x0 = xa[qq], x1 = xb[qq];
+#pragma unroll
+                for (int k = 0; k < QRB_NB; ++k) { x0 = __builtin_fma(-v[k], w0[k], x0); x1 = __builtin_fma(-v[k], w1[k], x1); }
+                if (on && r < RR) col[(int64_t)r * n_cols] = x0;
+                if (two && r < RR) col[(int64_t)r * n_cols + 1] = x1;
+            }
+        }
+    }
+}
+
+// U = V T (TRANS_T: X - V T^T V^T X = X - V (V T)^T X) or V T^T, row-major like V; T upper triangular
+template <bool TRANS_T>
+__device__ __forceinline__ void qrb_form_u(const double *__restrict__ Vr, const double *__restrict__ T, double *__restrict__ Ur, int RR)
+{
+    for (int e = threadIdx.x; e < RR * QRB_NB; e += QRB_THREADS) {
+        const int r = e / QRB_NB, k = e % QRB_NB;
+        double acc = 0.0;
+        if (TRANS_T) { for (int mm = 0; mm <= k; ++mm) acc = __builtin_fma(Vr[r * QRB_PITCH + mm], T[mm * QRB_NB + k], acc); }
+        else { for (int mm = k; mm < QRB_NB; ++mm) acc = __builtin_fma(Vr[r * QRB_PITCH + mm], T[k * QRB_NB + mm], acc); }
+        Ur[r * QRB_PITCH + k] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(QRB_THREADS) batched_qr_blocked_kernel(int n_rows, int n_cols, int64_t n_traj, int64_t ld,
+                                                                         double *__restrict__ a, double *__restrict__ rdiag,
+                                                                         double *__restrict__ scratch, double *__restrict__ t_store, int skip)
+{
+    // (skip & 8: the matrix is in `scratch` already and stays there -- the launcher's transposes; 1, 2, 4: timing experiments of a
+    // developer build: no trailing update / no second phase / no panel factorisation, the results are then wrong)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Vr = (double *)smem;                           // panel, [row - j0][QRB_PITCH]
+    double *Ur = Vr + (size_t)n_rows * QRB_PITCH;          // V op(T), same layout
+    __shared__ __attribute__((aligned(16))) double T[QRB_NB * QRB_NB];
+    __shared__ double G[QRB_NB * QRB_NB];
+    __shared__ double taus[QRB_NB];
+    const int64_t m = qr_member(blockIdx.x, n_traj);
+    if (m >= n_traj) return;                               // (the whole workgroup)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = QRB_THREADS / WAVE;
+    double *B = scratch + (int64_t)m * n_rows * n_cols;
+    const int n_panels = (n_cols + QRB_NB - 1) / QRB_NB;
+    double *Tg = t_store + (int64_t)m * n_panels * (QRB_NB * QRB_NB);
+    if (!(skip & 8)) for (int64_t e = tid; e < (int64_t)n_rows * n_cols; e += QRB_THREADS) B[e] = a[e * ld + m];
+    __syncthreads();
+    for (int p = 0; p < n_panels; ++p) {                   // ---- dgeqrf
+        const int j0 = p * QRB_NB, nbk = min(QRB_NB, n_cols - j0), RR = n_rows - j0;
+        for (int e = tid; e < RR * QRB_NB; e += QRB_THREADS) {
+            const int r = e / QRB_NB, k = e % QRB_NB;
+            Vr[r * QRB_PITCH + k] = k < nbk ? B[(int64_t)(j0 + r) * n_cols + j0 + k] : 0.0;
+        }
+        T[tid] = 0.0;                                      // (QRB_THREADS == QRB_NB * QRB_NB)
+        __syncthreads();
+        for (int jj = 0; jj < ((skip & 4) ? 0 : nbk); ++jj) {                 // dgeqr2 on the panel
+            double p2 = 0.0;
+            for (int r = jj + 1 + lane; r < RR; r += WAVE) { const double x = Vr[r * QRB_PITCH + jj]; p2 = __builtin_fma(x, x, p2); }
+            const double xn2 = wave_sum(p2);
+            const double alpha = Vr[jj * QRB_PITCH + jj];
+            double t = 0.0, beta = alpha, scale = 0.0;
+            if (xn2 != 0.0) { beta = -copysign(sqrt(__builtin_fma(alpha, alpha, xn2)), alpha); t = (beta - alpha) / beta; scale = 1.0 / (alpha - beta); }
+            for (int kc = jj + 1 + wave; kc < nbk; kc += NW) {
+                double d = 0.0;
+                for (int r = jj + 1 + lane; r < RR; r += WAVE) d = __builtin_fma(Vr[r * QRB_PITCH + jj], Vr[r * QRB_PITCH + kc], d);
+                const double wv = t * __builtin_fma(scale, wave_sum(d), Vr[jj * QRB_PITCH + kc]);
+                const double nw = -(wv * scale);
+                for (int r = jj + 1 + lane; r < RR; r += WAVE) Vr[r * QRB_PITCH + kc] = __builtin_fma(nw, Vr[r * QRB_PITCH + jj], Vr[r * QRB_PITCH + kc]);
+                if (lane == 0) Vr[jj * QRB_PITCH + kc] -= wv;
+            }
+            __syncthreads();                               // every read of the unscaled column jj is done
+            if (wave == jj % NW) {
+                for (int r = jj + 1 + lane; r < RR; r += WAVE) Vr[r * QRB_PITCH + jj] *= scale;
+                if (lane == 0) {
+                    Vr[jj * QRB_PITCH + jj] = beta;
+                    taus[jj] = t;
+                    rdiag[(int64_t)(j0 + jj) * ld + m] = beta;
+                }
+            }
+        }
+        __syncthreads();
+        // the panel goes back (V below the diagonal, R on and above it); in LDS it becomes V itself: unit diagonal, zeros above
+        for (int e = tid; e < RR * nbk; e += QRB_THREADS) {
+            const int r = e / nbk, k = e % nbk;
+            B[(int64_t)(j0 + r) * n_cols + j0 + k] = Vr[r * QRB_PITCH + k];
+        }
+        __syncthreads();
+        if (tid < QRB_NB * QRB_NB) {
+            const int r = tid / QRB_NB, k = tid % QRB_NB;
+            if (r < RR && k >= r) Vr[r * QRB_PITCH + k] = (k == r && k < nbk) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // G[k][i] = v_k . v_i (k < i), pairs dealt to the wavefronts; then T (dlarft) row by row: thread k keeps row k
+        for (int pr = wave; pr < QRB_NB * QRB_NB; pr += NW) {
+            const int k = pr / QRB_NB, i = pr % QRB_NB;
+            if (k >= i || i >= nbk) continue;
+            double d = 0.0;
+            for (int r = i + lane; r < RR; r += WAVE) d = __builtin_fma(Vr[r * QRB_PITCH + k], Vr[r * QRB_PITCH + i], d);
+            d = wave_sum(d);
+            if (lane == 0) G[k * QRB_NB + i] = d;
+        }
+        __syncthreads();
+        if (tid < nbk) {
+            const int k = tid;
+            T[k * QRB_NB + k] = taus[k];
+            for (int i = k + 1; i < nbk; ++i) {
+                double acc = 0.0;
+                for (int mm = k; mm < i; ++mm) acc = __builtin_fma(T[k * QRB_NB + mm], G[mm * QRB_NB + i], acc);
+                T[k * QRB_NB + i] = -taus[i] * acc;
+            }
+        }
+        __syncthreads();
+        if (j0 + nbk < n_cols && !(skip & 1)) {
+            qrb_form_u<true>(Vr, T, Ur, RR);
+            __syncthreads();
+            qrb_apply<0>(B, Vr, Ur, j0, nbk, j0 + nbk, n_cols, n_rows, n_cols);
+        }
+        // (kept for the second phase)
+        Tg[(int64_t)p * (QRB_NB * QRB_NB) + tid] = T[tid];
+        __syncthreads();
+    }
+    for (int p = (skip & 2) ? -1 : n_panels - 1; p >= 0; --p) {              // ---- dorgqr
+        const int j0 = p * QRB_NB, nbk = min(QRB_NB, n_cols - j0), RR = n_rows - j0;
+        for (int e = tid; e < RR * QRB_NB; e += QRB_THREADS) {
+            const int r = e / QRB_NB, k = e % QRB_NB;
+            Vr[r * QRB_PITCH + k] = (k < nbk && r > k) ? B[(int64_t)(j0 + r) * n_cols + j0 + k] : ((k < nbk && r == k) ? 1.0 : 0.0);
+        }
+        T[tid] = Tg[(int64_t)p * (QRB_NB * QRB_NB) + tid];
+        __syncthreads();
+        qrb_form_u<false>(Vr, T, Ur, RR);
+        __syncthreads();
+        qrb_apply<1>(B, Vr, Ur, j0, nbk, j0 + nbk, n_cols, n_rows, n_cols);
+        // the panel's own columns: (I - V T V^T) e_c = e_c - V (row c of V T^T)^T; thread = (column c of the panel, rows sl, sl + 16, ...)
+        {
+            const int c = tid % QRB_NB, sl = tid / QRB_NB;
+            if (c < nbk) {
+                double w[QRB_NB];
+#pragma unroll
+                for (int k = 0; k < QRB_NB; ++k) w[k] = Ur[c * QRB_PITCH + k];
+                for (int r = sl; r < RR; r += QRB_THREADS / QRB_NB) {
+                    double x = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < QRB_NB; ++k) x = __builtin_fma(-Vr[r * QRB_PITCH + k], w[k], x);
+                    B[(int64_t)(j0 + r) * n_cols + j0 + c] = x;
+                }
+                for (int r = sl; r < j0; r += QRB_THREADS / QRB_NB) B[(int64_t)r * n_cols + j0 + c] = 0.0;       // (entries of R above the panel)
+            }
+        }
+        __syncthreads();
+    }
+    if (!(skip & 8)) for (int64_t e = tid; e < (int64_t)n_rows * n_cols; e += QRB_THREADS) a[e * ld + m] = B[e];
+}
+
+// rows the blocked kernel holds a panel of in its LDS
+constexpr int QRB_MAX_ROWS = 400;
+
 void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
                               hipStream_t st)
 {
+    if (n_rows <= QRB_MAX_ROWS) {
+        double *t_store = scratch + (size_t)n_traj * n_rows * n_cols;
+        const size_t lds = 2 * sizeof(double) * (size_t)n_rows * QRB_PITCH;
+        static DynLdsLimit configured(64 * 1024 - 4608);          // per device, see launch_tiled (4.5 KB of static LDS next to it)
+        if (configured.needs(lds)) {
+            if (hipFuncSetAttribute((const void *)batched_qr_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+                configured.set(lds);
+        }
+        int skip = 0;
+#ifdef QGS_HIP_DEV_KNOBS
+        if (const char *e = std::getenv("QGS_HIP_QRB_SKIP")) skip = std::atoi(e);
+#endif
+        // A[row][col][member] <-> the members' contiguous copies by the tile transposes (whole lines on both sides: 0.3 ms each way for
+        // 1 024 x 228 x 228 instead of 0.7 ms of 8-byte accesses inside the kernel)
+        const int64_t n_inner = (int64_t)n_rows * n_cols;
+        hipLaunchKernelGGL(unpack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(n_inner, TILE)), dim3(256), 0, st, n_inner, n_traj, ld, a, scratch);
+        hipLaunchKernelGGL(batched_qr_blocked_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(QRB_THREADS), lds, st, n_rows, n_cols,
+                           n_traj, ld, a, rdiag, scratch, t_store, skip | 8);
+        hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(n_inner, TILE)), dim3(256), 0, st, n_inner, n_traj, ld, scratch, a);
+        return;
+    }
     double *taus = scratch + (size_t)n_traj * n_rows * n_cols;
     hipLaunchKernelGGL(batched_qr_global_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(QRG_THREADS), sizeof(double) * (size_t)n_rows, st,
                        n_rows, n_cols, n_traj, ld, a, rdiag, scratch, taus);

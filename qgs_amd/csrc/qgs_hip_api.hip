@@ -2179,9 +2179,9 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     HIPCHK(hipSetDevice(m->device));
     if (n_cols > 64 || n_rows > 300) {
         // beyond one column per lane / the LDS (e.g. the full 228-vector Lyapunov basis of MAOOAM 6x6): global-memory kernel
-        if (m->work.ensure(sizeof(double) * (size_t)n_traj * ((size_t)n_rows + 1) * (size_t)n_cols)) return -1;
+        if (m->work.ensure(sizeof(double) * (size_t)n_traj * (((size_t)n_rows + 17) * (size_t)n_cols + 256))) return -1;
         qgs::launch_batched_qr_global(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->work.f64(), (hipStream_t)stream);
-        note_kernel(m, "batched_qr_global_kernel", nullptr);
+        note_kernel(m, n_rows <= 400 ? "batched_qr_blocked_kernel" : "batched_qr_global_kernel", nullptr);
         HIPCHK(hipGetLastError());
         return 0;
     }

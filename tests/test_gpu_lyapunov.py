@@ -30,7 +30,10 @@ def test_batched_qr_matches_lapack():
               # allocator's copies in front of the DPP instructions showed (44 x 40 was wrong in round 5 before those instructions came
               # in runs behind a wait, tests/test_qr_codegen_cpu.py)
               (44, 40, 37), (64, 20, 33), (60, 30, 37), (56, 20, 34), (38, 34, 35), (64, 32, 33), (64, 16, 21), (64, 40, 33),
-              (100, 16, 19), (52, 52, 9), (42, 37, 66))
+              (100, 16, 19), (52, 52, 9), (42, 37, 66),
+              # blocked kernel (cols > 64 or rows > 300, up to 400 rows: dgeqrf + dorgqr with 16-column panels): panel counts 1 ... 15, a
+              # short last panel, member counts around the XCD mapping; beyond 400 rows the unblocked global-memory kernel
+              (228, 228, 9), (300, 200, 3), (97, 65, 4), (400, 17, 3), (80, 80, 17), (129, 128, 2), (401, 70, 2), (500, 3, 2))
     for n_rows, n_cols, n in shapes:
         a = rng.randn(n, n_rows, n_cols)
         ld = (n + 63) // 64 * 64
@@ -39,7 +42,8 @@ def test_batched_qr_matches_lapack():
         rd = torch.zeros((n_cols, ld), dtype=torch.float64, device='cuda')
         m.batched_qr_device(n, ld, n_rows, n_cols, d.data_ptr(), rd.data_ptr())
         torch.cuda.synchronize()
-        expect = 'qgs_spec_qr_%dx%d' % (n_rows, n_cols) if (n_cols <= 64 and n_rows <= 300) else 'batched_qr_global_kernel'
+        expect = ('qgs_spec_qr_%dx%d' % (n_rows, n_cols) if (n_cols <= 64 and n_rows <= 300)
+                  else ('batched_qr_blocked_kernel' if n_rows <= 400 else 'batched_qr_global_kernel'))
         if expect:
             assert m.last_kernel_info()['name'] == expect
         q = d[:, :, :n].cpu().numpy().transpose(2, 0, 1)
