@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(QRG_THREADS) batched_qr_global_kernel(int n_ro
 //    pass for the update.  Consecutive threads hold consecutive columns: every global access is whole lines.
 // dorgqr walks the panels backwards with H = I - V T V^T (T kept from the first phase in scratch): the rows of R above and inside a
 // panel count as zeros on the way in, the panel's own columns start from the identity.
-constexpr int QRB_THREADS = 256, QRB_NB = 16, QRB_PITCH = 18, QRB_AHEAD = 8;
+constexpr int QRB_THREADS = 256, QRB_NB = 16, QRB_PITCH = 18, QRB_AHEAD = 8, QRB_NC = 2;
 
 // X(rows j0 .., columns c_first .. c_end - 1) -= V (U^T X) with U = V op(T) formed once per panel (qrb_form_u): the product with
 // the 16 x 16 triangle is then part of the first pass instead of 272 FMAs per thread on 136 LDS operands (which the compiler
@@ -1257,61 +1257,77 @@ template <int VIRT>
 __device__ __forceinline__ void qrb_apply(double *__restrict__ B, const double *__restrict__ Vr, const double *__restrict__ Ur, int j0, int nbk,
                                            int c_first, int c_end, int n_rows, int n_cols)
 {
-    // A thread owns two columns and every S-th row of them: S = 1, 2, 4 or 8 lanes of a wavefront share a column pair (the fewer
-    // pairs are left, the more), their partial U^T X meet through shuffles.  Consecutive lanes hold consecutive pairs: whole lines.
-    // The loads of QRB_AHEAD rows are issued before their FMAs: at one or two wavefronts per SIMD the loop is bound by their latency.
-    const int RR = n_rows - j0, ncp = (c_end - c_first + 1) / 2;
+    // A thread owns QRB_NC consecutive columns and every S-th row of them: S = 1, 2, 4 or 8 lanes of a wavefront share a column
+    // group (the fewer groups are left, the more), their partial U^T X meet through shuffles.  Consecutive lanes hold consecutive
+    // groups: whole lines.  The loads of QRB_AHEAD rows are issued before their FMAs.
+    // (QRB_NC = 2 or 4 and QRB_AHEAD = 4 or 8 all measure the same, 5.2 - 5.3 ms for 1 024 x 228 x 228: the loops are bound by neither
+    // the LDS operands (LDS busy 25 %) nor the FMAs (VALU 19 %) but by the trailing matrix itself -- 512 members in flight x 416 KB do
+    // not fit the L2, every pass comes from HBM: 9.4 GB read + 4.7 GB written per launch, 2.7 TB/s with two wavefronts per SIMD;
+    // profiles/r05_qr.md section 11.)
+    const int RR = n_rows - j0, ncg = (c_end - c_first + QRB_NC - 1) / QRB_NC;
     int sb = 0;
-    while (sb < 3 && (ncp << (sb + 1)) <= QRB_THREADS) ++sb;
-    const int S = 1 << sb, lanes_cp = WAVE >> sb, per_pass = (QRB_THREADS / WAVE) * lanes_cp;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slice = lane / lanes_cp;
+    while (sb < 3 && (ncg << (sb + 1)) <= QRB_THREADS) ++sb;
+    const int S = 1 << sb, lanes_cg = WAVE >> sb, per_pass = (QRB_THREADS / WAVE) * lanes_cg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slice = lane / lanes_cg;
     const int first = VIRT == 1 ? nbk : 0;
-    for (int cp0 = 0; cp0 < ncp; cp0 += per_pass) {
-        const int cp = cp0 + wave * lanes_cp + (lane % lanes_cp);
-        const bool on = cp < ncp;
-        const int c = c_first + 2 * cp;
-        const bool two = on && c + 1 < c_end;
-        double w0[QRB_NB], w1[QRB_NB];
+    for (int cg0 = 0; cg0 < ncg; cg0 += per_pass) {
+        const int cg = cg0 + wave * lanes_cg + (lane % lanes_cg);
+        const int c = c_first + QRB_NC * cg;
+        bool on[QRB_NC];
 #pragma unroll
-        for (int k = 0; k < QRB_NB; ++k) { w0[k] = 0.0; w1[k] = 0.0; }
-        double *col = B + (int64_t)j0 * n_cols + (on ? c : c_first);
+        for (int ci = 0; ci < QRB_NC; ++ci) on[ci] = cg < ncg && c + ci < c_end;
+        double w[QRB_NC][QRB_NB];
+#pragma unroll
+        for (int ci = 0; ci < QRB_NC; ++ci)
+#pragma unroll
+            for (int k = 0; k < QRB_NB; ++k) w[ci][k] = 0.0;
+        double *col = B + (int64_t)j0 * n_cols + (on[0] ? c : c_first);
         for (int r0 = first + slice; r0 < RR; r0 += QRB_AHEAD * S) {
-            double xa[QRB_AHEAD], xb[QRB_AHEAD];
+            double x[QRB_AHEAD][QRB_NC];
 #pragma unroll
             for (int qq = 0; qq < QRB_AHEAD; ++qq) {
                 const int r = r0 + qq * S;
-                xa[qq] = (on && r < RR) ? col[(int64_t)r * n_cols] : 0.0;
-                xb[qq] = (two && r < RR) ? col[(int64_t)r * n_cols + 1] : 0.0;
+#pragma unroll
+                for (int ci = 0; ci < QRB_NC; ++ci) x[qq][ci] = (on[ci] && r < RR) ? col[(int64_t)r * n_cols + ci] : 0.0;
             }
 #pragma unroll
             for (int qq = 0; qq < QRB_AHEAD; ++qq) {
                 const double *u = Ur + min(r0 + qq * S, RR - 1) * QRB_PITCH;
 #pragma unroll
-                for (int k = 0; k < QRB_NB; ++k) { w0[k] = __builtin_fma(u[k], xa[qq], w0[k]); w1[k] = __builtin_fma(u[k], xb[qq], w1[k]); }
+                for (int k = 0; k < QRB_NB; ++k) {
+                    const double uk = u[k];
+#pragma unroll
+                    for (int ci = 0; ci < QRB_NC; ++ci) w[ci][k] = __builtin_fma(uk, x[qq][ci], w[ci][k]);
+                }
             }
         }
-        for (int off = lanes_cp; off < WAVE; off <<= 1) {
+        for (int off = lanes_cg; off < WAVE; off <<= 1) {
 #pragma unroll
-            for (int k = 0; k < QRB_NB; ++k) { w0[k] += __shfl_xor(w0[k], off); w1[k] += __shfl_xor(w1[k], off); }
+            for (int ci = 0; ci < QRB_NC; ++ci)
+#pragma unroll
+                for (int k = 0; k < QRB_NB; ++k) w[ci][k] += __shfl_xor(w[ci][k], off);
         }
         for (int r0 = slice; r0 < RR; r0 += QRB_AHEAD * S) {
-            double xa[QRB_AHEAD], xb[QRB_AHEAD];
+            double x[QRB_AHEAD][QRB_NC];
 #pragma unroll
             for (int qq = 0; qq < QRB_AHEAD; ++qq) {
                 const int r = r0 + qq * S;
                 const bool ld_ = r < RR && !(VIRT == 1 && r < nbk);
-                xa[qq] = (on && ld_) ? col[(int64_t)r * n_cols] : 0.0;
-                xb[qq] = (two && ld_) ? col[(int64_t)r * n_cols + 1] : 0.0;
+#pragma unroll
+                for (int ci = 0; ci < QRB_NC; ++ci) x[qq][ci] = (on[ci] && ld_) ? col[(int64_t)r * n_cols + ci] : 0.0;
             }
 #pragma unroll
             for (int qq = 0; qq < QRB_AHEAD; ++qq) {
                 const int r = r0 + qq * S;
                 const double *v = Vr + min(r, RR - 1) * QRB_PITCH;
-                double x0 = xa[qq], x1 = xb[qq];
 #pragma unroll
-                for (int k = 0; k < QRB_NB; ++k) { x0 = __builtin_fma(-v[k], w0[k], x0); x1 = __builtin_fma(-v[k], w1[k], x1); }
-                if (on && r < RR) col[(int64_t)r * n_cols] = x0;
-                if (two && r < RR) col[(int64_t)r * n_cols + 1] = x1;
+                for (int k = 0; k < QRB_NB; ++k) {
+                    const double vk = -v[k];
+#pragma unroll
+                    for (int ci = 0; ci < QRB_NC; ++ci) x[qq][ci] = __builtin_fma(vk, w[ci][k], x[qq][ci]);
+                }
+#pragma unroll
+                for (int ci = 0; ci < QRB_NC; ++ci) if (on[ci] && r < RR) col[(int64_t)r * n_cols + ci] = x[qq][ci];
             }
         }
     }
