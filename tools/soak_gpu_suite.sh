@@ -17,7 +17,7 @@ for i in $(seq 1 $N); do
     t1=$(date +%s)
     fault=$(grep -a -m1 -o "Memory access fault[^\"]*" /tmp/soak_run.log)
     echo "run $i rc=$rc $(tail -1 /tmp/soak_run.log) [$((t1 - t0)) s] ${fault}" >> $out
-    if [ $rc -ne 0 ]; then fail=$((fail + 1)); tail -30 /tmp/soak_run.log >> $out; fi
+    if [ $rc -ne 0 ]; then fail=$((fail + 1)); grep -a -n -m1 -A60 "Fatal Python error\|Traceback\|^E  " /tmp/soak_run.log >> $out; echo "..." >> $out; tail -30 /tmp/soak_run.log >> $out; cp /tmp/soak_run.log gpurun_out/soak_failed_run_$i.log; fi
 done
 echo "# failed runs: $fail of $N" >> $out
 tail -3 $out
