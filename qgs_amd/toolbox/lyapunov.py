@@ -474,8 +474,10 @@ class LyapunovsEstimator(object):
                     a0g = a0[lo:lo + cnt] if a0 is not None else np.random.random((cnt, self.n_dim, self.n_vec))
                     info.append(self._compute_shard_on_current_device(m, ic[lo:lo + cnt], a0g, mdt, part, budget, True))
             finally:
-                torch.cuda.current_stream().synchronize()
-                m.drain_wait()                                         # nothing on its way into the result blocks when they are handed out
+                # every stream of the device (a group cut into record windows copies on a stream of its own), then the drain thread:
+                # nothing is on its way into the result blocks when they are handed out
+                torch.cuda.synchronize(torch.device('cuda', m.device))
+                m.drain_wait()
             return max(i[0] for i in info), max(i[1] for i in info)
 
     def _member_groups(self, torch, m, n, pre_qr):
