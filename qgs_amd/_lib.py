@@ -400,6 +400,11 @@ class HipModel(object):
         return int(lib().qgs_model_info(self._h, 8))
 
     @property
+    def last_groups(self):
+        """Member groups the last `rk_integrate` into pageable memory ran in (1: all members in one pass)."""
+        return int(lib().qgs_model_info(self._h, 9))
+
+    @property
     def n_derived(self):
         """Derived monomials of the generated tendencies / Jacobian code (rank-5 tensors; (0, 0) for rank 3)."""
         return int(lib().qgs_model_info(self._h, 6)), int(lib().qgs_model_info(self._h, 7))
@@ -448,11 +453,21 @@ class HipModel(object):
         _check(lib().qgs_jacobian(self._h, xb.shape[0], xb, out))
         return out[0] if x.ndim == 1 else out
 
-    def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a):
+    def rk_integrate(self, time, ic, time_direction, write_steps, b, c, a, out=None):
+        """`out`: the caller's own (n_traj, ndim, n_records) C-contiguous float64 array instead of a block of the result pool."""
         time, ic, b, c, a = _c(time), _c(ic), _c(b), _c(c), _c(a)
         self._check_ic(ic)
         nrec = n_records(time, write_steps)
-        traj = _RESULTS.empty((ic.shape[0], self.ndim, nrec))
+        if out is not None:
+            if out.dtype != np.float64 or not out.flags.c_contiguous or out.shape != (ic.shape[0], self.ndim, nrec):
+                raise ValueError('out must be a C-contiguous float64 array of shape (n_traj, ndim, n_records)')
+            traj = out
+        else:
+            # (a record that will leave in member groups -- rk_member_groups of qgs_hip_api.hip: a large ensemble, beyond one device
+            # window -- is filled front to back: no huge pages, see _Store)
+            grouped = (ic.shape[0] >= 2048 and 3 * 8 * ic.shape[0] * self.ndim * nrec > (8 << 30)
+                       and 'QGS_HIP_RECORD_WINDOW_MB' not in os.environ)
+            traj = _RESULTS.empty((ic.shape[0], self.ndim, nrec), True, not grouped)
         _check(lib().qgs_rk_integrate(self._h, ic.shape[0], ic, time, len(time), int(time_direction), int(write_steps),
                                       len(b), b, c, a, traj))
         return traj

@@ -869,6 +869,8 @@ struct LaunchTuning {
     size_t tgl_share_min_bytes = (size_t)256 << 20;   // QGS_HIP_TGL_SHARE_MIN_MB
     bool tgl_plain = false;            // QGS_HIP_TGL_VARIANT=plain: never the shared-stage-state tangent kernel
     size_t window_bytes = (size_t)8 << 30;   // QGS_HIP_RECORD_WINDOW_MB: device memory the host-layout entry points spend on record windows
+    bool window_by_hand = false;             //   (set by hand: the records of qgs_rk_integrate stay in windows of records, no member groups)
+    int64_t group_members = 0;               // QGS_HIP_RECORD_GROUP_MEMBERS: members per group of qgs_rk_integrate's member groups (0: by rule)
     int d2h_mode = 0;                  // QGS_HIP_D2H=kernel|copy -> 1 | 2: records reach a page-locked host block by stores of the unpack kernel, or by a copy (0: by measurement)
     void read_env()
     {
@@ -883,7 +885,8 @@ struct LaunchTuning {
         if (const char *e = std::getenv("QGS_HIP_TGLS_CHUNK")) tgls_chunk = std::max<int64_t>(1, std::atoll(e));
         if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_MIN_MB")) tgl_share_min_bytes = (size_t)std::atoll(e) << 20;
         if (const char *e = std::getenv("QGS_HIP_TGL_VARIANT")) tgl_plain = !std::strcmp(e, "plain");
-        if (const char *e = std::getenv("QGS_HIP_RECORD_WINDOW_MB")) window_bytes = (size_t)std::max(1.0, std::atof(e) * 1048576.0);   // fractions allowed
+        if (const char *e = std::getenv("QGS_HIP_RECORD_WINDOW_MB")) { window_bytes = (size_t)std::max(1.0, std::atof(e) * 1048576.0); window_by_hand = true; }   // fractions allowed
+        if (const char *e = std::getenv("QGS_HIP_RECORD_GROUP_MEMBERS")) group_members = std::max<int64_t>(64, (std::atoll(e) + 63) / 64 * 64);
         if (const char *e = std::getenv("QGS_HIP_D2H")) d2h_mode = !std::strcmp(e, "kernel") ? 1 : (!std::strcmp(e, "copy") ? 2 : 0);
     }
 };
@@ -984,6 +987,7 @@ struct qgs_model {
     uint32_t *p_idx = nullptr, *p_idx2 = nullptr;
     double *p_val = nullptr;
     int64_t last_windows = 0;      // windows of the last host-layout integration (qgs_model_info 8)
+    int64_t last_groups = 1;       // member groups of the last qgs_rk_integrate (qgs_model_info 9)
     KernelInfo last;
 };
 
@@ -1726,6 +1730,7 @@ int64_t qgs_model_info(const qgs_model *m, int which)
     case 6: return (int64_t)m->der.t.size();
     case 7: return (int64_t)m->der.j.size();
     case 8: return m->last_windows;
+    case 9: return m->last_groups;
     default: return -1;
     }
 }
@@ -2428,12 +2433,12 @@ struct WindowPlan {
 };
 
 static WindowPlan plan_windows(const qgs_model *m, int64_t n_records, int64_t n_steps, int64_t write_steps, int backward,
-                               size_t bytes_per_record, int buffers)
+                               size_t bytes_per_record, int buffers, size_t budget = 0)
 {
     WindowPlan p;
     p.n_records = n_records; p.n_steps = n_steps; p.write_steps = write_steps; p.backward = backward;
     const size_t per = std::max<size_t>(1, bytes_per_record * (size_t)buffers);
-    p.W = (int64_t)std::max<size_t>(1, m->tune.window_bytes / per);
+    p.W = (int64_t)std::max<size_t>(1, (budget ? budget : m->tune.window_bytes) / per);
     if (p.W >= n_records) { p.W = n_records; p.n_windows = 1; }
     else p.n_windows = (n_records + p.W - 1) / p.W;
     return p;
@@ -2476,8 +2481,10 @@ static bool prefer_copy_route(const qgs_model *m, bool dst_is_device, int64_t n_
 struct DrainGuard {
     qgs_model *m;
     hipStream_t a, b;
+    bool armed = true;          // (false: the caller waits itself, after more work has been enqueued -- member groups)
     ~DrainGuard()
     {
+        if (!armed) return;
         (void)hipStreamSynchronize(a);
         (void)hipStreamSynchronize(b);
         for (int64_t t : m->drain_tickets) (void)qgs::bridge_wait_done(t, nullptr);
@@ -2596,8 +2603,11 @@ static int drain_window(qgs_model *m, int64_t n_inner, int64_t n_traj, int64_t l
 
 // ic_rows: (n_traj, ndim) in host memory (ic_on_device == 0) or device memory; traj: (n_traj, ndim, n_records) in host memory
 // (pageable or page-locked) or device memory.  Blocking.
+// (budget != 0: the window budget of this call; defer: return with the last window still on its way -- the caller, who runs the
+// next member group first, waits for both streams and the drain thread)
 static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int ic_on_device, const double *time, int64_t n_time,
-                       int time_direction, int64_t write_steps, int s, const double *b, const double *a, double *traj)
+                       int time_direction, int64_t write_steps, int s, const double *b, const double *a, double *traj,
+                       size_t budget = 0, bool defer = false)
 {
     if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
     if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
@@ -2625,7 +2635,7 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
     double *alias = device_alias(m, traj, sizeof(double) * (size_t)n_traj * nd * (size_t)n_records, &dst_dev);
     if (alias && prefer_copy_route(m, dst_dev, n_records, modes_b)) alias = nullptr;
     DrainGuard drain{m, sc, sd};
-    const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3);
+    const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b, alias ? 2 : 3, budget);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
     for (int i = 0; i < nbuf; ++i) if (m->b_win[i].ensure(modes_b * (size_t)plan.W)) return -1;
@@ -2647,9 +2657,41 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
         if (drain_window(m, nd, n_traj, ld, hi - lo, n_records, lo_s, win, alias, traj, m->b_rec_rows, sd)) return -1;
         HIPCHK(hipEventRecord(m->ev_copy[q], sd));
     }
+    if (defer) {
+        // the next group's kernels go to the compute stream: they must not overwrite this group's window before its unpack has run
+        HIPCHK(hipStreamWaitEvent(sc, m->ev_copy[(plan.n_windows - 1) & 1], 0));
+        drain.armed = false;
+        return 0;
+    }
     HIPCHK(hipStreamSynchronize(sc));
     HIPCHK(hipStreamSynchronize(sd));
     return drain_finish(m);
+}
+
+// Records of a large ensemble into PAGEABLE host memory leave in member groups: traj is (n_traj, ndim, n_records), so the record of
+// a group of members is one contiguous piece of it -- one window per group, streamed front to back by the drain thread while the next
+// group is integrated.  Windows of records reach every page of the block once per window, in runs of 8 W bytes (the first window
+// takes the page faults of the whole block).  Returns the members per group, or 0: windows of records (few members, a record that
+// fits one window, a page-locked or device destination, a window budget set by hand).
+static int64_t rk_member_groups(qgs_model *m, int64_t n_traj, int64_t n_records, double *traj, size_t *group_budget)
+{
+    const size_t per_member = sizeof(double) * (size_t)m->ndim * (size_t)n_records;
+    bool dst_dev = false;
+    if (device_alias(m, traj, per_member * (size_t)n_traj, &dst_dev) || dst_dev) return 0;
+    int64_t g = m->tune.group_members;
+    if (g <= 0) {
+        if (m->tune.window_by_hand || per_member * (size_t)n_traj * 3 <= m->tune.window_bytes) return 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+        // window + staging block of a group within a sixth of the free memory each; sixteen groups or more where that leaves 4 096
+        // members per group, never fewer than 1 024
+        const int64_t cap = (int64_t)(free_b / 6 / std::max<size_t>(1, per_member)) / 64 * 64;
+        g = std::min(cap, std::max<int64_t>(4096, ((n_traj + 15) / 16 + 63) / 64 * 64));
+        if (g < 1024) return 0;
+    }
+    if (g >= n_traj) return 0;
+    *group_budget = 3 * per_member * (size_t)round_ld(g) + ((size_t)1 << 20);       // (plan_windows divides by three buffers)
+    return g;
 }
 
 int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, int backward, int64_t W, int64_t k, int64_t *out)
@@ -2702,6 +2744,31 @@ int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const doubl
 {
     (void)c;
     if (!m || !ic || !traj || n_traj < 1) return fail("bad arguments");
+    if (time && n_time >= 1 && write_steps >= 0) {
+        HIPCHK(hipSetDevice(m->device));
+        const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+        size_t budget = 0;
+        const int64_t g = rk_member_groups(m, n_traj, n_records, traj, &budget);
+        if (g > 0) {
+            int rc = 0;
+            int64_t windows = 0;
+            for (int64_t lo = 0; lo < n_traj && !rc; lo += g) {
+                const int64_t cnt = std::min(g, n_traj - lo);
+                rc = rk_windowed(m, cnt, ic + lo * m->ndim, 0, time, n_time, time_direction, write_steps, s, b, a,
+                                 traj + lo * m->ndim * n_records, budget, true);
+                windows = std::max(windows, m->last_windows);
+            }
+            const std::string err = rc ? g_err : std::string();
+            // whatever way the loop ended: nothing of it is in flight when the caller's block is handed back
+            if (m->st_comp) (void)hipStreamSynchronize(m->st_comp);
+            if (m->st_copy) (void)hipStreamSynchronize(m->st_copy);
+            const int rd = drain_finish(m);
+            m->last_windows = windows;
+            m->last_groups = (n_traj + g - 1) / g;
+            return rc ? fail(err) : rd;
+        }
+        m->last_groups = 1;
+    }
     return rk_windowed(m, n_traj, ic, 0, time, n_time, time_direction, write_steps, s, b, a, traj);
 }
 

@@ -70,6 +70,40 @@ def test_windowed_record_equals_unwindowed(monkeypatch, d2h, kind):
     m.close()
 
 
+def test_member_groups_into_pageable_memory(monkeypatch):
+    """Records of a large ensemble into pageable memory leave in member groups (each a contiguous piece of the caller's array,
+    qgs_hip_api.hip rk_member_groups).  Forced at a small size: 1 500 members in groups of 448 (three + a ragged one of 156); every
+    group's slice is bitwise a run of just those members, the whole agrees with one pass to rounding (kernels are chosen by
+    ensemble size), forward and backward, write_steps 1 and 3; a page-locked destination keeps the windows of records."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    n, steps = 1500, 60
+    ic = np.random.RandomState(17).rand(n, g.ndim) * 0.01
+    t = _grid(steps)
+    for direction, ws in ((1, 1), (-1, 3)):
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None, QGS_HIP_RECORD_WINDOW_MB=None)
+        whole = np.array(m.rk_integrate(t, ic, direction, ws, B, C, A))
+        assert m.last_groups == 1
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=448)
+        out = np.full(whole.shape, np.nan)                                   # ordinary (pageable) memory
+        m.rk_integrate(t, ic, direction, ws, B, C, A, out=out)
+        assert m.last_groups == 4 and m.last_windows == 1
+        assert np.abs(out - whole).max() <= 1e-13 * np.abs(whole).max()
+        pinned = m.rk_integrate(t, ic, direction, ws, B, C, A)              # a block of the page-locked pool: no groups
+        assert m.last_groups == 1 and np.array_equal(pinned, whole)
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None)
+        for lo in (448, 1344):
+            part = np.array(m.rk_integrate(t, ic[lo:lo + 448], direction, ws, B, C, A))
+            assert np.array_equal(part, out[lo:lo + 448]), (direction, ws, lo)
+    # a window budget set by hand keeps the windows of records (no groups by the rule)
+    knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None, QGS_HIP_RECORD_WINDOW_MB=1)
+    out = np.full(whole.shape, np.nan)
+    m.rk_integrate(t, ic, -1, 3, B, C, A, out=out)
+    assert m.last_groups == 1 and m.last_windows >= 3 and np.array_equal(out, whole)
+    knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None, QGS_HIP_RECORD_WINDOW_MB=None)
+    m.close()
+
+
 @pytest.mark.parametrize('case', ['rksplit4', 'dense_tableau', 'rank5', 'heun2'])
 def test_windowed_record_in_the_other_stepper_families(monkeypatch, case):
     """The remaining steppers behind `rk_launch` carry their state across a window boundary as well: the 4-way row-split kernel

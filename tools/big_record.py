@@ -56,8 +56,8 @@ for rep in range(3 if mode == 'pageable' else 2):
     rc = L.qgs_rk_integrate(m._h, n, ic, t, len(t), 1, 1, 4, b, c, a, out)
     el = time.perf_counter() - t3
     assert rc == 0, _lib.last_error()
-    print('run %d: %d windows, %.3f s wall = %.1f GB/s of records to the host, %.3g traj-steps/s (compute alone would take %.3f s)'
-          % (rep, m.last_windows, el, nbytes / el / 1e9, n * steps / el, 6.2e-6 * steps))
+    print('run %d: %d member group(s), %d window(s) each, %.3f s wall = %.1f GB/s of records to the host, %.3g traj-steps/s (compute alone would take %.3f s)'
+          % (rep, m.last_groups, m.last_windows, el, nbytes / el / 1e9, n * steps / el, 6.2e-6 * steps))
 from oracle.oracle import OracleModel                                         # noqa: E402  (checker only)
 pick = np.array([0, 63, 64, n - 1])
 k = min(steps, 100) + 1                                                       # a run's first records do not depend on its length
