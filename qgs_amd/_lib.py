@@ -489,13 +489,20 @@ class HipModel(object):
     def ensemble_moments_device(self, n_traj, ld, n_rows, d_x, d_mean, d_var=0, stream=0):
         _check(lib().qgs_ensemble_moments_device(self._h, n_traj, ld, int(n_rows), d_x, d_mean, d_var or None, stream or None))
 
-    def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse):
+    def rk_tgls_integrate(self, time, ic, tg_ic, time_direction, write_steps, b, c, a, adjoint, inverse, out=None):
+        """`out`: the caller's own (traj, fmatrix) pair of C-contiguous float64 arrays instead of blocks of the result pool."""
         time, ic, tg_ic, b, c, a = _c(time), _c(ic), _c(tg_ic), _c(b), _c(c), _c(a)
         self._check_ic(ic, tg_ic)
         nrec = n_records(time, write_steps)
         n_traj, n_tg = ic.shape[0], tg_ic.shape[2]
-        traj = _RESULTS.empty((n_traj, self.ndim, nrec))
-        fm = _RESULTS.empty((n_traj, self.ndim, n_tg, nrec))
+        if out is not None:
+            traj, fm = out
+            for arr, shape in ((traj, (n_traj, self.ndim, nrec)), (fm, (n_traj, self.ndim, n_tg, nrec))):
+                if arr.dtype != np.float64 or not arr.flags.c_contiguous or arr.shape != shape:
+                    raise ValueError('out must be C-contiguous float64 arrays of shapes (n_traj, ndim, n_records) and (n_traj, ndim, n_tg, n_records)')
+        else:
+            traj = _RESULTS.empty((n_traj, self.ndim, nrec))
+            fm = _RESULTS.empty((n_traj, self.ndim, n_tg, nrec))
         _check(lib().qgs_rk_tgls_integrate(self._h, n_traj, n_tg, ic, tg_ic, time, len(time), int(time_direction),
                                            int(write_steps), len(b), b, c, a, int(bool(adjoint)), float(inverse),
                                            traj, fm))

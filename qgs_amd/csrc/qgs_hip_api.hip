@@ -2673,11 +2673,13 @@ static int rk_windowed(qgs_model *m, int64_t n_traj, const double *ic_rows, int 
 // group is integrated.  Windows of records reach every page of the block once per window, in runs of 8 W bytes (the first window
 // takes the page faults of the whole block).  Returns the members per group, or 0: windows of records (few members, a record that
 // fits one window, a page-locked or device destination, a window budget set by hand).
-static int64_t rk_member_groups(qgs_model *m, int64_t n_traj, int64_t n_records, double *traj, size_t *group_budget)
+static int64_t rk_member_groups(qgs_model *m, int64_t n_traj, size_t per_member, double *dst_a, size_t bytes_a, double *dst_b, size_t bytes_b,
+                                size_t *group_budget)
 {
-    const size_t per_member = sizeof(double) * (size_t)m->ndim * (size_t)n_records;
+    // (per_member: bytes of records per member over all destination blocks; dst_b may be null)
     bool dst_dev = false;
-    if (device_alias(m, traj, per_member * (size_t)n_traj, &dst_dev) || dst_dev) return 0;
+    if (device_alias(m, dst_a, bytes_a, &dst_dev) || dst_dev) return 0;
+    if (dst_b && (device_alias(m, dst_b, bytes_b, &dst_dev) || dst_dev)) return 0;
     int64_t g = m->tune.group_members;
     if (g <= 0) {
         if (m->tune.window_by_hand || per_member * (size_t)n_traj * 3 <= m->tune.window_bytes) return 0;
@@ -2748,7 +2750,8 @@ int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const doubl
         HIPCHK(hipSetDevice(m->device));
         const int64_t n_records = qgs_n_records(time, n_time, write_steps);
         size_t budget = 0;
-        const int64_t g = rk_member_groups(m, n_traj, n_records, traj, &budget);
+        const size_t per_member = sizeof(double) * (size_t)m->ndim * (size_t)n_records;
+        const int64_t g = rk_member_groups(m, n_traj, per_member, traj, per_member * (size_t)n_traj, nullptr, 0, &budget);
         if (g > 0) {
             int rc = 0;
             int64_t windows = 0;
@@ -2845,18 +2848,14 @@ int qgs_rk_integrate_moments(qgs_model *m, int64_t n_traj, const double *ic, con
     return 0;
 }
 
-int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
-                          const double *time, int64_t n_time, int time_direction, int64_t write_steps, int s,
-                          const double *b, const double *c, const double *a, int adjoint, double inverse, double *traj,
-                          double *fmatrix)
+} // extern "C"
+
+// (budget, defer: as rk_windowed)
+static int tgls_windowed(qgs_model *m, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                         const double *time, int64_t n_time, int time_direction, int64_t write_steps, int s,
+                         const double *b, const double *a, int adjoint, double inverse, double *traj,
+                         double *fmatrix, size_t budget = 0, bool defer = false)
 {
-    (void)c;
-    if (!m || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
-    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
-    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
-    if (write_steps < 0) return fail("write_steps must be >= 0");
-    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
-    if ((int64_t)m->ndim * n_tg > (int64_t)65535 * 64) return fail("ndim * n_tg too large for the layout conversion kernels");
     HIPCHK(hipSetDevice(m->device));
     if (streams_ready(m)) return -1;
     const int nd = m->ndim;
@@ -2879,7 +2878,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
     if (prefer_copy_route(m, dev_t || dev_f, n_records, modes_b + tg_modes_b)) alias_t = alias_f = nullptr;
     DrainGuard drain{m, sc, sd};
     const WindowPlan plan = plan_windows(m, n_records, n_steps, write_steps, backward, modes_b + tg_modes_b,
-                                         (alias_t && alias_f) ? 2 : 3);
+                                         (alias_t && alias_f) ? 2 : 3, budget);
     m->last_windows = plan.n_windows;
     const int nbuf = plan.n_windows > 1 ? 2 : 1;
     for (int i = 0; i < nbuf; ++i)
@@ -2900,9 +2899,56 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
         if (drain_window(m, n_inner, n_traj, ld, hi - lo, n_records, lo_s, fwin, alias_f, fmatrix, m->b_fm_rows, sd)) return -1;
         HIPCHK(hipEventRecord(m->ev_copy[q], sd));
     }
+    if (defer) {
+        HIPCHK(hipStreamWaitEvent(sc, m->ev_copy[(plan.n_windows - 1) & 1], 0));
+        drain.armed = false;
+        return 0;
+    }
     HIPCHK(hipStreamSynchronize(sc));
     HIPCHK(hipStreamSynchronize(sd));
     return drain_finish(m);
+}
+
+extern "C" {
+
+int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const double *ic, const double *tg_ic,
+                          const double *time, int64_t n_time, int time_direction, int64_t write_steps, int s,
+                          const double *b, const double *c, const double *a, int adjoint, double inverse, double *traj,
+                          double *fmatrix)
+{
+    (void)c;
+    if (!m || !ic || !tg_ic || !traj || !fmatrix || n_traj < 1 || n_tg < 1) return fail("bad arguments");
+    if (!time || n_time < 1 || !b || !a || s < 1) return fail("bad time grid / tableau");
+    if (time_direction != 1 && time_direction != -1) return fail("time_direction must be +1 or -1");
+    if (write_steps < 0) return fail("write_steps must be >= 0");
+    if (m->J.empty()) return fail("model was created without a Jacobian tensor");
+    if ((int64_t)m->ndim * n_tg > (int64_t)65535 * 64) return fail("ndim * n_tg too large for the layout conversion kernels");
+    HIPCHK(hipSetDevice(m->device));
+    // records of a large ensemble into pageable memory: member groups, as in qgs_rk_integrate (both blocks are member-major)
+    const int64_t n_records = qgs_n_records(time, n_time, write_steps);
+    size_t budget = 0;
+    const size_t per_traj = sizeof(double) * (size_t)m->ndim * (size_t)n_records, per_fm = per_traj * (size_t)n_tg;
+    const int64_t g = rk_member_groups(m, n_traj, per_traj + per_fm, traj, per_traj * (size_t)n_traj, fmatrix, per_fm * (size_t)n_traj, &budget);
+    if (g > 0) {
+        int rc = 0;
+        int64_t windows = 0;
+        const int64_t nd = m->ndim;
+        for (int64_t lo = 0; lo < n_traj && !rc; lo += g) {
+            const int64_t cnt = std::min(g, n_traj - lo);
+            rc = tgls_windowed(m, cnt, n_tg, ic + lo * nd, tg_ic + lo * nd * n_tg, time, n_time, time_direction, write_steps, s, b, a, adjoint,
+                               inverse, traj + lo * nd * n_records, fmatrix + lo * nd * n_tg * n_records, budget, true);
+            windows = std::max(windows, m->last_windows);
+        }
+        const std::string err = rc ? g_err : std::string();
+        if (m->st_comp) (void)hipStreamSynchronize(m->st_comp);
+        if (m->st_copy) (void)hipStreamSynchronize(m->st_copy);
+        const int rd = drain_finish(m);
+        m->last_windows = windows;
+        m->last_groups = (n_traj + g - 1) / g;
+        return rc ? fail(err) : rd;
+    }
+    m->last_groups = 1;
+    return tgls_windowed(m, n_traj, n_tg, ic, tg_ic, time, n_time, time_direction, write_steps, s, b, a, adjoint, inverse, traj, fmatrix);
 }
 
 // ---- the general contraction: sparse_mul3 / sparse_mul5 / sparse_mul2 / sparse_mul4 with any vectors -----------------------

@@ -239,6 +239,31 @@ def test_windowed_tangent_model_equals_unwindowed(monkeypatch, kind):
     m.close()
 
 
+def test_tangent_member_groups_into_pageable_memory(monkeypatch):
+    """The tangent model's two record blocks (trajectory and propagators, both member-major) in member groups: 700 members in groups
+    of 256; every group's slices are bitwise a run of just those members; tangent forward, adjoint backward with `inverse`."""
+    g, m = _model('m36')
+    knobs = _Knobs(monkeypatch, m)
+    n, n_tg, steps = 700, 5, 24
+    rng = np.random.RandomState(19)
+    ic, tg = rng.rand(n, g.ndim) * 0.01, rng.randn(n, g.ndim, n_tg)
+    t = _grid(steps)
+    for direction, ws, adj, inv in ((1, 1, False, 1.), (-1, 5, True, -1.)):
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None, QGS_HIP_RECORD_WINDOW_MB=None)
+        tr0, fm0 = (np.array(q) for q in m.rk_tgls_integrate(t, ic, tg, direction, ws, B, C, A, adj, inv))
+        assert m.last_groups == 1
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=256)
+        out = (np.full(tr0.shape, np.nan), np.full(fm0.shape, np.nan))      # ordinary (pageable) memory
+        m.rk_tgls_integrate(t, ic, tg, direction, ws, B, C, A, adj, inv, out=out)
+        assert m.last_groups == 3 and m.last_windows == 1
+        assert np.abs(out[0] - tr0).max() <= 1e-13 * np.abs(tr0).max() and np.abs(out[1] - fm0).max() <= 1e-12 * np.abs(fm0).max()
+        knobs.set(QGS_HIP_RECORD_GROUP_MEMBERS=None)
+        for lo, cnt in ((256, 256), (512, 188)):
+            tr, fm = m.rk_tgls_integrate(t, ic[lo:lo + cnt], tg[lo:lo + cnt], direction, ws, B, C, A, adj, inv)
+            assert np.array_equal(tr, out[0][lo:lo + cnt]) and np.array_equal(fm, out[1][lo:lo + cnt]), (direction, ws, lo)
+    m.close()
+
+
 def test_record_larger_than_its_device_budget_matches_the_oracle(monkeypatch):
     """A 65 536-member run whose record (65 536 x 36 x 41 doubles = 774 MB) is forced through 128 MB of device windows:
     sample members against the oracle, every record."""
