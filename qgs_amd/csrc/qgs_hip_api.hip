@@ -2696,6 +2696,17 @@ static int64_t rk_member_groups(qgs_model *m, int64_t n_traj, size_t per_member,
     return g;
 }
 
+// after a run in member groups: the windows and staging blocks of a group can be far larger than the budget the model otherwise
+// keeps (up to a third of the device's memory together) -- they go back to the device
+static void release_group_buffers(qgs_model *m)
+{
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    const size_t keep = std::max(m->tune.window_bytes, total_b / 16);          // (a repeated run of the same size finds its blocks again)
+    for (Buffer *b : {&m->b_win[0], &m->b_win[1], &m->b_fwin[0], &m->b_fwin[1], &m->b_rec_rows, &m->b_fm_rows})
+        if (b->cap > keep) b->release();
+}
+
 int qgs_record_window(int64_t n_records, int64_t n_steps, int64_t write_steps, int backward, int64_t W, int64_t k, int64_t *out)
 {
     if (!out || n_records < 1 || n_steps < 0 || write_steps < 0 || W < 1 || k < 0) return fail("bad arguments");
@@ -2766,6 +2777,7 @@ int qgs_rk_integrate(qgs_model *m, int64_t n_traj, const double *ic, const doubl
             if (m->st_comp) (void)hipStreamSynchronize(m->st_comp);
             if (m->st_copy) (void)hipStreamSynchronize(m->st_copy);
             const int rd = drain_finish(m);
+            release_group_buffers(m);
             m->last_windows = windows;
             m->last_groups = (n_traj + g - 1) / g;
             return rc ? fail(err) : rd;
@@ -2943,6 +2955,7 @@ int qgs_rk_tgls_integrate(qgs_model *m, int64_t n_traj, int64_t n_tg, const doub
         if (m->st_comp) (void)hipStreamSynchronize(m->st_comp);
         if (m->st_copy) (void)hipStreamSynchronize(m->st_copy);
         const int rd = drain_finish(m);
+        release_group_buffers(m);
         m->last_windows = windows;
         m->last_groups = (n_traj + g - 1) / g;
         return rc ? fail(err) : rd;
