@@ -26,8 +26,10 @@ for ws in (0, 1):
     est.compute_lyapunovs(0., 10., 40., 0.1, 0.01, ic=ic, write_steps=ws)
     el = time.perf_counter() - t0
     print('%d members, 400 intervals, write_steps=%d: %.3f s = %.3f ms per interval' % (n, ws, el, el / 400 * 1e3), flush=True)
-pr = cProfile.Profile()
-pr.enable()
-est.compute_lyapunovs(0., 10., 40., 0.1, 0.01, ic=ic, write_steps=0)
-pr.disable()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+for ws in (0, 1):
+    pr = cProfile.Profile()
+    pr.enable()
+    est.compute_lyapunovs(0., 10., 40., 0.1, 0.01, ic=ic, write_steps=ws)
+    pr.disable()
+    print('---- write_steps = %d' % ws)
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
