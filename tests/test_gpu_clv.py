@@ -104,6 +104,47 @@ def test_clvs_are_covariant(name, n_vec, sub):
     f.operands.release()
 
 
+@pytest.mark.parametrize('method', [0, 1])
+def test_clvs_with_the_benettin_runs_in_member_groups(monkeypatch, method):
+    """The Benettin runs under both methods (method 0 with its records on the host: vectors, the matrices before the QR steps and
+    the junction states; method 1: backward and forward vectors) with the ensemble forced into member groups of 64 (200 members:
+    three groups and a ragged one) give the vectors of the runs in one pass -- to rounding, the kernels being chosen by ensemble size."""
+    from conftest import load_golden
+    from qgs_amd.functions.tendencies import tendencies_from_tensor
+    from qgs_amd.toolbox.lyapunov import CovariantLyapunovsEstimator
+    g = load_golden('m36')
+    f, Df = tendencies_from_tensor(g.ndim, g['coo'], g['val'], g['jcoo'], g['jval'])
+    ic = np.random.RandomState(8).rand(200, g.ndim) * 0.01
+    res = {}
+    for groups in (None, '64'):
+        if groups is None:
+            monkeypatch.delenv('QGS_HIP_RECORD_GROUP_MEMBERS', raising=False)
+        else:
+            monkeypatch.setenv('QGS_HIP_RECORD_GROUP_MEMBERS', groups)
+        est = CovariantLyapunovsEstimator(num_threads=1)
+        est.set_func(f, Df)
+        est.device_resident = False
+        np.random.seed(21)
+        est.compute_clvs(0., 0.5, 1.5, 2.0, 0.1, 0.05, ic=ic, write_steps=1, n_vec=5, method=method, backward_vectors=True,
+                         forward_vectors=True)
+        tt, traj, exps, vecs = est.get_clvs()
+        if method == 1:
+            # (the intersection of the two subspaces is a singular-vector problem: inside a nearly degenerate pair its columns turn
+            # with the last bits of the input, so what is compared are the two Benettin runs themselves)
+            vecs = np.concatenate((est.get_blvs()[3], est.get_flvs()[3]), axis=2)
+        res[groups] = (np.array(traj), np.array(exps), np.array(vecs))
+        est.terminate()
+    (t0, e0, v0), (t1, e1, v1) = res[None], res['64']
+    assert t0.shape == t1.shape and v0.shape == v1.shape and np.isfinite(v1).all()
+    assert rel_err(t1, t0) < 1e-12
+    for i in range(0, 200, 7):
+        for r in range(v0.shape[3]):
+            assert _columns_up_to_sign(v1[i, :, :, r], v0[i, :, :, r]) < 1e-7, (method, i, r)
+    if method == 0:
+        assert np.abs(e1 - e0).max() < 1e-7 * max(1.0, np.abs(e0).max())
+    f.operands.release()
+
+
 @pytest.mark.parametrize('resident', [True, False])
 def test_clv_base_trajectory_windows_shorter_than_an_interval(monkeypatch, resident):
     """Method 0 reads the fine base trajectory once per interval, dt / mdt = 10 grid steps apart; with a window budget that
