@@ -298,8 +298,14 @@ def to_host(d_tensor):
         out = np.empty(tuple(d_tensor.shape), dtype=torch.empty(0, dtype=d_tensor.dtype).numpy().dtype)
     if nbytes:
         st = torch.cuda.current_stream(d_tensor.device).cuda_stream
-        _check(lib().qgs_memcpy_d2h(d_tensor.device.index or 0, out.ctypes.data, d_tensor.data_ptr(), nbytes, st or None))
+        _check(lib().qgs_memcpy_d2h(_cuda_index(d_tensor.device), out.ctypes.data, d_tensor.data_ptr(), nbytes, st or None))
     return out
+
+
+def _cuda_index(device):
+    """The GPU a torch tensor actually lives on: an index-less `torch.device('cuda')` means the CURRENT device, not GPU 0."""
+    import torch
+    return torch.cuda.current_device() if device.index is None else device.index
 
 
 def to_device(array, device):
@@ -313,7 +319,7 @@ def to_device(array, device):
     t = torch.empty(a.shape, dtype=torch.from_numpy(np.empty(0, dtype=a.dtype)).dtype, device=device)
     if a.nbytes:
         st = torch.cuda.current_stream(device).cuda_stream
-        _check(lib().qgs_memcpy_h2d(device.index or 0, t.data_ptr(), a.ctypes.data, a.nbytes, st or None))
+        _check(lib().qgs_memcpy_h2d(_cuda_index(t.device), t.data_ptr(), a.ctypes.data, a.nbytes, st or None))
     return t
 
 

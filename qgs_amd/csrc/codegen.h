@@ -50,6 +50,18 @@ struct CodegenOptions {
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
+    bool lds_asm = true;       // the LDS-resident stepper (rank 3) with a hand-scheduled stage body: qgs_spec_rkldsa<W> (codegen_lds_asm.cpp);
+                               //     its own workgroup shape and phase size:
+    int lds_asm_waves = 8;    //     wavefronts per 64 members (16: 128 registers per lane; 8: 256)
+    int lds_asm_mincap = 10;   //     a wavefront takes at most as many rows as leave it a cache of this many modes
+    int lds_asm_cap = 64;      //     modes cached per phase (one half of the factor cache when lds_asm_pingpong)
+    bool lds_asm_pingpong = false;  // the LDS reads of phase p + 1 land in the idle half of the cache while phase p computes
+    int lds_asm_lanes = 2;     //     statements whose instructions are emitted round-robin (independent dependency chains)
+    int lds_asm_coef = 1;      //     coefficients: 0 = scalar loads into two SGPR buffers; 1 = vector loads into a ring of registers + DPP broadcast
+    int lds_asm_ring = 3;      //     (1) chunks of 16 coefficients held in registers
+    int lds_asm_chunk = 16;    //     coefficients per scalar-load chunk (two SGPR buffers of this size)
+    int lds_asm_vfree = 24;    //     low VGPRs left to the compiler's frame code
+    int lds_asm_sfree = 24;    //     low SGPRs left to the compiler's frame code
     int lds_order = 1;         // ... order of the grouped statements inside a phase of the stepper: 0 by (row, |c|), 1 by (|c|, row): partner
                                //     rows' equal coefficients become neighbours for the de-duplication (52.7 -> 51.8 ms, emit_lds_phases)
 };

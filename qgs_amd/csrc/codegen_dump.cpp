@@ -51,8 +51,22 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "ilv=", 4)) opt.interleave = std::atoi(argv[a] + 4);
         if (!std::strncmp(argv[a], "ldsorder=", 9)) opt.lds_order = std::atoi(argv[a] + 9);
         if (!std::strncmp(argv[a], "ldscap=", 7)) opt.lds_cap = std::atoi(argv[a] + 7);
+        if (!std::strncmp(argv[a], "asm=", 4)) opt.lds_asm = std::atoi(argv[a] + 4) != 0;
+        if (!std::strncmp(argv[a], "asmcoef=", 8)) opt.lds_asm_coef = std::atoi(argv[a] + 8);
+        if (!std::strncmp(argv[a], "asmring=", 8)) opt.lds_asm_ring = std::atoi(argv[a] + 8);
+        if (!std::strncmp(argv[a], "asmmincap=", 10)) opt.lds_asm_mincap = std::atoi(argv[a] + 10);
+        if (!std::strncmp(argv[a], "asmwaves=", 9)) opt.lds_asm_waves = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "asmcap=", 7)) opt.lds_asm_cap = std::atoi(argv[a] + 7);
+        if (!std::strncmp(argv[a], "asmpp=", 6)) opt.lds_asm_pingpong = std::atoi(argv[a] + 6) != 0;
+        if (!std::strncmp(argv[a], "asmlanes=", 9)) opt.lds_asm_lanes = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "asmchunk=", 9)) opt.lds_asm_chunk = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "asmvfree=", 9)) opt.lds_asm_vfree = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "asmsfree=", 9)) opt.lds_asm_sfree = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "ldswaves=", 9)) opt.lds_waves = std::atoi(argv[a] + 9);
+        if (!std::strncmp(argv[a], "ldsyload=", 9)) opt.lds_yload_ahead = std::atoi(argv[a] + 9);
     }
     if (rank == 5) opt.row_split = 1;
+    if (!der.t.empty()) opt.lds_asm = false;           // (as the library: the hand-scheduled LDS stepper takes rank-3 tensors only)
     std::fprintf(stderr, "ndim %d rank %d terms %zu jac terms %zu derived %zu / %zu tendency fp64 instr %lld\n", ndim, rank, T.size(),
                  J.size(), der.t.size(), der.j.size(), (long long)qgs::count_tendency_flops_instr(ndim, T, opt) + (long long)der.t.size());
     if (ndim <= 64) std::fputs(qgs::generate_source(ndim, T, J, stages, opt, der).c_str(), stdout);

@@ -1,0 +1,609 @@
+// codegen_lds_asm.cpp -- the LDS-resident stepper of large systems with a hand-scheduled stage body.  See codegen.h /
+// codegen_internal.h; the frame (workgroup shape, stage state in LDS, rows split over wavefronts, phases that cache a set of
+// modes in registers) is the one of emit_rk_lds_kernel in codegen_lds.cpp.
+//
+// Why.  Left to the compiler, the straight-line stage body of that kernel spills at every workgroup shape (420 B per lane at 16
+// wavefronts, 700 - 1 100 B at 12 and 8: profiles/r06_lds228_variants.txt) -- the machine scheduler hoists LDS reads and
+// coefficient fetches across the phases the generator laid out, and every `s_waitcnt lgkmcnt(0)` (LDS reads and scalar loads share
+// one counter, scalar loads return out of order) waits for something that has only just been issued: 57 % of the wavefront-cycles
+// of qgs_spec_rklds16 are waits.  The generator knows every live range, so here it allocates the registers itself and emits the
+// stage body as ONE inline-assembly statement per wavefront:
+//   * registers: the running sums `acc` (tied to the C++ variables by physical-register constraints), the stage sums `k`, a few
+//     temporaries, and the factor cache in two halves -- phase p computes out of one half while the LDS reads of phase p + 1 land
+//     in the other;
+//   * coefficients: the wavefront's table is consumed in chunks of 16 entries held in two SGPR buffers; the scalar loads of chunk
+//     c + 1 leave at the moment chunk c starts being consumed, so the one `s_waitcnt lgkmcnt(0)` per chunk waits for loads that
+//     have been in flight for a whole chunk (~50 fp64 instructions) -- and it is also the wait that covers the LDS reads issued a
+//     phase ahead;
+//   * the step-start state y is read back from the private global buffer into the idle cache half during the last phase
+//     (vector-memory counter: in order, separate from the LDS / scalar counter), and not at all in the last stage;
+//   * nothing is spilled, no lane moves, no scratch.
+// Everything outside the stage body (prologue, record stores, stage-state store for the tangent pass, final stores) stays C++.
+#include "codegen_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+
+namespace qgs {
+namespace detail {
+
+namespace {
+
+std::string vreg(int r) { return "v[" + std::to_string(r) + ":" + std::to_string(r + 1) + "]"; }
+std::string sreg(int r) { return "s[" + std::to_string(r) + ":" + std::to_string(r + 1) + "]"; }
+
+// One instruction of the stage body before the coefficients are placed.
+struct AIns {
+    enum Kind { MulT, FmaT, AccK, MovK, Raw } kind;
+    int t = 0;              // temporary (VGPR number) written by MulT / FmaT, or read by AccK when src_temp
+    int a = 0, b = 0;       // factor registers (MulT / FmaT)
+    bool neg = false;       // MulT / FmaT: the product enters negated
+    int row = 0;            // AccK / MovK: own-row index (0 .. R-1)
+    double coef = 0.0;      // AccK / MovK: signed coefficient (a table entry)
+    int src = 0;            // AccK: register multiplied by the coefficient
+    std::string text;       // Raw
+};
+
+struct Statement { std::vector<AIns> ins; };
+
+// Row blocks: contiguous in a row sequence (neighbouring rows share their factors: every departure from contiguity costs
+// instructions -- two runs per wavefront + 4 %, four runs + 10 % on MAOOAM 6x6), balanced by the fp64 instructions a block really
+// needs with the factor cache ITS row count leaves (cap_for), at most `max_rows` rows per block (the registers).  The sequence is
+// the one of lds_partition: rows in order, the cheap ones (MAOOAM: the ocean rows) spread evenly through it.  Optimal contiguous
+// split for the current cost estimate by dynamic programming, the estimate refined against the real counts a few times.
+std::vector<std::vector<int>> asm_partition(int n_rows, const RowTerms &rt, int W, const std::function<int(int)> &cap_for, int max_rows)
+{
+    std::vector<double> c(n_rows + 1, 0.0);
+    double total = 0.0;
+    for (int i = 1; i <= n_rows; ++i) {
+        c[i] = 1;
+        for (const PTerm &t : rt[i]) c[i] += (t.j == 0) ? 1 : 2;
+        total += c[i];
+    }
+    std::vector<int> seq;
+    {
+        std::vector<int> heavy, light;
+        for (int i = 1; i <= n_rows; ++i) ((c[i] * 2 * n_rows < total) ? light : heavy).push_back(i);
+        double heavy_total = 0, run = 0;
+        for (int i : heavy) heavy_total += c[i];
+        size_t nl = 0;
+        for (int i : heavy) {
+            seq.push_back(i);
+            run += c[i];
+            while (nl < light.size() && run * (double)light.size() >= heavy_total * (double)(nl + 1)) seq.push_back(light[nl++]);
+        }
+        while (nl < light.size()) seq.push_back(light[nl++]);
+    }
+    const int n = (int)seq.size();
+    if ((int64_t)W * max_rows < n) throw std::logic_error("codegen: the hand-scheduled LDS stepper has too few registers for this many rows per wavefront");
+    std::vector<std::vector<int>> best;
+    double best_max = 0.0;
+    for (int iter = 0; iter < 8; ++iter) {
+        std::vector<double> pre(n + 1, 0.0);
+        for (int q = 0; q < n; ++q) pre[q + 1] = pre[q] + c[seq[q]];
+        const double INF = 1e300;
+        std::vector<std::vector<double>> dp(W + 1, std::vector<double>(n + 1, INF));
+        std::vector<std::vector<int>> from(W + 1, std::vector<int>(n + 1, -1));
+        dp[0][0] = 0.0;
+        for (int w = 1; w <= W; ++w)
+            for (int q = 1; q <= n; ++q)
+                for (int q0 = std::max(0, q - max_rows); q0 < q; ++q0) {
+                    if (dp[w - 1][q0] >= INF) continue;
+                    const double v = std::max(dp[w - 1][q0], pre[q] - pre[q0]);
+                    if (v < dp[w][q]) { dp[w][q] = v; from[w][q] = q0; }
+                }
+        if (from[W][n] < 0) throw std::logic_error("codegen: no row partition within the register plan");
+        std::vector<std::vector<int>> cand(W);
+        for (int w = W, q = n; w >= 1; --w) {
+            const int q0 = from[w][q];
+            cand[w - 1].assign(seq.begin() + q0, seq.begin() + q);
+            q = q0;
+        }
+        double worst = 0.0;
+        std::vector<double> actual(W, 0.0), est(W, 0.0);
+        for (int v = 0; v < W; ++v) {
+            std::sort(cand[v].begin(), cand[v].end());
+            actual[v] = (double)lds_wave_instr(n_rows, rt, cand[v], cap_for((int)cand[v].size()), true);
+            for (int i : cand[v]) est[v] += c[i];
+            worst = std::max(worst, actual[v]);
+        }
+        if (best.empty() || worst < best_max) { best = cand; best_max = worst; }
+        for (int v = 0; v < W; ++v)
+            if (est[v] > 0.0) for (int i : cand[v]) c[i] *= actual[v] / est[v];
+    }
+    return best;
+}
+
+}  // namespace
+
+void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+{
+    const int W = opt.lds_asm_waves, cap = std::max(2, opt.lds_asm_cap), NL = std::max(1, opt.lds_asm_lanes);
+    const bool pp = opt.lds_asm_pingpong;
+    const bool dpp = opt.lds_asm_coef == 1;                  // coefficients through vector memory + DPP broadcast (else: SGPR chunks)
+    const int CE = dpp ? 16 : ((opt.lds_asm_chunk == 8 || opt.lds_asm_chunk == 12) ? opt.lds_asm_chunk : 16);     // coefficients per chunk
+    const int NR = dpp ? std::max(2, opt.lds_asm_ring) : 0;  // coefficient chunks in registers (dpp): chunk c in ring slot c % NR
+    const int VT = std::min(256, (512 / ((W + 3) / 4)) / 8 * 8);                                     // registers a lane may have
+    const std::string kname = "qgs_spec_rkldsa" + std::to_string(W);
+    RowTerms rt(ndim + 1);
+    for (int i = 1; i <= ndim; ++i) {
+        for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
+        for (const Bil &b : rows[i].bil) rt[i].push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+    }
+    // register plan of a wavefront with R rows: [0, VF) the compiler's, then acc, k, temporaries, address registers, (dpp: the
+    // coefficient ring,) cache.  The cache is what the rows leave: wavefronts with few, long rows get the large cache their rows
+    // profit from.
+    const int VF = std::max(16, opt.lds_asm_vfree) / 2 * 2;
+    struct Plan { int ACC0, K0, T0, LB1, L15, RING, C0, NS, half, cap; };
+    auto plan_for = [&](int R) {
+        Plan pl;
+        pl.ACC0 = VF; pl.K0 = pl.ACC0 + 2 * R; pl.T0 = pl.K0 + 2 * R; pl.LB1 = pl.T0 + 2 * NL; pl.L15 = pl.LB1 + 1;
+        pl.RING = (pl.L15 + 2) / 2 * 2;
+        pl.C0 = pl.RING + 2 * NR;
+        pl.NS = (VT - pl.C0) / 2;
+        pl.half = pp ? pl.NS / 2 : pl.NS;
+        pl.cap = std::min(cap, pl.half);
+        return pl;
+    };
+    int max_rows = 0;                                        // the most rows that still leave a phase of `lds_asm_mincap` modes
+    while (plan_for(max_rows + 1).cap >= std::max(4, opt.lds_asm_mincap)) ++max_rows;
+    const std::vector<std::vector<int>> owns = asm_partition(ndim, rt, W, [&](int R) { return plan_for(R).cap; }, max_rows);
+    std::vector<int> slot(ndim + 1, 0), slot0(W, 0);
+    {
+        int q = 0;
+        for (int w = 0; w < W; ++w) { slot0[w] = q; for (int d : owns[w]) slot[d] = q++; }
+    }
+    // scalar plan: [0, SF) the compiler's, (SGPR mode: two coefficient buffers,) address pairs.  Every uniform input arrives in a
+    // VGPR and is moved to an SGPR of this plan by v_readfirstlane_b32: under the SGPR pressure this statement creates, the compiler
+    // handed VGPRs to "s"-constrained operands in some of the wavefront branches.
+    const int SF = std::max(16, opt.lds_asm_sfree) / 4 * 4;
+    const int BUF[2] = {SF, SF + 2 * CE}, YB = dpp ? SF : SF + 4 * CE, KT = YB + 2, YW = KT + 2, KB = dpp ? YW + 2 : YW, LAST = KB + 2;
+    if (LAST + 1 > 96) throw std::logic_error("codegen: the hand-scheduled LDS stepper does not fit its scalar plan");
+
+    std::ostringstream o;
+    std::vector<KTable> tables(W);
+    LdsStats stats;
+    int64_t n_chunks = 0, n_extra_waits = 0;
+    std::vector<int64_t> wave_instr(W, 0);
+    o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members, stage body\n"
+      << "// hand-scheduled: " << VT << " registers per lane = " << VF << " for the frame + 2 x 2 per own row (acc, k) + " << 2 * NL
+      << " temporaries + the factor cache in " << (pp ? "two halves" : "one set") << " (phases of <= " << cap << " modes); coefficients in chunks of "
+      << CE << (dpp ? " through vector memory, " + std::to_string(NR) + " chunks in registers, broadcast by DPP" : " in two SGPR buffers") << "\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
+      << "    const f64* __restrict__ y_in,\n"
+      << "    f64* __restrict__ y_out,        // final state, X[mode][member] (may be null)\n"
+      << "    f64* __restrict__ ywork,        // private [workgroup][mode][64]: state at the start of the current step\n"
+      << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
+      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S)\n{\n";
+    o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
+    o << "    const int lane = threadIdx.x & 63;\n"
+      << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
+      << "    const unsigned ldsaddr = (unsigned)(unsigned long long)(&xs[0][0]) + lane8;   // LDS byte address of xs[0][lane]\n"
+      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+      << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
+      << "    const bool live = m0 < n_traj;\n"
+      << "    const i64 m = live ? m0 : (n_traj - 1);\n"
+      << "    f64* const ywg = ywork + (i64)blockIdx.x * " << ndim * 64 << ";              // this workgroup's block (uniform)\n"
+      << "    QGS_CLOCK_MARK(0)\n";
+    for (int w = 0; w < W; ++w) {
+        const std::vector<int> &own = owns[w];
+        const int R = (int)own.size();
+        const Plan pl = plan_for(R);
+        const int ACC0 = pl.ACC0, K0 = pl.K0, T0 = pl.T0, LB1 = pl.LB1, L15 = pl.L15, RING = pl.RING, C0 = pl.C0, NS = pl.NS, half = pl.half;
+        std::map<int, int> ridx;
+        for (int i = 0; i < R; ++i) ridx[own[i]] = i;
+        auto ACC = [&](int i) { return ACC0 + 2 * i; };
+        auto KR = [&](int i) { return K0 + 2 * i; };
+        o << "    " << (w == 0 ? "if" : "else if") << " (wave == " << w << ") {   // rows:";
+        for (int i : own) o << " " << i;
+        o << "\n";
+        const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
+        for (int d : own) o << I2 << "f64 acc" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+        o << I2 << "f64* const yw = ywg + " << slot0[w] * 64 << ";      // rows of this wavefront: consecutive 512-byte lines\n";
+        for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << (slot[d] - slot0[w]) * 64 << " + lane] = acc" << d << ";\n";
+        o << I2 << "__syncthreads();\n";
+        o << I2 << "const unsigned ywlo = (unsigned)(unsigned long long)yw, ywhi = (unsigned)((unsigned long long)yw >> 32);\n";
+        o << I2 << "QGS_REC_INIT\n";
+        o << I2 << "const unsigned long long kt = (unsigned long long)(kf64*)" << kname << "_kt" << w << ";\n"
+          << I2 << "const unsigned ktlo = (unsigned)kt, kthi = (unsigned)(kt >> 32);\n";
+        o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
+        o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
+        o << I3 << "if (ti == next_rec) {\n"
+          << I4 << "i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));   // keeps the row offsets out of the loop-invariant set\n"
+          << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ldr + m;\n"
+          << I4 << "++iw; next_rec += write_steps;\n"
+          << I4 << "if (live) {\n";
+        for (int d : own) o << I4 << "    p[" << (d - 1) << " * ldr] = " << "acc" << d << ";\n";
+        o << I4 << "}\n" << I3 << "}\n";
+        o << "#pragma nounroll\n";
+        o << I3 << "for (int st = 0; st < S; ++st) {\n";
+        o << I4 << "const int last = (st == S - 1);\n";
+        o << I4 << "const f64 hb = dt * tab[st];\n";
+        o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
+        o << I4 << "if (stages && live) {\n"
+          << I4 << "    i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
+          << I4 << "    f64* sp = stages + ((ti - step_begin) * S + st) * " << ndim << " * ldr + m;\n";
+        for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
+        o << I4 << "}\n";
+
+        // ---- the stage body --------------------------------------------------------------------------------------------------
+        std::vector<PTerm> terms;
+        for (int i : own) terms.insert(terms.end(), rt[i].begin(), rt[i].end());
+        const std::vector<Phase> phases = build_phases(ndim, terms, pl.cap);
+        const int P = (int)phases.size();
+        stats.phases += P;
+
+        std::vector<std::string> body;                       // assembly lines
+        KTable &tab = tables[w];
+        int chunk = 0;                                       // coefficient chunk being consumed
+        std::vector<char> touched(R, 0);
+        bool lds_pending = false;
+        // Vector-memory operations in flight, oldest first.  Loads return in order, so "operation T has completed" is
+        // `s_waitcnt vmcnt(number of operations issued after T)`.  The early reads of the step-start state are skipped in the last
+        // stage (`maybe`): a wait for anything else does not count them -- it then waits for a few of them too where they were issued.
+        struct VmOp { int id; bool maybe; };
+        std::vector<VmOp> vmq;
+        int vm_next = 0;
+        auto vm_issue = [&](bool maybe) { vmq.push_back({vm_next, maybe}); return vm_next++; };
+        auto vm_wait = [&](int id, bool count_maybe) {
+            size_t at = vmq.size();
+            for (size_t q = 0; q < vmq.size(); ++q) if (vmq[q].id == id) { at = q; break; }
+            if (at == vmq.size()) return;                     // completed by an earlier wait
+            int after = 0;
+            for (size_t q = at + 1; q < vmq.size(); ++q) if (count_maybe || !vmq[q].maybe) ++after;
+            body.push_back("s_waitcnt vmcnt(" + std::to_string(std::min(after, 63)) + ")");
+            vmq.erase(vmq.begin(), vmq.begin() + (long)at + 1);
+        };
+        // -- coefficients, SGPR mode: chunk c in buffer c % 2, requested when chunk c - 1 starts being consumed
+        auto issue_chunk = [&](int c) {
+            const int base = BUF[c % 2];
+            int off = 0;
+            for (int n : (CE == 16 ? std::vector<int>{16, 16} : (CE == 12 ? std::vector<int>{16, 8} : std::vector<int>{16}))) {
+                body.push_back("s_load_dwordx" + std::to_string(n) + " s[" + std::to_string(base + off) + ":" + std::to_string(base + off + n - 1) +
+                               "], " + sreg(KT) + ", " + std::to_string((c * CE) * 8 + off * 4));
+                off += n;
+            }
+        };
+        // -- coefficients, DPP mode: chunk c = 16 doubles, lane l of every row of 16 lanes loads entry l; ring slot c % NR
+        std::vector<int> ring_op(std::max(1, NR), -1);
+        int kb_block = 0;
+        auto issue_ring = [&](int c) {
+            if (c / 32 != kb_block) {                         // 13-bit immediate offsets: a new base every 32 chunks
+                kb_block = c / 32;
+                body.push_back("s_add_u32 s" + std::to_string(KB) + ", s" + std::to_string(KT) + ", " + std::to_string(4096 * kb_block));
+                body.push_back("s_addc_u32 s" + std::to_string(KB + 1) + ", s" + std::to_string(KT + 1) + ", 0");
+            }
+            body.push_back("global_load_dwordx2 " + vreg(RING + 2 * (c % NR)) + ", v" + std::to_string(L15) + ", " + sreg(KB) + " offset:" + std::to_string((c % 32) * 128));
+            ring_op[c % NR] = vm_issue(false);
+        };
+        auto boundary = [&]() {                              // chunk `chunk` is used up
+            ++chunk;
+            ++n_chunks;
+            if (dpp) {
+                issue_ring(chunk + NR - 1);                   // into the slot of the chunk just finished (chunks chunk .. chunk + NR - 2 are there or on their way)
+                vm_wait(ring_op[chunk % NR], false);
+            } else {
+                body.push_back("s_waitcnt lgkmcnt(0)");
+                lds_pending = false;
+                issue_chunk(chunk + 1);
+            }
+        };
+        struct Coef { std::string sgpr; int reg = 0, lane = 0; bool neg = false; };
+        auto coef_operand = [&](double c, bool allow_neg = true) -> Coef {
+            Coef r;
+            auto at = [&](size_t q, size_t lo) {
+                r.neg = std::signbit(tab.vals[q]) != std::signbit(c);
+                r.lane = (int)(q - lo);
+                r.reg = RING + 2 * (chunk % std::max(1, NR));
+                r.sgpr = std::string(r.neg ? "-" : "") + sreg(BUF[chunk % 2] + 2 * r.lane);
+            };
+            const size_t lo = (size_t)chunk * CE;
+            for (size_t q = lo; q < tab.vals.size(); ++q)
+                if (std::fabs(tab.vals[q]) == std::fabs(c) && c != 0.0 && (allow_neg || std::signbit(tab.vals[q]) == std::signbit(c))) { at(q, lo); return r; }
+            if (tab.vals.size() == lo + (size_t)CE) boundary();
+            tab.vals.push_back(c);
+            ++stats.coef;
+            at(tab.vals.size() - 1, (size_t)chunk * CE);
+            return r;
+        };
+        auto acc_k = [&](int row, double c, int src) {        // k[row] += c * src
+            const Coef cf = coef_operand(c);
+            if (dpp)
+                body.push_back("v_fmac_f64_dpp " + vreg(KR(row)) + ", " + (cf.neg ? "-" : "") + vreg(cf.reg) + ", " + vreg(src) + " row_newbcast:" +
+                               std::to_string(cf.lane) + " row_mask:0xf bank_mask:0xf");
+            else if (!touched[row]) body.push_back("v_mul_f64 " + vreg(KR(row)) + ", " + cf.sgpr + ", " + vreg(src));
+            else body.push_back("v_fma_f64 " + vreg(KR(row)) + ", " + cf.sgpr + ", " + vreg(src) + ", " + vreg(KR(row)));
+            touched[row] = 1;
+            ++stats.instr;
+            ++wave_instr[w];
+        };
+        auto place = [&](const AIns &in) {
+            switch (in.kind) {
+            case AIns::MulT:
+                body.push_back("v_mul_f64 " + vreg(in.t) + ", " + (in.neg ? "-" : "") + vreg(in.a) + ", " + vreg(in.b));
+                ++stats.instr; ++wave_instr[w];
+                break;
+            case AIns::FmaT:
+                body.push_back("v_fma_f64 " + vreg(in.t) + ", " + (in.neg ? "-" : "") + vreg(in.a) + ", " + vreg(in.b) + ", " + vreg(in.t));
+                ++stats.instr; ++wave_instr[w];
+                break;
+            case AIns::AccK: acc_k(in.row, in.coef, in.src); break;
+            case AIns::MovK:
+                if (dpp) {                                    // k = 0 (stage start) + c0 * 1.0
+                    body.push_back("v_mov_b64 " + vreg(T0) + ", 1.0");
+                    acc_k(in.row, in.coef, T0);
+                } else {
+                    const Coef cf = coef_operand(in.coef, false);           // (a move takes no negation)
+                    body.push_back("v_mov_b64 " + vreg(KR(in.row)) + ", " + cf.sgpr);
+                    touched[in.row] = 1;
+                }
+                break;
+            case AIns::Raw: body.push_back(in.text); break;
+            }
+        };
+        auto cache_base = [&](int p) { return C0 + 2 * ((pp && (p & 1)) ? half : 0); };
+        auto lds_reads = [&](int p) {                         // the modes of phase p into its cache half
+            const Phase &ph = phases[p];
+            const int base = cache_base(p);
+            size_t i = 0;
+            for (; i + 1 < ph.modes.size(); i += 2)           // two rows per instruction: offsets in units of 64 doubles
+                body.push_back("ds_read2st64_b64 v[" + std::to_string(base + 2 * (int)i) + ":" + std::to_string(base + 2 * (int)i + 3) +
+                               "], %[lds] offset0:" + std::to_string(ph.modes[i] - 1) + " offset1:" + std::to_string(ph.modes[i + 1] - 1));
+            if (i < ph.modes.size()) {
+                const int64_t off = (int64_t)(ph.modes[i] - 1) * 512;
+                body.push_back("ds_read_b64 " + vreg(base + 2 * (int)i) + ", " + (off >= 65536 ? "v" + std::to_string(LB1) : std::string("%[lds]")) +
+                               " offset:" + std::to_string(off & 65535));
+            }
+            stats.loads += (int64_t)ph.modes.size();
+            lds_pending = true;
+        };
+        auto lds_wait = [&]() { body.push_back("s_waitcnt lgkmcnt(0)"); lds_pending = false; };
+        // global address of own row i: YB pair = yw + 4096 * (i / 8), immediate offset 512 * (i % 8)
+        int yb_block = -1;
+        auto ybase = [&](int i) {
+            if (i / 8 != yb_block) {
+                yb_block = i / 8;
+                if (yb_block == 0) body.push_back("s_mov_b64 " + sreg(YB) + ", " + sreg(YW));
+                else {
+                    body.push_back("s_add_u32 s" + std::to_string(YB) + ", s" + std::to_string(YW) + ", " + std::to_string(4096 * yb_block));
+                    body.push_back("s_addc_u32 s" + std::to_string(YB + 1) + ", s" + std::to_string(YW + 1) + ", 0");
+                }
+            }
+            return sreg(YB) + " offset:" + std::to_string(512 * (i % 8));
+        };
+
+        // -- stage start: uniform inputs, first coefficients, factors of phase 0
+        body.push_back("v_readfirstlane_b32 s" + std::to_string(KT) + ", %[ktlo]");
+        body.push_back("v_readfirstlane_b32 s" + std::to_string(KT + 1) + ", %[kthi]");
+        body.push_back("v_readfirstlane_b32 s" + std::to_string(YW) + ", %[ywlo]");
+        body.push_back("v_readfirstlane_b32 s" + std::to_string(YW + 1) + ", %[ywhi]");
+        body.push_back("v_readfirstlane_b32 s" + std::to_string(LAST) + ", %[last]");
+        body.push_back("v_add_u32 v" + std::to_string(LB1) + ", 0x10000, %[lds]");
+        if (dpp) body.push_back("v_and_b32 v" + std::to_string(L15) + ", 0x78, %[lane8]");
+        body.push_back("s_nop 4");                            // (an SGPR written by a VALU instruction is not an address at once)
+        if (dpp) {
+            body.push_back("s_mov_b64 " + sreg(KB) + ", " + sreg(KT));
+            for (int c = 0; c < NR; ++c) issue_ring(c);        // every slot: chunk c + NR follows into the slot chunk c leaves
+            for (int i = 0; i < R; ++i) { body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0"); touched[i] = 1; }
+            if (P > 0) lds_reads(0);
+            vm_wait(ring_op[0], false);
+            lds_wait();
+        } else {
+            issue_chunk(0);
+            if (P > 0) lds_reads(0);
+            lds_wait();
+            issue_chunk(1);
+        }
+        for (int i = 0; i < R; ++i) {
+            const Row &r = rows[own[i]];
+            if (r.has_c0 && r.c0 != 0.0) { AIns in; in.kind = AIns::MovK; in.row = i; in.coef = r.c0; place(in); }
+        }
+        // where the step-start state lands.  Early: cache slots the last phases do not use (two halves: the idle half during the last
+        // phase), requested when phase `y_phase` starts; late (what does not fit there): the cache after the last phase, in batches.
+        std::vector<int> yreg(R, -1), yop(R, -1);
+        std::vector<int> early_regs, late_regs;
+        int y_phase = P;
+        if (pp && P > 0) {
+            const int idle = C0 + 2 * (((P - 1) & 1) ? 0 : half), act = C0 + 2 * (((P - 1) & 1) ? half : 0);
+            for (int i = 0; i < half; ++i) { early_regs.push_back(idle + 2 * i); late_regs.push_back(act + 2 * i); }
+            y_phase = P - 1;
+        } else if (P > 0) {
+            // the longest tail of phases (at most 3) that leaves room for every row, else the last phase alone
+            int used = 0;
+            y_phase = P - 1;
+            for (int p = P - 1; p >= std::max(0, P - 3); --p) {
+                const int u = std::max(used, (int)phases[p].modes.size());
+                if (p < P - 1 && NS - u < R) break;
+                used = u;
+                y_phase = p;
+            }
+            for (int i = used; i < NS; ++i) early_regs.push_back(C0 + 2 * i);
+            for (int i = 0; i < used; ++i) late_regs.push_back(C0 + 2 * i);
+        } else {
+            for (int i = 0; i < NS; ++i) late_regs.push_back(C0 + 2 * i);
+        }
+        for (int l = 0; l < NL; ++l) late_regs.push_back(T0 + 2 * l);
+        const int y_early = std::min(R, (int)early_regs.size());
+        for (int i = 0; i < y_early; ++i) yreg[i] = early_regs[i];
+        auto y_loads = [&](int from, int to, bool maybe) {
+            for (int i = from; i < to; ++i) {
+                const std::string at = ybase(i);
+                body.push_back("global_load_dwordx2 " + vreg(yreg[i]) + ", %[lane8], " + at);
+                yop[i] = vm_issue(maybe);
+            }
+        };
+
+        for (int p = 0; p < P; ++p) {
+            const Phase &ph = phases[p];
+            if (pp) {
+                if (lds_pending) { lds_wait(); ++n_extra_waits; }
+                if (p + 1 < P) lds_reads(p + 1);
+            } else if (p > 0) { lds_reads(p); lds_wait(); ++n_extra_waits; }
+            if (p == y_phase && y_early > 0) {
+                body.push_back("s_cmp_lg_u32 s" + std::to_string(LAST) + ", 0");
+                body.push_back("s_cbranch_scc1 .Lqgs_ny%=");
+                yb_block = -1;
+                y_loads(0, y_early, true);
+                body.push_back(".Lqgs_ny%=:");
+            }
+            const int base = cache_base(p);
+            std::map<int, int> xreg;
+            for (size_t i = 0; i < ph.modes.size(); ++i) xreg[ph.modes[i]] = base + 2 * (int)i;
+            // statements of the phase: grouped (equal |c| within a row), then singles sharing their product
+            std::map<std::pair<int, double>, std::vector<PTerm>> pieces;
+            std::vector<PTerm> singles;
+            for (const PTerm &t : ph.terms) {
+                if (t.j == 0) singles.push_back(t);
+                else pieces[{t.row, std::fabs(t.c)}].push_back(t);
+            }
+            std::vector<const std::vector<PTerm> *> piece_list;
+            for (auto &kv : pieces) piece_list.push_back(&kv.second);
+            std::stable_sort(piece_list.begin(), piece_list.end(), [](const std::vector<PTerm> *x, const std::vector<PTerm> *y) {
+                return std::fabs((*x)[0].c) < std::fabs((*y)[0].c);
+            });
+            std::vector<Statement> sts;
+            for (const std::vector<PTerm> *gp : piece_list) {
+                const std::vector<PTerm> &g = *gp;
+                if (g.size() == 1) { singles.push_back(g[0]); continue; }
+                Statement s;
+                const bool ref_neg = std::signbit(g[0].c);
+                for (size_t n = 0; n < g.size(); ++n) {
+                    AIns in;
+                    in.kind = n == 0 ? AIns::MulT : AIns::FmaT;
+                    in.a = xreg[g[n].j]; in.b = xreg[g[n].k];
+                    in.neg = std::signbit(g[n].c) != ref_neg;
+                    s.ins.push_back(in);
+                }
+                AIns in; in.kind = AIns::AccK; in.row = ridx[g[0].row]; in.coef = g[0].c; in.src = -1;
+                s.ins.push_back(in);
+                sts.push_back(std::move(s));
+            }
+            std::sort(singles.begin(), singles.end(), [](const PTerm &x, const PTerm &y) {
+                return x.j != y.j ? x.j < y.j : (x.k != y.k ? x.k < y.k : x.row < y.row);
+            });
+            for (size_t a = 0; a < singles.size();) {
+                size_t b = a;
+                while (b < singles.size() && singles[b].j == singles[a].j && singles[b].k == singles[a].k) ++b;
+                Statement s;
+                const PTerm &t0 = singles[a];
+                if (t0.j != 0) {
+                    AIns in; in.kind = AIns::MulT; in.a = xreg[t0.j]; in.b = xreg[t0.k];
+                    s.ins.push_back(in);
+                }
+                for (size_t q = a; q < b; ++q) {
+                    AIns in; in.kind = AIns::AccK; in.row = ridx[singles[q].row]; in.coef = singles[q].c;
+                    in.src = t0.j == 0 ? xreg[t0.k] : -1;
+                    s.ins.push_back(in);
+                }
+                sts.push_back(std::move(s));
+                a = b;
+            }
+            // NL statements in flight, their instructions round-robin (independent fp64 dependency chains)
+            std::vector<size_t> cur(NL), pos(NL, 0);
+            size_t next = 0;
+            for (int l = 0; l < NL; ++l) cur[l] = next < sts.size() ? next++ : (size_t)-1;
+            for (bool any = true; any;) {
+                any = false;
+                for (int l = 0; l < NL; ++l) {
+                    if (cur[l] == (size_t)-1) continue;
+                    AIns in = sts[cur[l]].ins[pos[l]++];
+                    in.t = T0 + 2 * l;
+                    if (in.kind == AIns::AccK && in.src < 0) in.src = in.t;
+                    place(in);
+                    any = true;
+                    if (pos[l] == sts[cur[l]].ins.size()) { cur[l] = next < sts.size() ? next++ : (size_t)-1; pos[l] = 0; }
+                }
+            }
+        }
+        for (int i = 0; i < R; ++i)
+            if (!touched[i]) body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0");
+        // -- end of the stage: acc += hb k; next stage state = y + ha k (or the new state after the last stage)
+        for (int i = 0; i < R; ++i)
+            body.push_back("v_fma_f64 " + vreg(ACC(i)) + ", %[hb], " + vreg(KR(i)) + ", " + vreg(ACC(i)));
+        body.push_back("s_cmp_lg_u32 s" + std::to_string(LAST) + ", 0");
+        body.push_back("s_cbranch_scc1 .Lqgs_last%=");
+        yb_block = -1;
+        {
+            const int B = (int)late_regs.size();
+            int issued_to = std::min(R, y_early + B);
+            for (int i = y_early; i < issued_to; ++i) yreg[i] = late_regs[(i - y_early) % B];
+            y_loads(y_early, issued_to, false);
+            for (int i = 0; i < R; ++i) {
+                if (i >= issued_to) {                      // next batch: its registers are those of rows consumed a batch ago
+                    const int to = std::min(R, issued_to + B);
+                    for (int q = issued_to; q < to; ++q) yreg[q] = late_regs[(q - y_early) % B];
+                    y_loads(issued_to, to, false);
+                    issued_to = to;
+                }
+                vm_wait(yop[i], true);
+                body.push_back("v_fma_f64 " + vreg(KR(i)) + ", %[ha], " + vreg(KR(i)) + ", " + vreg(yreg[i]));
+            }
+        }
+        body.push_back("s_barrier");
+        auto xs_write = [&](int reg0) {
+            for (int i = 0; i < R; ++i) {
+                const int64_t off = (int64_t)(own[i] - 1) * 512;
+                body.push_back("ds_write_b64 " + (off >= 65536 ? "v" + std::to_string(LB1) : std::string("%[lds]")) + ", " + vreg(reg0 + 2 * i) +
+                               " offset:" + std::to_string(off & 65535));
+            }
+        };
+        xs_write(K0);
+        body.push_back("s_branch .Lqgs_join%=");
+        body.push_back(".Lqgs_last%=:");
+        yb_block = -1;
+        for (int i = 0; i < R; ++i) {
+            const std::string at = ybase(i);
+            body.push_back("global_store_dwordx2 %[lane8], " + vreg(ACC(i)) + ", " + at);
+        }
+        body.push_back("s_barrier");
+        xs_write(ACC0);
+        body.push_back(".Lqgs_join%=:");
+        // nothing is left in flight (coefficient chunks requested ahead of the table's end included)
+        body.push_back("s_waitcnt vmcnt(0) lgkmcnt(0)");
+        body.push_back("s_barrier");
+        tab.pad_to = ((size_t)chunk + (dpp ? NR + 1 : 2)) * CE;
+
+        o << I4 << "// " << R << " rows, cache " << NS << " slots, phases of <= " << pl.cap << " modes: " << P << " phases, " << wave_instr[w]
+          << " fp64 instructions\n";
+        o << I4 << "asm volatile(\n";
+        for (const std::string &ln : body) o << I4 << "    \"" << ln << "\\n\"\n";
+        o << I4 << "    :";
+        for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << "\"+{" << vreg(ACC(i)) << "}\"(acc" << own[i] << ")";
+        o << "\n" << I4 << "    : [lds] \"v\"(ldsaddr), [lane8] \"v\"(lane8), [hb] \"v\"(hb), [ha] \"v\"(ha), [ktlo] \"v\"(ktlo), [kthi] \"v\"(kthi), "
+          << "[ywlo] \"v\"(ywlo), [ywhi] \"v\"(ywhi), [last] \"v\"(last)\n";
+        o << I4 << "    :";
+        bool first = true;
+        for (int r = K0; r < VT; ++r) { o << (first ? " " : ", ") << "\"v" << r << "\""; first = false; }
+        for (int r = SF; r < LAST + 1; ++r) o << ", \"s" << r << "\"";
+        o << ", \"scc\", \"memory\");\n";
+        o << I3 << "}\n";
+        o << I2 << "}\n";
+        o << I2 << "if (live) {\n" << I3 << "if (y_out) {\n";
+        for (int d : own) o << I4 << "y_out[" << (d - 1) << " * ld + m] = " << "acc" << d << ";\n";
+        o << I3 << "}\n" << I3 << "if (write_final) {\n"
+          << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
+        for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = " << "acc" << d << ";\n";
+        o << I3 << "}\n" << I2 << "}\n    }\n";
+    }
+    o << "    QGS_CLOCK_MARK(2)\n}\n";
+    out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
+        << " fp64 instructions, " << stats.coef << " coefficient table entries in " << n_chunks + W << " chunks, "
+        << n_extra_waits << " further waits for LDS reads\n";
+    {
+        int64_t mx = 0, sum = 0;
+        for (int64_t v : wave_instr) { mx = std::max(mx, v); sum += v; }
+        out << "// fp64 instructions of the wavefronts: max / mean = " << (sum ? (double)mx * W / (double)sum : 0.0) << "\n";
+    }
+    for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
+    out << o.str();
+}
+
+}  // namespace detail
+}  // namespace qgs

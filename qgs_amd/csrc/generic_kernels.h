@@ -145,7 +145,7 @@ void launch_clv_backstep(int nv, int64_t n_traj, int64_t ld, const double *rm, c
                          const double *noise, double pert, hipStream_t st);
 // any shape (n_cols > 64 or matrices beyond the LDS): matrix in a global scratch copy, blocked (dgeqrf + dorgqr, 16-column panels) up to
 // 400 rows; scratch = n_traj * ((n_rows + 17) * n_cols + 256) doubles
-void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
+const char *launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
                               hipStream_t st);
 // mean / variance over the members of every row of X[row][member]; `part` holds 2 * n_rows * moments_splits() doubles
 int moments_splits(int64_t n_rows, int64_t n_traj);

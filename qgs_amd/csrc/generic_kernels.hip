@@ -1476,17 +1476,35 @@ __global__ void __launch_bounds__(QRB_THREADS) batched_qr_blocked_kernel(int n_r
 // rows the blocked kernel holds a panel of in its LDS
 constexpr int QRB_MAX_ROWS = 400;
 
-void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
-                              hipStream_t st)
+// Returns the name of the kernel that was launched.  The blocked kernel needs 2 * 8 * 18 * n_rows bytes of dynamic LDS next to 4.5 KB of
+// static LDS (70 KB at 228 rows, 119 KB at 400): where the device does not grant that (the attribute call fails, or the device's
+// opt-in limit is smaller -- any GPU with 64 KB of LDS), the unblocked kernel (8 * n_rows bytes) takes every shape, as before round 5.
+const char *launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, double *scratch,
+                                     hipStream_t st)
 {
-    if (n_rows <= QRB_MAX_ROWS) {
-        double *t_store = scratch + (size_t)n_traj * n_rows * n_cols;
-        const size_t lds = 2 * sizeof(double) * (size_t)n_rows * QRB_PITCH;
-        static DynLdsLimit configured(64 * 1024 - 4608);          // per device, see launch_tiled (4.5 KB of static LDS next to it)
+    constexpr size_t QRB_STATIC_LDS = 4608;
+    bool blocked = n_rows <= QRB_MAX_ROWS;
+    const size_t lds = 2 * sizeof(double) * (size_t)n_rows * QRB_PITCH;
+    if (blocked) {
+        static DynLdsLimit configured(64 * 1024 - QRB_STATIC_LDS);          // per device, see launch_tiled
         if (configured.needs(lds)) {
-            if (hipFuncSetAttribute((const void *)batched_qr_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            int dev = 0, optin = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) optin = 0;
+            if (optin > 0 && lds + QRB_STATIC_LDS > (size_t)optin) blocked = false;
+            else if (hipFuncSetAttribute((const void *)batched_qr_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
                 configured.set(lds);
+            else {
+                (void)hipGetLastError();                                    // the refusal is handled here, not reported by a later call
+                blocked = false;
+            }
         }
+    }
+#ifdef QGS_HIP_DEV_KNOBS
+    if (const char *e = std::getenv("QGS_HIP_QR_UNBLOCKED")) if (*e == '1') blocked = false;
+#endif
+    if (blocked) {
+        double *t_store = scratch + (size_t)n_traj * n_rows * n_cols;
         int skip = 0;
 #ifdef QGS_HIP_DEV_KNOBS
         if (const char *e = std::getenv("QGS_HIP_QRB_SKIP")) skip = std::atoi(e);
@@ -1498,11 +1516,12 @@ void launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int64_t ld
         hipLaunchKernelGGL(batched_qr_blocked_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(QRB_THREADS), lds, st, n_rows, n_cols,
                            n_traj, ld, a, rdiag, scratch, t_store, skip | 8);
         hipLaunchKernelGGL(pack_kernel, dim3(blocks_for(n_traj, TILE), blocks_for(n_inner, TILE)), dim3(256), 0, st, n_inner, n_traj, ld, scratch, a);
-        return;
+        return "batched_qr_blocked_kernel";
     }
     double *taus = scratch + (size_t)n_traj * n_rows * n_cols;
     hipLaunchKernelGGL(batched_qr_global_kernel, dim3((unsigned)(8 * ((n_traj + 7) / 8))), dim3(QRG_THREADS), sizeof(double) * (size_t)n_rows, st,
                        n_rows, n_cols, n_traj, ld, a, rdiag, scratch, taus);
+    return "batched_qr_global_kernel";
 }
 
 void launch_batched_qr(int n_rows, int n_cols, int64_t n_traj, int64_t ld, double *a, double *rdiag, hipStream_t st)

@@ -1347,6 +1347,17 @@ void apply_env_options(qgs::CodegenOptions &cg)
     if (const char *e = std::getenv("QGS_HIP_ROW_SPLIT")) cg.row_split = std::max(1, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_TGL_SHARE_X")) cg.tgl_share_x = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_INTERLEAVE")) cg.interleave = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM")) cg.lds_asm = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_WAVES")) cg.lds_asm_waves = std::min(16, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_CAP")) cg.lds_asm_cap = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_PP")) cg.lds_asm_pingpong = (*e == '1');
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_LANES")) cg.lds_asm_lanes = std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_CHUNK")) cg.lds_asm_chunk = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_COEF")) cg.lds_asm_coef = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_RING")) cg.lds_asm_ring = std::max(2, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_MINCAP")) cg.lds_asm_mincap = std::max(4, std::atoi(e));
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_VFREE")) cg.lds_asm_vfree = std::atoi(e);
+    if (const char *e = std::getenv("QGS_HIP_LDS_ASM_SFREE")) cg.lds_asm_sfree = std::atoi(e);
     if (const char *e = std::getenv("QGS_HIP_LDS_WAVES")) cg.lds_waves = std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("QGS_HIP_LDS_CAP")) cg.lds_cap = std::max(2, std::atoi(e));
     if (const char *e = std::getenv("QGS_HIP_LDS_GROUP")) cg.lds_group = (*e == '1');
@@ -1497,7 +1508,9 @@ int launch_rk_lds(qgs_model *m, int64_t n_traj, int64_t ld, const double *y_in, 
     void *args[] = {(void *)&y_in, &y_out, &yw, &d_rec, &stages, (void *)&d_time, (void *)&d_tab,
                     &nt, &l, &sb, &se, &ws, &nr, &bw, &wf, &S, &one};      // `one`: the extra argument of the tendencies-only flavour
     note_kernel(m, name, f);
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * m->cg.lds_waves, 1, 1, 0, st, args, nullptr));
+    // (the hand-scheduled stepper has a workgroup shape of its own; the tendencies-only flavour is always the compiler-scheduled one)
+    const int waves = (which == qgs::Kernel::RkLds && m->cg.lds_asm) ? m->cg.lds_asm_waves : m->cg.lds_waves;
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)blocks, 1, 1, 64 * waves, 1, 1, 0, st, args, nullptr));
     return 0;
 }
 
@@ -1673,6 +1686,7 @@ int qgs_model_create_rank(int device, int ndim, int rank, int64_t nnz, const int
     if (r5 && upload_reduced(m)) { qgs_model_destroy(m); return -1; }
     classify_model(m);
     apply_env_options(m->cg);
+    if (!m->der.t.empty()) m->cg.lds_asm = false;       // the hand-scheduled LDS stepper takes rank-3 tensors only
     m->tune.read_env();
     if (r5) m->cg.row_split = 1;       // the row-split stepper would evaluate the derived monomials once per wavefront
     *out = m;
@@ -2185,8 +2199,7 @@ int qgs_batched_qr_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_rows, 
     if (n_cols > 64 || n_rows > 300) {
         // beyond one column per lane / the LDS (e.g. the full 228-vector Lyapunov basis of MAOOAM 6x6): global-memory kernel
         if (m->work.ensure(sizeof(double) * (size_t)n_traj * (((size_t)n_rows + 17) * (size_t)n_cols + 256))) return -1;
-        qgs::launch_batched_qr_global(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->work.f64(), (hipStream_t)stream);
-        note_kernel(m, n_rows <= 400 ? "batched_qr_blocked_kernel" : "batched_qr_global_kernel", nullptr);
+        note_kernel(m, qgs::launch_batched_qr_global(n_rows, n_cols, n_traj, ld, d_a, d_rdiag, m->work.f64(), (hipStream_t)stream), nullptr);
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -3248,6 +3261,7 @@ int qgs_prebuild_rank(int ndim, int rank, int64_t nnz, const int32_t *coo, const
     m.arch = (arch && *arch) ? arch : target_arch(-1);
     if (load_tensors(&m, rank, nnz, coo, val, jnnz, jcoo, jval, nullptr, nullptr)) return -1;
     apply_env_options(m.cg);
+    if (!m.der.t.empty()) m.cg.lds_asm = false;
     if (rank == 5) m.cg.row_split = 1;
     std::vector<int> stages(stage_counts, stage_counts + n_stage_counts);
     classify_model(&m);

@@ -247,6 +247,15 @@ class _RecordWindows(object):
         self.used = None
         self.flushed += 1
 
+    def abort(self):
+        """After an exception inside a run: wait for every stream of the device and for the drain thread (a secondary error is
+        swallowed -- the first one is what the caller sees)."""
+        for wait in (lambda: self.torch.cuda.synchronize(self.compute.device), self.m.drain_wait):
+            try:
+                wait()
+            except Exception:
+                pass
+
     def finish(self, wait=True):
         """Hand the last window over; `wait=False`: the caller waits for the drain itself (`HipModel.drain_wait`), after it has
         enqueued more work -- the member groups of `LyapunovsEstimator._compute_shard`."""
@@ -499,7 +508,7 @@ class LyapunovsEstimator(object):
         # a group's window + its staging block, two groups in flight: within a third of the free memory; eight groups or more where
         # that leaves 2 048 members per group (the tangent kernels fill the GPU from there), never fewer than 1 024
         cap = (free // 3) // (4 * per_member) // 64 * 64
-        g = min(cap, max(2048, -(-n // 8 + 63) // 64 * 64))
+        g = min(cap, max(2048, ((n + 7) // 8 + 63) // 64 * 64))
         if g < 1024 or g >= n:
             return n, None
         return int(g), 2 * per_member * int(g) + (1 << 20)
@@ -595,54 +604,61 @@ class LyapunovsEstimator(object):
                 return slots[3]
             return None
 
-        if not forward:
-            # ---- backward Lyapunov vectors (lyapunov.py:564-632) ----
-            pre, tim = self._pretime, self._time
-            rdiag = None
-            for ti in range(len(pre) - 1):
-                tt, d = pre[ti], pre[ti + 1] - pre[ti]
-                sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
-                rdiag = propagate(ti, sub, 1)
-            if rdiag is None:       # no spin-up interval
-                rdiag = rdiag0
-            if out_junction is not None:
-                out_junction[...] = _lib.to_host(base.state(at[n_pre - 1])[:, :n].t())
-            iw, last = 0, None
-            for ti in range(len(tim) - 1):
-                tt, d = tim[ti], tim[ti + 1] - tim[ti]
-                last = (rdiag, d)                                                   # m_exp = log|diag r| / dt
-                pre = None
-                if write_steps > 0 and ti % write_steps == 0:
-                    pre = record(iw, n_pre - 1 + ti, rdiag, d)
-                    iw += 1
-                sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
-                rdiag = propagate(n_pre - 1 + ti, sub, 1, pre)
-            record(self.n_records - 1, len(at) - 1, last[0] if last else None, last[1] if last else 1.0)
-        else:
-            # ---- forward Lyapunov vectors (lyapunov.py:480-552): integrate the tangent model backward in time ----
-            tim, post = self._pretime, self._time            # the reference's (time, posttime)
-            rpost, rtim = reverse(post), reverse(tim)
-            n_t = len(tim)
-            rdiag = None
-            for ti in range(len(rpost) - 1):
-                tt, d = rpost[ti], rpost[ti + 1] - rpost[ti]
-                sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
-                rdiag = propagate(n_t - 1 + (len(post) - 1 - ti), sub, -1)          # posttraj[:, :, -1-ti]
-            if rdiag is None:
-                rdiag = rdiag0
-            iw, last, y_idx = self.n_records - 1, None, n_t - 1
-            for ti in range(len(rtim) - 1):
-                tt, d = rtim[ti], rtim[ti + 1] - rtim[ti]
-                y_idx = n_t - 1 - ti                                                 # traj[:, :, -1-ti]
-                last = (rdiag, d)
-                if write_steps > 0 and ti % write_steps == 0:
-                    record(iw, y_idx, rdiag, d)
-                    iw -= 1
-                sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
-                rdiag = propagate(y_idx, sub, -1)
-            record(0, y_idx, last[0] if last else None, last[1] if last else 1.0)
+        try:
+            if not forward:
+                # ---- backward Lyapunov vectors (lyapunov.py:564-632) ----
+                pre, tim = self._pretime, self._time
+                rdiag = None
+                for ti in range(len(pre) - 1):
+                    tt, d = pre[ti], pre[ti + 1] - pre[ti]
+                    sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
+                    rdiag = propagate(ti, sub, 1)
+                if rdiag is None:       # no spin-up interval
+                    rdiag = rdiag0
+                if out_junction is not None:
+                    out_junction[...] = _lib.to_host(base.state(at[n_pre - 1])[:, :n].t())
+                iw, last = 0, None
+                for ti in range(len(tim) - 1):
+                    tt, d = tim[ti], tim[ti + 1] - tim[ti]
+                    last = (rdiag, d)                                                   # m_exp = log|diag r| / dt
+                    pre = None
+                    if write_steps > 0 and ti % write_steps == 0:
+                        pre = record(iw, n_pre - 1 + ti, rdiag, d)
+                        iw += 1
+                    sub = np.concatenate((np.arange(tt, tt + d, mdt), np.full((1,), tt + d)))
+                    rdiag = propagate(n_pre - 1 + ti, sub, 1, pre)
+                record(self.n_records - 1, len(at) - 1, last[0] if last else None, last[1] if last else 1.0)
+            else:
+                # ---- forward Lyapunov vectors (lyapunov.py:480-552): integrate the tangent model backward in time ----
+                tim, post = self._pretime, self._time            # the reference's (time, posttime)
+                rpost, rtim = reverse(post), reverse(tim)
+                n_t = len(tim)
+                rdiag = None
+                for ti in range(len(rpost) - 1):
+                    tt, d = rpost[ti], rpost[ti + 1] - rpost[ti]
+                    sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
+                    rdiag = propagate(n_t - 1 + (len(post) - 1 - ti), sub, -1)          # posttraj[:, :, -1-ti]
+                if rdiag is None:
+                    rdiag = rdiag0
+                iw, last, y_idx = self.n_records - 1, None, n_t - 1
+                for ti in range(len(rtim) - 1):
+                    tt, d = rtim[ti], rtim[ti + 1] - rtim[ti]
+                    y_idx = n_t - 1 - ti                                                 # traj[:, :, -1-ti]
+                    last = (rdiag, d)
+                    if write_steps > 0 and ti % write_steps == 0:
+                        record(iw, y_idx, rdiag, d)
+                        iw -= 1
+                    sub = np.concatenate((np.arange(tt + d, tt, mdt), np.full((1,), tt)))
+                    rdiag = propagate(y_idx, sub, -1)
+                record(0, y_idx, last[0] if last else None, last[1] if last else 1.0)
 
-        rec.finish(wait=not grouped)               # (a member group: the caller waits for the drain after the last group)
+            rec.finish(wait=not grouped)               # (a member group: the caller waits for the drain after the last group)
+        except BaseException:
+            # the drain thread may still be scattering flushed windows into the result blocks: nothing of this run is on its way
+            # into them (or left in the model's drain tickets / staging pool) when the exception reaches the caller, who frees or
+            # recycles those blocks
+            rec.abort()
+            raise
         return base.n_windows, rec.n_windows
 
     def get_lyapunovs(self):
@@ -1020,15 +1036,19 @@ class CovariantLyapunovsEstimator(object):
             # local exponents from the norms of the backward step, on the device: -log|norm| / dt   (lyapunov.py:1280, 1285)
             m.local_exponents_device(nv * ld, norm.data_ptr(), -dte[ti], s_norm.data_ptr(), stream)
         iw = 1
-        for k, ti in enumerate(range(tw, -1, -1)):
-            m.clv_backstep_device(n, ld, nv, r_all[ti].data_ptr(), am.data_ptr(), am_new.data_ptr(), norm.data_ptr(),
-                                  nz_time[k].data_ptr() if nz_time is not None else None, pert, stream)
-            am, am_new = am_new, am
-            if ws > 0 and (tw - ti) % ws == 0:
-                record(self.n_records - iw, ti)
-                iw += 1
-        record(0, 0)
-        rec.finish()
+        try:
+            for k, ti in enumerate(range(tw, -1, -1)):
+                m.clv_backstep_device(n, ld, nv, r_all[ti].data_ptr(), am.data_ptr(), am_new.data_ptr(), norm.data_ptr(),
+                                      nz_time[k].data_ptr() if nz_time is not None else None, pert, stream)
+                am, am_new = am_new, am
+                if ws > 0 and (tw - ti) % ws == 0:
+                    record(self.n_records - iw, ti)
+                    iw += 1
+            record(0, 0)
+            rec.finish()
+        except BaseException:
+            rec.abort()            # (as in LyapunovsEstimator._compute_shard_on_current_device)
+            raise
         return t_forward - t_start, _clock.perf_counter() - t_forward
 
     def _subspaces(self, mdt, backward_vectors, forward_vectors):

@@ -14,6 +14,7 @@ statement, are checked here on the COMPILED instruction stream:
 
 The factors themselves are checked against LAPACK on the GPU (tests/test_gpu_lyapunov.py), the algorithm being that of
 np.linalg.qr as the reference uses it (qgs/toolbox/lyapunov.py:600-610)."""
+import glob
 import os
 import re
 import shutil
@@ -204,7 +205,7 @@ def test_compiled_model_kernels_have_no_inline_asm_hazard(tmp_path):
     from conftest import GOLDEN_DIR
     csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), 'csrc')
     dump = str(tmp_path / 'codegen_dump')
-    subprocess.run(['g++', '-O1', '-std=c++17', '-o', dump, os.path.join(csrc, 'codegen_dump.cpp'), os.path.join(csrc, 'codegen.cpp')],
+    subprocess.run(['g++', '-O1', '-std=c++17', '-o', dump, os.path.join(csrc, 'codegen_dump.cpp')] + [f for f in sorted(glob.glob(os.path.join(csrc, 'codegen*.cpp'))) if not f.endswith('codegen_dump.cpp')],
                    check=True, timeout=600)
     g = np.load(os.path.join(GOLDEN_DIR, 'm36.npz'))
     txt = tmp_path / 'm36.txt'

@@ -1,6 +1,7 @@
 """CPU: the kernel generator (a 1.9 k-line string builder, qgs_amd/csrc/codegen.cpp) under AddressSanitizer + UBSan on every golden
 tensor, every emitter (register-resident, general-tableau, LDS-resident, tangent / adjoint, batched QR).  GPU sanitizers are not
 available on the pool; the generator is host code and is checked here."""
+import glob
 import os
 import subprocess
 
@@ -16,7 +17,7 @@ CSRC = os.path.join(REPO, 'qgs_amd', 'csrc')
 def dump_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp('san') / 'codegen_dump_san')
     subprocess.run(['g++', '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=undefined',
-                    '-fno-omit-frame-pointer', '-o', out, os.path.join(CSRC, 'codegen_dump.cpp'), os.path.join(CSRC, 'codegen.cpp')],
+                    '-fno-omit-frame-pointer', '-o', out, os.path.join(CSRC, 'codegen_dump.cpp')] + [f for f in sorted(glob.glob(os.path.join(CSRC, 'codegen*.cpp'))) if not f.endswith('codegen_dump.cpp')],
                    check=True, timeout=600)
     return out
 

@@ -11,6 +11,7 @@ import json
 import os
 
 import numpy as np
+from kernel_names import LDS_STEPPER, LDS_STEPPER_RANK5
 import pytest
 
 from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
@@ -122,7 +123,7 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
     refs = [ora.integrate_runge_kutta_jit(t, ic, d, ws, b, c, a, threads=4) for d, ws, b, c, a in cases]
     tg = rng.randn(min(n_traj, 3), g.ndim, 2)
     rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
-    for kind, kname in ((1, 'gen_rk_tiled_kernel'), (2, 'qgs_spec_rklds16')):
+    for kind, kname in ((1, 'gen_rk_tiled_kernel'), (2, LDS_STEPPER)):
         m.set_kernel(kind)
         for (d, ws, b, c, a), ref in zip(cases, refs):
             out = m.rk_integrate(t, ic, d, ws, b, c, a)
@@ -189,7 +190,7 @@ def test_rank5_models_vs_oracle(models, name, n_traj):
         assert rel_err(m.jacobian(ic[:nt]), ora.Df(0., ic[:nt])) < 1e-14, kind
         assert rel_err(m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a']), ref4) < 1e-12, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_rk_s4' if name == 'd38' else 'qgs_spec_rklds16')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_rk_s4' if name == 'd38' else LDS_STEPPER_RANK5)
         assert rel_err(m.rk_integrate(t, ic, -1, 0, b2, c2, a2), ref2) < 1e-12, kind
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
@@ -362,7 +363,7 @@ def test_full_size_properties_config3(models):
     ic = np.random.RandomState(3).rand(n, g.ndim) * 0.01
     t = np.concatenate((np.arange(0., 2.0, 0.1), [2.0]))
     full = m.rk_integrate(t, ic, 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
-    assert m.last_kernel_info()['name'] == 'qgs_spec_rklds16'
+    assert m.last_kernel_info()['name'] == LDS_STEPPER
     assert np.isfinite(full).all()
     pick = np.array([0, 15, 16, 63, 64, 1000, 32767, 65535])
     alone = m.rk_integrate(t, ic[pick], 1, 0, RK4['b'], RK4['c'], RK4['a'])[:, :, 0]
@@ -517,7 +518,7 @@ def test_lds_resident_kernels_on_a_second_tensor_ndim72():
     t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
     ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = rng.randn(9, f.ndim, 6)
-    for kind, names in ((1, ('gen_rk_tiled_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16'))):
+    for kind, names in ((1, ('gen_rk_tiled_kernel', None)), (2, (LDS_STEPPER, 'qgs_spec_tgllds16'))):
         m.set_kernel(kind)
         out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
         assert m.last_kernel_info()['name'] == names[0]
@@ -556,7 +557,7 @@ def test_lds_resident_kernels_rank5_ndim106(monkeypatch, tile_members):
     ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = rng.randn(9, f.ndim, 6)
     sfx = 'm8' if tile_members == 8 else ''
-    for kind, names in ((1, ('gen_rk_kernel', None)), (2, ('qgs_spec_rklds16', 'qgs_spec_tgllds16' + sfx))):
+    for kind, names in ((1, ('gen_rk_kernel', None)), (2, (LDS_STEPPER_RANK5, 'qgs_spec_tgllds16' + sfx))):
         m.set_kernel(kind)
         assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14, kind
         out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
@@ -614,13 +615,13 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     assert stepper_name(m36, 36, 65536, *r38) == 'qgs_spec_rkd_s4'
     t228 = models('t228')
     t228.set_kernel(0)
-    assert stepper_name(t228, 228, 4096) == 'qgs_spec_rklds16'
+    assert stepper_name(t228, 228, 4096) == LDS_STEPPER
     assert stepper_name(t228, 228, 1) == 'gen_rk_wave_kernel'        # lane-group variant (4 lanes per row)
     d38, q38 = models('d38'), models('q38')
     d38.set_kernel(0)
     q38.set_kernel(0)
     assert stepper_name(d38, 38, 65536) == 'qgs_spec_rk_s4'
-    assert stepper_name(q38, 38, 4096) == 'qgs_spec_rklds16'
+    assert stepper_name(q38, 38, 4096) == LDS_STEPPER_RANK5
     assert stepper_name(q38, 38, 1) == 'gen_rk_wave_kernel'
     assert stepper_name(d38, 38, 1) == 'gen_rk_wave_kernel'
 

@@ -10,6 +10,7 @@ import ctypes
 import os
 
 import numpy as np
+from kernel_names import LDS_STEPPER
 import pytest
 
 from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
@@ -633,7 +634,7 @@ def test_cache_miss_compiles_the_same_lds_stepper(tmp_path):
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     out = p.stdout.decode()
     info = json.loads([ln for ln in out.splitlines() if ln.startswith('INFO ')][0][5:])
-    assert info['name'] == 'qgs_spec_rklds16', info
+    assert info['name'] == LDS_STEPPER, info
     assert info['vgprs'] <= 128 and info['scratch_bytes'] <= 448, info
     assert 'FINITE 1' in out
 

@@ -10,12 +10,14 @@ hits (damaged / foreign entries are recompiled), bounded cache directory, decode
 GPU part: the Done-criteria of VERDICT round 3 item 1 (three parameter values, one set of objects, bitwise equal to
 from-scratch compiles, second and third model in < 0.2 s; the same at ndim 228)."""
 import json
+import glob
 import os
 import subprocess
 import sys
 import time
 
 import numpy as np
+from kernel_names import LDS_STEPPER
 import pytest
 
 from conftest import GOLDEN_DIR, REPO, load_golden
@@ -217,7 +219,7 @@ def test_cache_directory_is_bounded(tmp_path):
 @pytest.fixture(scope='module')
 def dump_binary(tmp_path_factory):
     out = str(tmp_path_factory.mktemp('cgd') / 'codegen_dump')
-    subprocess.run(['g++', '-O1', '-std=c++17', '-o', out, os.path.join(CSRC, 'codegen_dump.cpp'), os.path.join(CSRC, 'codegen.cpp')],
+    subprocess.run(['g++', '-O1', '-std=c++17', '-o', out, os.path.join(CSRC, 'codegen_dump.cpp')] + [f for f in sorted(glob.glob(os.path.join(CSRC, 'codegen*.cpp'))) if not f.endswith('codegen_dump.cpp')],
                    check=True, timeout=600)
     return out
 
@@ -382,4 +384,4 @@ def test_sweep_of_the_bench_model_compiles_once(tmp_path):
 
 @pytest.mark.gpu
 def test_sweep_at_ndim_228_compiles_once(tmp_path):
-    _check_sweep(tmp_path, 't228', 4096, False, 'qgs_spec_rklds16')
+    _check_sweep(tmp_path, 't228', 4096, False, LDS_STEPPER)

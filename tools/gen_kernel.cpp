@@ -1,6 +1,6 @@
 // Developer tool: print the generated source of one specialised kernel for a tensor given as text
 // (first line: ndim nnz; then "i j k value" per line, value as hex float or decimal).
-//   g++ -O1 -std=c++17 -I qgs_amd/csrc tools/gen_kernel.cpp qgs_amd/csrc/codegen.cpp -o /tmp/gen_kernel
+//   g++ -O1 -std=c++17 -I qgs_amd/csrc tools/gen_kernel.cpp qgs_amd/csrc/codegen.cpp qgs_amd/csrc/codegen_steppers.cpp qgs_amd/csrc/codegen_tangent.cpp qgs_amd/csrc/codegen_lds.cpp qgs_amd/csrc/codegen_qr.cpp -o /tmp/gen_kernel
 //   /tmp/gen_kernel tensor.txt rklds [stages] > k.hip && hipcc --offload-arch=gfx950 -c -Rpass-analysis=kernel-resource-usage k.hip
 #include <cstdio>
 #include <cstdlib>
