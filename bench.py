@@ -107,13 +107,45 @@ def load_model_tensors(kd=0.0290, kdp=0.0290):
 # ---------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` typed directly
 # ---------------------------------------------------------------------------------------------------------------
-def visible_gpus():
+KFD_NODES = '/sys/class/kfd/kfd/topology/nodes'
+
+
+def masked_count(n, env=None):
+    """`n` physical GPUs cut down by the visibility masks a HIP process honours: ROCR_VISIBLE_DEVICES (applied by the ROCr runtime:
+    indices or `GPU-<uuid>` names), then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES (applied by HIP to what ROCr left).  An entry
+    that is not a valid index ends the list, as in the runtimes (`0,1,-1,2` = two devices); an empty value hides every GPU."""
+    env = os.environ if env is None else env
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = env.get(var)
+        if v is None:
+            continue
+        kept, seen = 0, set()
+        for q in v.split(','):
+            q = q.strip()
+            if q.startswith('GPU-') and len(q) > 4:
+                key = q
+            else:
+                try:
+                    key = int(q)
+                except ValueError:
+                    break
+                if key < 0 or key >= n:
+                    break
+            if key in seen:
+                break
+            seen.add(key)
+            kept += 1
+        n = min(n, kept)
+    return n
+
+
+def visible_gpus(kfd_nodes=None, env=None):
     """Number of GPUs the child ranks will see, counted WITHOUT loading the HIP runtime (the launcher parent must stay
     GPU-free: it only starts child processes): the KFD topology nodes that have SIMDs (CPUs are nodes with simd_count 0),
     cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when set."""
     import glob
     n, seen = 0, 0
-    for path in glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties'):
+    for path in glob.glob(os.path.join(kfd_nodes or KFD_NODES, '*', 'properties')):
         try:
             with open(path) as f:
                 for line in f:
@@ -126,20 +158,20 @@ def visible_gpus():
             pass
     if seen == 0:
         # no readable KFD topology (unusual container): ask a short-lived child, so that this process still never loads HIP
+        # (the child applies the masks itself)
         try:
             out = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'],
                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300).stdout
             return int(out.decode().strip().splitlines()[-1])
         except (OSError, ValueError, IndexError, subprocess.TimeoutExpired):
             return 0
-    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
-        v = os.environ.get(var)
-        if v is not None:
-            n = min(n, len([q for q in v.split(',') if q.strip() != '']))
-    return n
+    return masked_count(n, env)
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, program=None, grace=2.0):
+    """Start `n` ranks of `program` (default: this file) on 127.0.0.1, relay rank 0's standard output, return the exit code.  A rank
+    that dies -- before or after the process group is up -- ends the job: its peers get `grace` seconds to report on their own,
+    then exactly the processes started here are killed and the parent exits non-zero (never a hang in a collective)."""
     import socket
     m = visible_gpus()
     if m < n:
@@ -156,7 +188,7 @@ def launch_ranks(n, argv):
         # device tensors across processes) fails with `hipIpcGetMemHandle: invalid argument` under the legacy mode.  The pool
         # exports the variable already; it is set here only when the operator's environment does not say otherwise.
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+        procs.append(subprocess.Popen([sys.executable, program or os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     # a rank that dies would leave the others waiting in a collective: watch all of them, stop the rest (exactly the
     # processes started above) as soon as one fails
@@ -171,7 +203,7 @@ def launch_ranks(n, argv):
             break
         time.sleep(0.2)
     if failed:
-        time.sleep(2.0)                                   # let the failing rank's peers report on their own first
+        time.sleep(grace)                                 # let the failing rank's peers report on their own first
         for p in procs:
             if p.poll() is None:
                 p.kill()
@@ -184,6 +216,40 @@ def launch_ranks(n, argv):
         print('bench.py: ranks failed (rank, exit code): %r' % bad, file=sys.stderr)
         return 1
     return 0
+
+
+def rccl_report(torch, dist, dev, world, rank):
+    """What the communicator says about itself, for the line of an N > 1 run (and of --force-dist): RCCL's version, the number of
+    ranks the process group reports, how many ranks actually answer a collective, and which GPU every rank sits on -- so that a
+    SCALE record can answer "did RCCL see N ranks on N different GPUs" without a rerun.  Collectives: one all_reduce, one all_gather
+    of 16 numbers; outside every timed region."""
+    out = {'backend': dist.get_backend(), 'world_size_reported': dist.get_world_size(), 'world_size_requested': world}
+    try:
+        v = torch.cuda.nccl.version()
+        out['rccl_version'] = '.'.join(str(q) for q in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        out['rccl_version'] = 'unavailable (%r)' % (e,)
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones)
+    out['ranks_answering_all_reduce'] = int(round(float(ones.item())))
+    props = torch.cuda.get_device_properties(dev)
+    bus = getattr(props, 'pci_bus_id', -1)
+    mine = torch.tensor([rank, dev.index if dev.index is not None else -1, int(bus) if isinstance(bus, int) else -1,
+                         int(getattr(props, 'pci_device_id', -1)), int(getattr(props, 'pci_domain_id', -1)),
+                         int(props.multi_processor_count), int(props.total_memory >> 30), os.getpid()] + [0] * 8,
+                        dtype=torch.int64, device=dev)
+    table = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(table, mine)
+    out['ranks'] = [{'rank': int(t[0]), 'device_index': int(t[1]), 'pci_bus_id': int(t[2]), 'pci_device_id': int(t[3]),
+                     'pci_domain_id': int(t[4]), 'compute_units': int(t[5]), 'memory_gib': int(t[6]), 'pid': int(t[7])} for t in table]
+    out['distinct_gpus'] = len({(r['pci_domain_id'], r['pci_bus_id'], r['pci_device_id'], r['device_index']) for r in out['ranks']})
+    out['device_name'] = props.name
+    out['env'] = {k: os.environ.get(k) for k in ('HSA_ENABLE_IPC_MODE_LEGACY', 'NCCL_DEBUG', 'ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES',
+                                                 'CUDA_VISIBLE_DEVICES', 'MASTER_ADDR', 'NCCL_SOCKET_IFNAME')}
+    if rank == 0:
+        print('bench.py: RCCL %s, %d ranks in the process group, %d answered, %d distinct GPUs' %
+              (out['rccl_version'], out['world_size_reported'], out['ranks_answering_all_reduce'], out['distinct_gpus']), file=sys.stderr)
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1118,6 +1184,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    rccl = rccl_report(torch, dist, dev, world, rank) if use_dist else None
 
     from qgs_amd import _lib
 
@@ -1200,6 +1267,8 @@ def main():
                          'note': 'the state stays in VGPRs for all steps of a launch, so HBM moves the initial and final states '
                                  'only; the kernel is bound by fp64 VALU issue'},
         }
+        if rccl is not None:
+            result['rccl'] = rccl
         if ref_elapsed:
             # the denominator of this line's scaling efficiency: what one GPU does with the same members-per-GPU when nothing is gathered
             per_gpu = float(n_traj) * rk_steps * ref_passes / ref_elapsed

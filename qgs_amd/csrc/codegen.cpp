@@ -452,7 +452,8 @@ std::string options_signature(const CodegenOptions &o)
       << ",lm" << o.lds_tgl_members << ",lc" << o.lds_cap << ",lg" << o.lds_group << ",ld" << o.lds_coeff_dedupe << ",ly" << o.lds_yload_ahead
       << ",lo" << o.lds_order << ",la" << o.lds_asm << ":" << o.lds_asm_waves << ":" << o.lds_asm_cap << ":" << o.lds_asm_pingpong << ":"
       << o.lds_asm_lanes << ":" << o.lds_asm_chunk << ":" << o.lds_asm_vfree << ":" << o.lds_asm_sfree << ":" << o.lds_asm_mincap << ":" << o.lds_asm_coef
-      << ":" << o.lds_asm_ring;
+      << ":" << o.lds_asm_ring << ":" << o.lds_asm_progressive << ":" << o.lds_asm_merge
+      << ":" << o.lds_asm_keep;
     return s.str();
 }
 

@@ -58,6 +58,10 @@ struct CodegenOptions {
     bool lds_asm_pingpong = false;  // the LDS reads of phase p + 1 land in the idle half of the cache while phase p computes
     int lds_asm_lanes = 2;     //     statements whose instructions are emitted round-robin (independent dependency chains)
     int lds_asm_coef = 1;      //     coefficients: 0 = scalar loads into two SGPR buffers; 1 = vector loads into a ring of registers + DPP broadcast
+    bool lds_asm_progressive = true;  // (1, one cache set) statements ordered by the last factor they need, each instruction waits only
+                               //     for the LDS reads it needs (in-order returns, nothing else on the counter)
+    bool lds_asm_merge = true; //     consecutive phases whose modes fit the cache together are one phase (the greedy cover's tail of 2 - 4-mode phases)
+    bool lds_asm_keep = true;  //     (one cache set) a mode the previous phase left in a slot stays there and is not read again
     int lds_asm_ring = 3;      //     (1) chunks of 16 coefficients held in registers
     int lds_asm_chunk = 16;    //     coefficients per scalar-load chunk (two SGPR buffers of this size)
     int lds_asm_vfree = 24;    //     low VGPRs left to the compiler's frame code

@@ -53,6 +53,9 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "ldscap=", 7)) opt.lds_cap = std::atoi(argv[a] + 7);
         if (!std::strncmp(argv[a], "asm=", 4)) opt.lds_asm = std::atoi(argv[a] + 4) != 0;
         if (!std::strncmp(argv[a], "asmcoef=", 8)) opt.lds_asm_coef = std::atoi(argv[a] + 8);
+        if (!std::strncmp(argv[a], "asmmerge=", 9)) opt.lds_asm_merge = std::atoi(argv[a] + 9) != 0;
+        if (!std::strncmp(argv[a], "asmkeep=", 8)) opt.lds_asm_keep = std::atoi(argv[a] + 8) != 0;
+        if (!std::strncmp(argv[a], "asmprog=", 8)) opt.lds_asm_progressive = std::atoi(argv[a] + 8) != 0;
         if (!std::strncmp(argv[a], "asmring=", 8)) opt.lds_asm_ring = std::atoi(argv[a] + 8);
         if (!std::strncmp(argv[a], "asmmincap=", 10)) opt.lds_asm_mincap = std::atoi(argv[a] + 10);
         if (!std::strncmp(argv[a], "asmwaves=", 9)) opt.lds_asm_waves = std::atoi(argv[a] + 9);

@@ -236,7 +236,21 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         // ---- the stage body --------------------------------------------------------------------------------------------------
         std::vector<PTerm> terms;
         for (int i : own) terms.insert(terms.end(), rt[i].begin(), rt[i].end());
-        const std::vector<Phase> phases = build_phases(ndim, terms, pl.cap);
+        std::vector<Phase> phases;
+        for (Phase &ph : build_phases(ndim, terms, pl.cap)) {
+            // the greedy cover ends in a tail of phases of 2 - 4 modes (isolated factor pairs): consecutive phases whose modes fit the
+            // cache together are one phase (one round of LDS reads and one wait instead of ten)
+            if (!phases.empty() && opt.lds_asm_merge) {
+                std::vector<int> u;
+                std::set_union(phases.back().modes.begin(), phases.back().modes.end(), ph.modes.begin(), ph.modes.end(), std::back_inserter(u));
+                if ((int)u.size() <= pl.cap) {
+                    phases.back().modes.swap(u);
+                    phases.back().terms.insert(phases.back().terms.end(), ph.terms.begin(), ph.terms.end());
+                    continue;
+                }
+            }
+            phases.push_back(std::move(ph));
+        }
         const int P = (int)phases.size();
         stats.phases += P;
 
@@ -349,20 +363,29 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             }
         };
         auto cache_base = [&](int p) { return C0 + 2 * ((pp && (p & 1)) ? half : 0); };
-        auto lds_reads = [&](int p) {                         // the modes of phase p into its cache half
-            const Phase &ph = phases[p];
-            const int base = cache_base(p);
-            size_t i = 0;
-            for (; i + 1 < ph.modes.size(); i += 2)           // two rows per instruction: offsets in units of 64 doubles
-                body.push_back("ds_read2st64_b64 v[" + std::to_string(base + 2 * (int)i) + ":" + std::to_string(base + 2 * (int)i + 3) +
-                               "], %[lds] offset0:" + std::to_string(ph.modes[i] - 1) + " offset1:" + std::to_string(ph.modes[i + 1] - 1));
-            if (i < ph.modes.size()) {
-                const int64_t off = (int64_t)(ph.modes[i] - 1) * 512;
-                body.push_back("ds_read_b64 " + vreg(base + 2 * (int)i) + ", " + (off >= 65536 ? "v" + std::to_string(LB1) : std::string("%[lds]")) +
-                               " offset:" + std::to_string(off & 65535));
+        int n_read_instr = 0;                                 // LDS read instructions of the phase whose factors are being loaded
+        struct ReadIns { int slot, m0, m1; };                 // modes m0 (, m1) into cache slot(s) `slot` (, slot + 1); m1 == 0: one mode
+        auto emit_reads = [&](int base, const std::vector<ReadIns> &reads) {
+            for (const ReadIns &r : reads) {
+                if (r.m1)                                     // two rows per instruction: offsets in units of 64 doubles
+                    body.push_back("ds_read2st64_b64 v[" + std::to_string(base + 2 * r.slot) + ":" + std::to_string(base + 2 * r.slot + 3) +
+                                   "], %[lds] offset0:" + std::to_string(r.m0 - 1) + " offset1:" + std::to_string(r.m1 - 1));
+                else {
+                    const int64_t off = (int64_t)(r.m0 - 1) * 512;
+                    body.push_back("ds_read_b64 " + vreg(base + 2 * r.slot) + ", " + (off >= 65536 ? "v" + std::to_string(LB1) : std::string("%[lds]")) +
+                                   " offset:" + std::to_string(off & 65535));
+                }
+                stats.loads += r.m1 ? 2 : 1;
             }
-            stats.loads += (int64_t)ph.modes.size();
-            lds_pending = true;
+            n_read_instr = (int)reads.size();
+            lds_pending = !reads.empty();
+        };
+        auto lds_reads = [&](int p, const std::vector<int> &modes) {          // `modes` of phase p into its cache half, slot i = modes[i]
+            std::vector<ReadIns> reads;
+            size_t i = 0;
+            for (; i + 1 < modes.size(); i += 2) reads.push_back({(int)i, modes[i], modes[i + 1]});
+            if (i < modes.size()) reads.push_back({(int)i, modes[i], 0});
+            emit_reads(cache_base(p), reads);
         };
         auto lds_wait = [&]() { body.push_back("s_waitcnt lgkmcnt(0)"); lds_pending = false; };
         // global address of own row i: YB pair = yw + 4096 * (i / 8), immediate offset 512 * (i % 8)
@@ -392,19 +415,10 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             body.push_back("s_mov_b64 " + sreg(KB) + ", " + sreg(KT));
             for (int c = 0; c < NR; ++c) issue_ring(c);        // every slot: chunk c + NR follows into the slot chunk c leaves
             for (int i = 0; i < R; ++i) { body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0"); touched[i] = 1; }
-            if (P > 0) lds_reads(0);
-            vm_wait(ring_op[0], false);
-            lds_wait();
         } else {
             issue_chunk(0);
-            if (P > 0) lds_reads(0);
-            lds_wait();
-            issue_chunk(1);
         }
-        for (int i = 0; i < R; ++i) {
-            const Row &r = rows[own[i]];
-            if (r.has_c0 && r.c0 != 0.0) { AIns in; in.kind = AIns::MovK; in.row = i; in.coef = r.c0; place(in); }
-        }
+        bool start_pending = true;                            // the first coefficients have been requested, not waited for
         // where the step-start state lands.  Early: cache slots the last phases do not use (two halves: the idle half during the last
         // phase), requested when phase `y_phase` starts; late (what does not fit there): the cache after the last phase, in batches.
         std::vector<int> yreg(R, -1), yop(R, -1);
@@ -415,23 +429,17 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             for (int i = 0; i < half; ++i) { early_regs.push_back(idle + 2 * i); late_regs.push_back(act + 2 * i); }
             y_phase = P - 1;
         } else if (P > 0) {
-            // the longest tail of phases (at most 3) that leaves room for every row, else the last phase alone
-            int used = 0;
-            y_phase = P - 1;
-            for (int p = P - 1; p >= std::max(0, P - 3); --p) {
-                const int u = std::max(used, (int)phases[p].modes.size());
-                if (p < P - 1 && NS - u < R) break;
-                used = u;
-                y_phase = p;
-            }
-            for (int i = used; i < NS; ++i) early_regs.push_back(C0 + 2 * i);
-            for (int i = 0; i < used; ++i) late_regs.push_back(C0 + 2 * i);
+            y_phase = P - 1;                                  // (registers: the slots the last phase leaves free, known once it is planned)
         } else {
             for (int i = 0; i < NS; ++i) late_regs.push_back(C0 + 2 * i);
         }
-        for (int l = 0; l < NL; ++l) late_regs.push_back(T0 + 2 * l);
-        const int y_early = std::min(R, (int)early_regs.size());
-        for (int i = 0; i < y_early; ++i) yreg[i] = early_regs[i];
+        int y_early = 0;
+        auto settle_y_regs = [&]() {
+            for (int l = 0; l < NL; ++l) late_regs.push_back(T0 + 2 * l);
+            y_early = std::min(R, (int)early_regs.size());
+            for (int i = 0; i < y_early; ++i) yreg[i] = early_regs[i];
+        };
+        if (pp || P == 0) settle_y_regs();
         auto y_loads = [&](int from, int to, bool maybe) {
             for (int i = from; i < to; ++i) {
                 const std::string at = ybase(i);
@@ -440,23 +448,8 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             }
         };
 
-        for (int p = 0; p < P; ++p) {
-            const Phase &ph = phases[p];
-            if (pp) {
-                if (lds_pending) { lds_wait(); ++n_extra_waits; }
-                if (p + 1 < P) lds_reads(p + 1);
-            } else if (p > 0) { lds_reads(p); lds_wait(); ++n_extra_waits; }
-            if (p == y_phase && y_early > 0) {
-                body.push_back("s_cmp_lg_u32 s" + std::to_string(LAST) + ", 0");
-                body.push_back("s_cbranch_scc1 .Lqgs_ny%=");
-                yb_block = -1;
-                y_loads(0, y_early, true);
-                body.push_back(".Lqgs_ny%=:");
-            }
-            const int base = cache_base(p);
-            std::map<int, int> xreg;
-            for (size_t i = 0; i < ph.modes.size(); ++i) xreg[ph.modes[i]] = base + 2 * (int)i;
-            // statements of the phase: grouped (equal |c| within a row), then singles sharing their product
+        // statements of a phase, factors named by mode (registers are assigned once the load order is known)
+        auto statements_of = [&](const Phase &ph) {
             std::map<std::pair<int, double>, std::vector<PTerm>> pieces;
             std::vector<PTerm> singles;
             for (const PTerm &t : ph.terms) {
@@ -477,7 +470,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                 for (size_t n = 0; n < g.size(); ++n) {
                     AIns in;
                     in.kind = n == 0 ? AIns::MulT : AIns::FmaT;
-                    in.a = xreg[g[n].j]; in.b = xreg[g[n].k];
+                    in.a = g[n].j; in.b = g[n].k;
                     in.neg = std::signbit(g[n].c) != ref_neg;
                     s.ins.push_back(in);
                 }
@@ -494,18 +487,124 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                 Statement s;
                 const PTerm &t0 = singles[a];
                 if (t0.j != 0) {
-                    AIns in; in.kind = AIns::MulT; in.a = xreg[t0.j]; in.b = xreg[t0.k];
+                    AIns in; in.kind = AIns::MulT; in.a = t0.j; in.b = t0.k;
                     s.ins.push_back(in);
                 }
                 for (size_t q = a; q < b; ++q) {
                     AIns in; in.kind = AIns::AccK; in.row = ridx[singles[q].row]; in.coef = singles[q].c;
-                    in.src = t0.j == 0 ? xreg[t0.k] : -1;
+                    in.src = t0.j == 0 ? t0.k : -1;         // a mode, or the statement's temporary
                     s.ins.push_back(in);
                 }
                 sts.push_back(std::move(s));
                 a = b;
             }
+            return sts;
+        };
+        auto modes_of = [](const Statement &s) {
+            std::vector<int> m;
+            for (const AIns &in : s.ins) {
+                if (in.kind == AIns::MulT || in.kind == AIns::FmaT) { m.push_back(in.a); m.push_back(in.b); }
+                else if (in.kind == AIns::AccK && in.src > 0) m.push_back(in.src);
+            }
+            return m;
+        };
+
+        std::vector<int> resident(NS, 0);                      // single cache set: the mode every slot holds (0: none)
+        for (int p = 0; p < P; ++p) {
+            const Phase &ph = phases[p];
+            std::vector<Statement> sts = statements_of(ph);
+            const bool progressive = dpp && !pp && opt.lds_asm_progressive;
+            std::map<int, int> slot_of, read_of;                // mode -> cache slot; mode -> index of the read instruction that brings it (-1: resident)
+            std::vector<ReadIns> reads;
+            if (pp) {
+                // load order of the factors: by first use
+                std::vector<int> order;
+                for (const Statement &st : sts) for (int m : modes_of(st)) if (!slot_of.count(m)) { slot_of[m] = (int)order.size(); order.push_back(m); }
+                for (auto &kv : slot_of) read_of[kv.first] = kv.second / 2;
+                if (p == 0) lds_reads(0, order);
+                if (lds_pending) { lds_wait(); ++n_extra_waits; }
+            } else {
+                // One cache set: a mode the previous phases left in a slot stays there (and is not read again); statements whose factors
+                // are all resident come first -- they run while the new factors are on their way -- the others in the order their last
+                // factor arrives; every instruction waits only for the reads it needs (LDS returns in order; DPP mode: nothing else on
+                // the counter).
+                std::vector<char> wanted(ndim + 1, 0);
+                for (int m : ph.modes) wanted[m] = 1;
+                std::vector<int> free_slots;
+                for (int q = 0; q < NS; ++q) {
+                    if (resident[q] && wanted[resident[q]] && opt.lds_asm_keep) { slot_of[resident[q]] = q; read_of[resident[q]] = -1; }
+                    else { resident[q] = 0; free_slots.push_back(q); }
+                }
+                auto is_new = [&](const Statement &st) { for (int m : modes_of(st)) if (!slot_of.count(m)) return true; return false; };
+                if (progressive) std::stable_partition(sts.begin(), sts.end(), [&](const Statement &st) { return !is_new(st); });
+                std::vector<int> fresh;                          // new modes by first use
+                {
+                    std::map<int, int> seen;
+                    for (const Statement &st : sts) for (int m : modes_of(st)) if (!slot_of.count(m) && !seen.count(m)) { seen[m] = 1; fresh.push_back(m); }
+                }
+                if (fresh.size() > free_slots.size()) throw std::logic_error("codegen: phase does not fit the factor cache");
+                size_t f = 0, q = 0;
+                while (f < fresh.size()) {                       // adjacent free slots take two modes per instruction
+                    if (f + 1 < fresh.size() && q + 1 < free_slots.size() && free_slots[q + 1] == free_slots[q] + 1) {
+                        reads.push_back({free_slots[q], fresh[f], fresh[f + 1]});
+                        q += 2; f += 2;
+                    } else {
+                        reads.push_back({free_slots[q], fresh[f], 0});
+                        q += 1; f += 1;
+                    }
+                }
+                for (size_t r = 0; r < reads.size(); ++r) {
+                    slot_of[reads[r].m0] = reads[r].slot; read_of[reads[r].m0] = (int)r; resident[reads[r].slot] = reads[r].m0;
+                    if (reads[r].m1) { slot_of[reads[r].m1] = reads[r].slot + 1; read_of[reads[r].m1] = (int)r; resident[reads[r].slot + 1] = reads[r].m1; }
+                }
+                if (progressive) {
+                    auto last_read = [&](const Statement &st) { int v = -1; for (int m : modes_of(st)) v = std::max(v, read_of[m]); return v; };
+                    std::stable_sort(sts.begin(), sts.end(), [&](const Statement &x, const Statement &y) { return last_read(x) < last_read(y); });
+                }
+                emit_reads(C0, reads);
+                if (!progressive && !reads.empty()) { lds_wait(); ++n_extra_waits; }
+                if (p == P - 1) {                               // the step-start state: into the slots this last phase does not use
+                    for (int q2 = 0; q2 < NS; ++q2) (resident[q2] && wanted[resident[q2]] ? late_regs : early_regs).push_back(C0 + 2 * q2);
+                    settle_y_regs();
+                }
+            }
+            if (start_pending) {                              // first phase: the first coefficients
+                if (dpp) vm_wait(ring_op[0], false);
+                else { lds_wait(); issue_chunk(1); }
+                start_pending = false;
+                for (int i = 0; i < R; ++i) {
+                    const Row &r = rows[own[i]];
+                    if (r.has_c0 && r.c0 != 0.0) { AIns in; in.kind = AIns::MovK; in.row = i; in.coef = r.c0; place(in); }
+                }
+            }
+            const int base = cache_base(p);
+            std::map<int, int> xreg;
+            for (auto &kv : slot_of) xreg[kv.first] = base + 2 * kv.second;
+            if (pp && p + 1 < P) {                             // the next phase's factors into the idle half, in ITS order of first use
+                std::vector<Statement> nx = statements_of(phases[p + 1]);
+                std::vector<int> no; std::map<int, int> seen;
+                for (const Statement &s : nx) for (int m : modes_of(s)) if (!seen.count(m)) { seen[m] = 1; no.push_back(m); }
+                // (the same order `assign` finds when that phase is emitted: sts are rebuilt from the same terms)
+                lds_reads(p + 1, no);
+            }
+            if (p == y_phase && y_early > 0) {
+                body.push_back("s_cmp_lg_u32 s" + std::to_string(LAST) + ", 0");
+                body.push_back("s_cbranch_scc1 .Lqgs_ny%=");
+                yb_block = -1;
+                y_loads(0, y_early, true);
+                body.push_back(".Lqgs_ny%=:");
+            }
             // NL statements in flight, their instructions round-robin (independent fp64 dependency chains)
+            int reads_done = progressive ? 0 : n_read_instr;   // LDS read instructions known to have returned
+            const int reads_total = n_read_instr;
+            auto need = [&](int read) {                        // read instruction `read` of this phase has returned (-1: resident)
+                const int q = read + 1;                        // read instructions needed
+                if (q <= reads_done) return;
+                const int allow = std::min(15, reads_total - q);          // 4-bit counter: at most 15 may stay outstanding
+                body.push_back("s_waitcnt lgkmcnt(" + std::to_string(allow) + ")");
+                reads_done = reads_total - allow;
+                if (reads_done >= reads_total) lds_pending = false;
+            };
             std::vector<size_t> cur(NL), pos(NL, 0);
             size_t next = 0;
             for (int l = 0; l < NL; ++l) cur[l] = next < sts.size() ? next++ : (size_t)-1;
@@ -515,12 +614,23 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                     if (cur[l] == (size_t)-1) continue;
                     AIns in = sts[cur[l]].ins[pos[l]++];
                     in.t = T0 + 2 * l;
-                    if (in.kind == AIns::AccK && in.src < 0) in.src = in.t;
+                    if (in.kind == AIns::MulT || in.kind == AIns::FmaT) {
+                        if (progressive) need(std::max(read_of[in.a], read_of[in.b]));
+                        in.a = xreg[in.a]; in.b = xreg[in.b];
+                    } else if (in.kind == AIns::AccK) {
+                        if (in.src > 0) { if (progressive) need(read_of[in.src]); in.src = xreg[in.src]; }
+                        else in.src = in.t;
+                    }
                     place(in);
                     any = true;
                     if (pos[l] == sts[cur[l]].ins.size()) { cur[l] = next < sts.size() ? next++ : (size_t)-1; pos[l] = 0; }
                 }
             }
+            if (progressive && reads_done < reads_total) { lds_wait(); }      // (a phase without statements cannot happen; keeps the counter exact)
+            lds_pending = pp && p + 1 < P;
+        }
+        if (start_pending) {                                  // no phase at all (cannot happen for a tensor with terms)
+            if (dpp) vm_wait(ring_op[0], false); else { lds_wait(); issue_chunk(1); }
         }
         for (int i = 0; i < R; ++i)
             if (!touched[i]) body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0");

@@ -5,6 +5,8 @@ conventions (integrate.py:29-179, 240-552); the stepping itself (the reference's
 `_integrate_runge_kutta_jit` / `_integrate_runge_kutta_tgls_jit`, integrate.py:182-223, 555-614) runs on
 the GPU through `qgs_rk_integrate` / `qgs_rk_tgls_integrate` for the whole ensemble at once.
 """
+import os
+
 import numpy as np
 
 from qgs_amd.functions.util import reverse
@@ -79,13 +81,21 @@ def in_multi_process_job():
         return False
 
 
+def auto_all_devices_enabled():
+    """`QGS_HIP_AUTO_ALL_DEVICES=1`: large ensembles spread over every visible GPU without being asked to (below).  Off by default:
+    the single-process device group has run on one physical GPU only so far (device 0 listed several times; no multi-GPU box was
+    ever available to the build), and a default must not be the first thing to execute on two devices."""
+    return os.environ.get('QGS_HIP_AUTO_ALL_DEVICES', '0') == '1'
+
+
 def resolve_device(device, n_traj=None):
     """The `device` argument of the integrators: a GPU index, a list of indices, 'all', or None = the device the tendencies
-    were created for -- unless the ensemble has at least AUTO_ALL_DEVICES_MIN_TRAJ members, the node has several GPUs and this
-    process has them to itself, in which case None means all of them (the reference's default is every core of the machine,
-    integrator.py:79-82).  A rank of a multi-process job never spreads by itself: there `None` keeps meaning the tendencies'
-    own device, and all GPUs must be asked for explicitly (device='all')."""
-    if device is None and n_traj is not None and n_traj >= AUTO_ALL_DEVICES_MIN_TRAJ and not in_multi_process_job():
+    were created for.  With `QGS_HIP_AUTO_ALL_DEVICES=1`, None means all GPUs of the node when the ensemble has at least
+    AUTO_ALL_DEVICES_MIN_TRAJ members, the node has several GPUs and this process has them to itself (the reference's default is
+    every core of the machine, integrator.py:79-82).  A rank of a multi-process job never spreads by itself: there `None` keeps
+    meaning the tendencies' own device, and all GPUs must be asked for explicitly (device='all')."""
+    if (device is None and n_traj is not None and n_traj >= AUTO_ALL_DEVICES_MIN_TRAJ and auto_all_devices_enabled()
+            and not in_multi_process_job()):
         from qgs_amd import _lib
         if len(_lib.visible_devices()) > 1:
             return 'all'

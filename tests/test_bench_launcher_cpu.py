@@ -126,3 +126,104 @@ def test_bench_default_workloads_follow_the_baseline_configs():
     assert [bench.default_members(n) for n in (1, 2, 4, 8)] == [65536, 65536, 65536, 131072]
     assert 8 * bench.default_members(8) == 1048576
     assert bench.visible_gpus() == 0
+
+
+def _fake_kfd(tmp_path, simd_counts):
+    for i, c in enumerate(simd_counts):
+        d = tmp_path / 'nodes' / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n' % (0 if c else 64, c))
+    return str(tmp_path / 'nodes')
+
+
+def test_gpu_count_from_a_kfd_tree_and_the_visibility_masks(tmp_path):
+    """An 8-GPU node as the launcher parent sees it (two CPU nodes + eight GPU nodes in the KFD topology), under the masks an
+    operator may have set: indices, uuids, an empty value, an invalid entry that ends the list, ROCr's mask and HIP's together."""
+    sys.path.insert(0, REPO)
+    import bench
+    nodes = _fake_kfd(tmp_path, [0, 0] + [1024] * 8)
+    assert bench.visible_gpus(nodes, env={}) == 8
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '0,1,2,3'}) == 4
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': 'GPU-1fa2,GPU-77c0'}) == 2
+    assert bench.visible_gpus(nodes, env={'HIP_VISIBLE_DEVICES': ''}) == 0
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '0,1,-1,2'}) == 2          # the runtimes stop at the first invalid entry
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '0,1,9'}) == 2            # (an index beyond the node)
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '0,0,1'}) == 1            # (a repeated entry)
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '0,1,2,3', 'HIP_VISIBLE_DEVICES': '0,1'}) == 2
+    assert bench.visible_gpus(nodes, env={'ROCR_VISIBLE_DEVICES': '4,5', 'CUDA_VISIBLE_DEVICES': '0,1,2'}) == 2
+    assert bench.visible_gpus(_fake_kfd(tmp_path / 'cpu_only', [0, 0]), env={}) == 0
+
+
+_STUB_RANK = """import os, sys, time
+rank = int(os.environ['RANK'])
+assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+mode = sys.argv[1]
+if mode == 'ok':
+    if rank == 0:
+        print('{"metric": "stub", "rank0": true}')
+    sys.exit(0)
+if mode == 'die_before_rendezvous':
+    if rank == 1:
+        sys.exit(7)                     # e.g. its GPU is missing: it never reaches init_process_group
+    time.sleep(600)                     # rank 0 waits in the rendezvous for a peer that will never come
+"""
+
+
+def _run_launcher(tmp_path, mode, grace=0.5):
+    stub = tmp_path / 'stub_rank.py'
+    stub.write_text(_STUB_RANK)
+    code = ("import sys, time\n"
+            "sys.path.insert(0, %r)\n"
+            "import bench\n"
+            "bench.visible_gpus = lambda *a, **k: 2\n"
+            "t0 = time.time()\n"
+            "rc = bench.launch_ranks(2, [%r], program=%r, grace=%r)\n"
+            "print('ELAPSED %%.1f' %% (time.time() - t0), file=sys.stderr)\n"
+            "sys.exit(rc)\n" % (REPO, mode, str(stub), grace))
+    return subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+
+
+def test_launcher_relays_rank_zero_and_exits_zero(tmp_path):
+    p = _run_launcher(tmp_path, 'ok')
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert p.stdout.decode().strip() == '{"metric": "stub", "rank0": true}'
+
+
+def test_a_rank_that_dies_before_the_rendezvous_ends_the_job(tmp_path):
+    """Rank 1 exits before `init_process_group`; rank 0 would wait for it for ever.  The parent notices, gives the peers their grace
+    period, kills exactly the processes it started and exits 1 within seconds -- naming the rank that failed."""
+    p = _run_launcher(tmp_path, 'die_before_rendezvous')
+    err = p.stderr.decode()
+    assert p.returncode == 1, err[-2000:]
+    assert '(1, 7)' in err and 'ranks failed' in err
+    elapsed = float([ln for ln in err.splitlines() if ln.startswith('ELAPSED')][0].split()[1])
+    assert elapsed < 30.0, err
+    assert p.stdout.decode().strip() == ''
+
+
+def test_traffic_lookup_never_mixes_grid_sizes(tmp_path):
+    """`roofline.traffic` is a committed PMC figure looked up by (kernel, work-items of the launch, duration): two grid sizes of one
+    kernel name are two entries; a grid the table does not hold gives None, never another grid's bytes (the headline
+    carried the 1 048 576-member launch's 604 MB)."""
+    sys.path.insert(0, REPO)
+    import bench
+    table = {'k@grid65536': {'hbm_bytes_per_launch': 11, 'mean_ms': 0.5, 'grid': 65536},
+             'k@grid65536/class1': {'hbm_bytes_per_launch': 38, 'mean_ms': 4.4, 'grid': 65536},
+             'k@grid1048576': {'hbm_bytes_per_launch': 604, 'mean_ms': 69.0, 'grid': 1048576},
+             'k': {'hbm_bytes_per_launch': 604, 'mean_ms': 69.0, 'grid': 1048576}}                     # (a bare key of an older table: ignored)
+    get = lambda grid, ms: (bench.traffic_entry('k', grid, ms, table) or {}).get('hbm_bytes_per_launch')
+    assert get(65536, 4.3) == 38 and get(65536, 0.48) == 11 and get(1048576, 68.7) == 604
+    assert get(131072, 8.6) is None and get(65536, 40.0) is None
+    assert len({get(65536, 4.3), get(1048576, 68.7)}) == 2
+    # the committed table: every entry is keyed by kernel AND grid, and no two grids of a kernel share a value
+    real = bench._traffic_table()
+    assert real and all('@grid' in k for k in real), sorted(real)
+    by_kernel = {}
+    for k, e in real.items():
+        by_kernel.setdefault(k.split('@')[0], {}).setdefault(e['grid'], set()).add(e['hbm_bytes_per_launch'])
+    for kern, grids in by_kernel.items():
+        vals = [frozenset(v) for v in grids.values()]
+        assert len(vals) == len(set(vals)), kern
+    assert bench.launch_threads('qgs_spec_rk_s4', 65536) == 65536 and bench.launch_threads('qgs_spec_rk_s4', 1048576) == 1048576
+    assert bench.launch_threads('qgs_spec_rkldsa8', 65536) == 1024 * 512 and bench.launch_threads('qgs_spec_rklds16', 65536) == 1024 * 1024
+    assert bench.launch_threads('qgs_spec_qr_36x36', 16384) == 262144 and bench.launch_threads('qgs_spec_tglp_s4', 16384, 36) == 589824

@@ -3,11 +3,18 @@ per-shard moments are pooled, how members are dealt to shards."""
 import numpy as np
 
 
-def test_default_device_is_every_gpu_for_large_ensembles(monkeypatch):
+def test_default_device_is_every_gpu_for_large_ensembles_only_on_request(monkeypatch):
+    """Spreading a large ensemble over every visible GPU without being asked to is opt-in (QGS_HIP_AUTO_ALL_DEVICES=1): the
+    single-process device group has never run on two physical devices."""
     from qgs_amd.integrators import integrate as fn
     from qgs_amd import _lib
     assert fn.resolve_device(None, 1000) is None and fn.resolve_device(0, 10 ** 7) == 0
     monkeypatch.setattr(_lib, 'visible_devices', lambda: [0, 1, 2, 3, 4, 5, 6, 7])
+    for var in ('LOCAL_RANK', 'RANK', 'WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.delenv('QGS_HIP_AUTO_ALL_DEVICES', raising=False)
+    assert fn.resolve_device(None, 10 ** 7) is None and fn.resolve_device('all', 10 ** 7) == 'all'      # the default: one device
+    monkeypatch.setenv('QGS_HIP_AUTO_ALL_DEVICES', '1')
     assert fn.resolve_device(None, 2 * 65536) == 'all' and fn.resolve_device(None, 2 * 65536 - 1) is None
     assert fn.resolve_device([0, 1], 10 ** 7) == [0, 1]
     monkeypatch.setattr(_lib, 'visible_devices', lambda: [0])
@@ -22,6 +29,7 @@ def test_a_rank_of_a_multi_process_job_never_spreads_by_itself(monkeypatch):
     monkeypatch.setattr(_lib, 'visible_devices', lambda: [0, 1, 2, 3, 4, 5, 6, 7])
     for var in ('LOCAL_RANK', 'RANK', 'WORLD_SIZE'):
         monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('QGS_HIP_AUTO_ALL_DEVICES', '1')
     assert fn.resolve_device(None, 10 ** 7) == 'all'
     for var, val in (('LOCAL_RANK', '3'), ('RANK', '0'), ('WORLD_SIZE', '8')):
         monkeypatch.setenv(var, val)

@@ -11,6 +11,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from qgs_amd import _lib  # noqa: E402
+if os.environ.get("RK_AB_LIB"):                    # another build of the library (developer knobs)
+    _lib.LIB_PATH = os.path.abspath(os.environ["RK_AB_LIB"])
 
 kind, n, steps = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 2
