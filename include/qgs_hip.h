@@ -69,7 +69,9 @@ int qgs_model_destroy(qgs_model *m);
 
 /* Model properties: which=0 ndim, 1 nnz, 2 jnnz, 3 device, 4 specialised-kernel available (0/1), 5 tensor rank,
  * 6 / 7 number of derived monomials of the tendencies / Jacobian code (rank 5), 8 number of record windows the last
- * host-layout integration of this model was cut into. */
+ * host-layout integration of this model was cut into, 9 member groups of that integration, 10 / 11 terms of the tendencies /
+ * Jacobian polynomial in the bilinear form the generated code evaluates (rank 3: the tensor entries of rows >= 1; rank 5: after
+ * the products shared between monomials have become derived monomials). */
 int64_t qgs_model_info(const qgs_model *m, int which);
 
 /* Select the kernel family: 0 = automatic (specialised when available, else generic),

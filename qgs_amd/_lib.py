@@ -415,6 +415,11 @@ class HipModel(object):
         """Derived monomials of the generated tendencies / Jacobian code (rank-5 tensors; (0, 0) for rank 3)."""
         return int(lib().qgs_model_info(self._h, 6)), int(lib().qgs_model_info(self._h, 7))
 
+    @property
+    def n_reduced_terms(self):
+        """Terms of the tendencies / Jacobian polynomial in the bilinear form the generated code evaluates (qgs_model_info 10, 11)."""
+        return int(lib().qgs_model_info(self._h, 10)), int(lib().qgs_model_info(self._h, 11))
+
     def last_kernel_info(self):
         name = ctypes.create_string_buffer(128)
         v, s, l, sc = _int(0), _int(0), _int(0), _int(0)

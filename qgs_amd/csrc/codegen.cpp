@@ -399,6 +399,11 @@ bool tableau_is_subdiagonal(int s, const double *a)
     return true;
 }
 
+bool tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt)
+{
+    return rank3 && detail::tgl_asm_applies(ndim, 4, opt);
+}
+
 bool kernel_uses_jacobian(Kernel k)
 {
     switch (k) {
@@ -417,7 +422,7 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::RkSplit: return "qgs_spec_rksplit" + std::to_string(opt.row_split) + "_s" + std::to_string(S);
     case Kernel::RkStages: return "qgs_spec_rkstages_s" + std::to_string(S);
     case Kernel::RkStagesPair: return "qgs_spec_rkstagesp_s" + std::to_string(S);
-    case Kernel::TglPair: return "qgs_spec_tglp_s" + std::to_string(S);
+    case Kernel::TglPair: return (opt.tgl_asm && S >= 2 && S <= 4 ? "qgs_spec_tglpa_s" : "qgs_spec_tglp_s") + std::to_string(S);
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::RkLds: return opt.lds_asm ? "qgs_spec_rkldsa" + std::to_string(opt.lds_asm_waves) : "qgs_spec_rklds" + std::to_string(opt.lds_waves);
     case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
@@ -453,7 +458,7 @@ std::string options_signature(const CodegenOptions &o)
       << ",lo" << o.lds_order << ",la" << o.lds_asm << ":" << o.lds_asm_waves << ":" << o.lds_asm_cap << ":" << o.lds_asm_pingpong << ":"
       << o.lds_asm_lanes << ":" << o.lds_asm_chunk << ":" << o.lds_asm_vfree << ":" << o.lds_asm_sfree << ":" << o.lds_asm_mincap << ":" << o.lds_asm_coef
       << ":" << o.lds_asm_ring << ":" << o.lds_asm_progressive << ":" << o.lds_asm_merge
-      << ":" << o.lds_asm_keep;
+      << ":" << o.lds_asm_keep << ":" << o.lds_asm_fmac << ",ta" << o.tgl_asm << ":" << o.tgl_asm_ring;
     return s.str();
 }
 
@@ -486,6 +491,11 @@ GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const
     case Kernel::RkStages: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t); break;
     case Kernel::RkStagesPair: emit_rk_kernel(o, ndim, rows, S, true, opt, der.t, false, true); break;
     case Kernel::TglPair:
+        if (opt.tgl_asm && S >= 2 && S <= 4) {
+            if (!der.j.empty() || !tgl_asm_applies(ndim, S, opt)) throw std::logic_error("codegen: the hand-scheduled tangent kernel does not exist for this model");
+            emit_tgl_asm_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt);
+            break;
+        }
         emit_tgl_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), build_wx_rows(ndim, jac_tensor, true), S, opt, der.j, 1, false, true);
         break;
     case Kernel::RkRec: emit_rk_kernel(o, ndim, rows, S, false, opt, der.t, true); break;

@@ -37,6 +37,10 @@ struct CodegenOptions {
     int tgl_interleave = 2;    // tangent kernel: rows whose statements are emitted round-robin (config 4, 100 calls: 0.949 -> 0.933 ms with park_v)
     bool tgl_park_v = true;    // tangent kernel: park the step-start vector in LDS after stage 0 (four register vectors instead of five)
     bool tgl_pair = true;      // stage record in mode pairs between qgs_spec_rkstagesp_s<S> and qgs_spec_tglp_s<S> (128-bit accesses)
+    bool tgl_asm = false;      // the pair kernel of the tangent model (qgs_spec_tglp_s<S>) with a hand-scheduled body: qgs_spec_tglpa_s<S>
+                               // (codegen_tangent_asm.cpp; rank-3 tensors, 2 - 4 stages, ndim <= 37).  Bitwise the same results; measured
+                               // 0.977 against 0.935 ms per call at config 4 (profiles/r06_tgls.md): off, selectable with QGS_HIP_TGL_ASM=1
+    int tgl_asm_ring = 6;      // ... coefficient chunks of 16 held in registers
     bool tgl_coeff_dedupe = true;  // tangent kernel: same de-duplication of coefficient fetches as lds_coeff_dedupe (config 4: 1.24 -> 1.20 ms)
     int tgl_share_x = 4;       // tangent kernel: columns (wavefronts) per workgroup that share the stage states of 64 members
                                // through LDS, next stage prefetched during the current one (1 = every wavefront loads its own)
@@ -56,10 +60,12 @@ struct CodegenOptions {
     int lds_asm_mincap = 10;   //     a wavefront takes at most as many rows as leave it a cache of this many modes
     int lds_asm_cap = 64;      //     modes cached per phase (one half of the factor cache when lds_asm_pingpong)
     bool lds_asm_pingpong = false;  // the LDS reads of phase p + 1 land in the idle half of the cache while phase p computes
-    int lds_asm_lanes = 2;     //     statements whose instructions are emitted round-robin (independent dependency chains)
+    int lds_asm_lanes = 3;     //     statements whose instructions are emitted round-robin (independent dependency chains; three keep a sum two
+                               //     instructions away from the DPP instruction that reads it)
     int lds_asm_coef = 1;      //     coefficients: 0 = scalar loads into two SGPR buffers; 1 = vector loads into a ring of registers + DPP broadcast
     bool lds_asm_progressive = true;  // (1, one cache set) statements ordered by the last factor they need, each instruction waits only
                                //     for the LDS reads it needs (in-order returns, nothing else on the counter)
+    bool lds_asm_fmac = true;  //     t = fma(a, b, t) as the two-address v_fmac_f64 (4 bytes instead of 8)
     bool lds_asm_merge = true; //     consecutive phases whose modes fit the cache together are one phase (the greedy cover's tail of 2 - 4-mode phases)
     bool lds_asm_keep = true;  //     (one cache set) a mode the previous phase left in a slot stays there and is not read again
     int lds_asm_ring = 3;      //     (1) chunks of 16 coefficients held in registers
@@ -146,6 +152,8 @@ void canonicalize(const std::vector<Term> &terms, Canonical &out, int ulp = DEFA
 enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds, TglX, RkRec, TendLds, RkDense, TglDense, RkLdsDense,
                     RkStagesPair, TglPair };
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
+// the hand-scheduled pair kernel of the tangent model exists for a model of this size (callers clear CodegenOptions::tgl_asm otherwise)
+bool tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt);
 bool kernel_uses_jacobian(Kernel k);     // its coefficients come from the Jacobian tensor (else: from the tendencies tensor)
 GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                                 const CodegenOptions &opt, const Derived &der = Derived());

@@ -5,6 +5,7 @@
 //                         names / options / dispatch (generate_kernel), canonical form of a tensor, rank-5 reduction
 //   codegen_steppers.cpp  register-resident kernels: f, Df, fused RK steppers (sub-diagonal, general tableau, row-split)
 //   codegen_tangent.cpp   register-resident tangent / adjoint kernels
+//   codegen_tangent_asm.cpp  the pair kernel of the tangent model with a hand-scheduled body (inline assembly, fixed registers)
 //   codegen_lds.cpp       LDS-resident kernels of large systems: phases, row partition, stepper, f, tangent / adjoint
 //   codegen_lds_asm.cpp   the LDS-resident stepper with a hand-scheduled stage body (inline assembly, fixed registers)
 //   codegen_qr.cpp        shape-specialised batched Householder QR
@@ -126,6 +127,10 @@ void emit_rk_split_kernel(std::ostringstream &out, int ndim, const std::vector<R
 void emit_tgl_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
                      const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt,
                      const std::vector<std::pair<int, int>> &der, int share_x = 1, bool dense = false, bool pair_x = false);
+
+void emit_tgl_asm_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &tgl,
+                         const std::vector<std::vector<WX>> &adj, int S, const CodegenOptions &opt);
+bool tgl_asm_applies(int ndim, int S, const CodegenOptions &opt);      // the hand-scheduled tangent kernel exists for this shape
 
 // ---- LDS-resident kernels (codegen_lds.cpp, codegen_lds_asm.cpp) ---------------------------------------------------------------------
 // Terms live in "node space": a node is one LDS-resident value (stepper: node m = mode m; tangent model: node j = w_j,

@@ -169,7 +169,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
     std::ostringstream o;
     std::vector<KTable> tables(W);
     LdsStats stats;
-    int64_t n_chunks = 0, n_extra_waits = 0;
+    int64_t n_chunks = 0, n_extra_waits = 0, n_hazard_nops = 0;
     std::vector<int64_t> wave_instr(W, 0);
     o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members, stage body\n"
       << "// hand-scheduled: " << VT << " registers per lane = " << VF << " for the frame + 2 x 2 per own row (acc, k) + " << 2 * NL
@@ -255,6 +255,8 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         stats.phases += P;
 
         std::vector<std::string> body;                       // assembly lines
+        std::map<int, long> last_valu_write;
+        long slot_lines = 0, slot_count = 0;
         KTable &tab = tables[w];
         int chunk = 0;                                       // coefficient chunk being consumed
         std::vector<char> touched(R, 0);
@@ -327,14 +329,36 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             at(tab.vals.size() - 1, (size_t)chunk * CE);
             return r;
         };
+        // A DPP instruction must not read a register -- accumulator and second operand included -- that a VALU instruction wrote within
+        // the last two wait states.  Two wavefronts per SIMD usually put an instruction of the partner in between, but a wavefront
+        // also runs alone (its partner at a barrier or in a wait): the spacing is kept by construction.  Every line of the body is
+        // one issue slot; the last VALU write of every register a DPP instruction may read is remembered; what the statement order
+        // (three statements round-robin) does not space is spaced by s_nop.
+        auto slot_now = [&]() {
+            for (; slot_lines < (long)body.size(); ++slot_lines) {
+                const std::string &ln = body[slot_lines];
+                if (ln[0] == '.') continue;
+                slot_count += (ln.compare(0, 6, "s_nop ") == 0) ? 1 + std::atoi(ln.c_str() + 6) : 1;
+            }
+            return slot_count;
+        };
+        auto valu_wrote = [&](int reg) { last_valu_write[reg] = slot_now(); };      // right after pushing the writing instruction
+        auto dpp_reads = [&](int reg) {                       // right before pushing the DPP instruction
+            auto it = last_valu_write.find(reg);
+            if (it == last_valu_write.end()) return;
+            const long between = slot_now() - it->second;
+            if (between < 2) { body.push_back("s_nop " + std::to_string(1 - between)); ++n_hazard_nops; }
+        };
         auto acc_k = [&](int row, double c, int src) {        // k[row] += c * src
             const Coef cf = coef_operand(c);
+            if (dpp) { dpp_reads(KR(row)); dpp_reads(src); }
             if (dpp)
                 body.push_back("v_fmac_f64_dpp " + vreg(KR(row)) + ", " + (cf.neg ? "-" : "") + vreg(cf.reg) + ", " + vreg(src) + " row_newbcast:" +
                                std::to_string(cf.lane) + " row_mask:0xf bank_mask:0xf");
             else if (!touched[row]) body.push_back("v_mul_f64 " + vreg(KR(row)) + ", " + cf.sgpr + ", " + vreg(src));
             else body.push_back("v_fma_f64 " + vreg(KR(row)) + ", " + cf.sgpr + ", " + vreg(src) + ", " + vreg(KR(row)));
             touched[row] = 1;
+            valu_wrote(KR(row));
             ++stats.instr;
             ++wave_instr[w];
         };
@@ -342,16 +366,21 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             switch (in.kind) {
             case AIns::MulT:
                 body.push_back("v_mul_f64 " + vreg(in.t) + ", " + (in.neg ? "-" : "") + vreg(in.a) + ", " + vreg(in.b));
+                valu_wrote(in.t);
                 ++stats.instr; ++wave_instr[w];
                 break;
             case AIns::FmaT:
-                body.push_back("v_fma_f64 " + vreg(in.t) + ", " + (in.neg ? "-" : "") + vreg(in.a) + ", " + vreg(in.b) + ", " + vreg(in.t));
+                // (the two-address form is a 4-byte instruction: a third less code to fetch for these statements)
+                if (!in.neg && opt.lds_asm_fmac) body.push_back("v_fmac_f64 " + vreg(in.t) + ", " + vreg(in.a) + ", " + vreg(in.b));
+                else body.push_back("v_fma_f64 " + vreg(in.t) + ", " + (in.neg ? "-" : "") + vreg(in.a) + ", " + vreg(in.b) + ", " + vreg(in.t));
+                valu_wrote(in.t);
                 ++stats.instr; ++wave_instr[w];
                 break;
             case AIns::AccK: acc_k(in.row, in.coef, in.src); break;
             case AIns::MovK:
                 if (dpp) {                                    // k = 0 (stage start) + c0 * 1.0
                     body.push_back("v_mov_b64 " + vreg(T0) + ", 1.0");
+                    valu_wrote(T0);
                     acc_k(in.row, in.coef, T0);
                 } else {
                     const Coef cf = coef_operand(in.coef, false);           // (a move takes no negation)
@@ -414,7 +443,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         if (dpp) {
             body.push_back("s_mov_b64 " + sreg(KB) + ", " + sreg(KT));
             for (int c = 0; c < NR; ++c) issue_ring(c);        // every slot: chunk c + NR follows into the slot chunk c leaves
-            for (int i = 0; i < R; ++i) { body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0"); touched[i] = 1; }
+            for (int i = 0; i < R; ++i) { body.push_back("v_mov_b64 " + vreg(KR(i)) + ", 0"); touched[i] = 1; valu_wrote(KR(i)); }
         } else {
             issue_chunk(0);
         }
@@ -705,7 +734,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
     o << "    QGS_CLOCK_MARK(2)\n}\n";
     out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient table entries in " << n_chunks + W << " chunks, "
-        << n_extra_waits << " further waits for LDS reads\n";
+        << n_extra_waits << " further waits for LDS reads, " << n_hazard_nops << " s_nop for the DPP read-after-write spacing\n";
     {
         int64_t mx = 0, sum = 0;
         for (int64_t v : wave_instr) { mx = std::max(mx, v); sum += v; }

@@ -11,7 +11,7 @@ import json
 import os
 
 import numpy as np
-from kernel_names import LDS_STEPPER, LDS_STEPPER_RANK5
+from kernel_names import LDS_STEPPER, LDS_STEPPER_RANK5, TGL_PAIR, TGL_PAIR_ASM
 import pytest
 
 from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
@@ -494,7 +494,7 @@ def test_shared_stage_state_tangent_kernel(models, n_traj, n_tg):
         try:
             m.set_kernel(2)                                   # re-reads the selection knobs
             _, fm1 = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
-            assert m.last_kernel_info()['name'] == 'qgs_spec_tglp_s%d' % len(b)      # (stage record in mode pairs)
+            assert m.last_kernel_info()['name'] == TGL_PAIR % len(b)      # (stage record in mode pairs)
         finally:
             del os.environ['QGS_HIP_TGL_VARIANT']
             m.set_kernel(2)
@@ -607,7 +607,7 @@ def test_kernel_selection_at_the_baseline_configurations(models):
     assert stepper_name(m36, 36, 65536) == 'qgs_spec_rk_s4'
     assert stepper_name(m36, 36, 16384) == 'qgs_spec_rksplit4_s4'
     assert stepper_name(m36, 36, 64) == 'gen_rk_wave_kernel'
-    assert tangent_name(m36, 36, 16384, 36) == 'qgs_spec_tglp_s4'          # fed by qgs_spec_rkstagesp_s4: stage record in mode pairs
+    assert tangent_name(m36, 36, 16384, 36) == TGL_PAIR % 4          # fed by qgs_spec_rkstagesp_s4: stage record in mode pairs
     assert tangent_name(m36, 36, 1024, 36) == 'qgs_spec_tgl_s4'            # fed by the wave-per-trajectory stepper: plain record
     assert tangent_name(m36, 36, 65536, 36) == 'qgs_spec_tglx4_s4'
     r38 = (np.array([1., 3., 3., 1.]) / 8., np.array([0., 1. / 3, 2. / 3, 1.]),
@@ -702,8 +702,42 @@ def test_paired_stage_record_equals_plain(monkeypatch, seed, ndim):
         res = []
         for d, ws, adj, inv in ((1, 1, False, 1.), (-1, 2, True, -1.)):
             res.append(m.rk_tgls_integrate(t, x, tg, d, ws, RK4['b'], RK4['c'], RK4['a'], adj, inv))
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if pair == '1' else 'qgs_spec_tgl_s4')
+            assert m.last_kernel_info()['name'] == (TGL_PAIR % 4 if pair == '1' else 'qgs_spec_tgl_s4')
         out[pair] = res
+        m.close()
+    for (tr1, fm1), (tr0, fm0) in zip(out['1'], out['0']):
+        assert np.array_equal(tr1, tr0) and np.array_equal(fm1, fm0)
+
+
+@pytest.mark.parametrize('seed,ndim,stages', [(31, 36, 4), (32, 7, 4), (33, 12, 2), (34, 5, 3)])
+def test_hand_scheduled_tangent_kernel_equals_the_compiler_scheduled_one(monkeypatch, seed, ndim, stages):
+    """`qgs_spec_tglpa_s<S>` (codegen_tangent_asm.cpp: registers allocated by the generator, the next stage state prefetched into the
+    accumulation registers, step-start vector and running sum in LDS, coefficients through a register ring + DPP broadcast, all steps
+    between two records one assembly loop) does the arithmetic of `qgs_spec_tglp_s<S>` in the same order: the results must be
+    BITWISE equal -- tangent and adjoint, forward and backward, records every step / every 2 / none, odd and even ndim, 2 - 4 stages,
+    ensembles that do not fill their last wavefront."""
+    from qgs_amd import _lib
+    coo, val, jcoo, jval = _random_system(seed, ndim, 3, 12 * ndim)
+    rng = np.random.RandomState(seed)
+    x = rng.rand(150, ndim) * 0.3
+    tg = rng.randn(150, ndim, 3)
+    t = np.concatenate((np.arange(0., 0.07, 0.01), [0.07]))
+    if stages == 4:
+        b, c, a = RK4['b'], RK4['c'], RK4['a']
+    elif stages == 2:
+        b, c = np.array([0., 1.]), np.array([0., .5]); a = np.zeros((2, 2)); a[1, 0] = .5
+    else:
+        b, c = np.array([1. / 6, 2. / 3, 1. / 6]), np.array([0., .5, 1.]); a = np.zeros((3, 3)); a[1, 0] = .5; a[2, 1] = 1.
+    out = {}
+    for asm in ('1', '0'):
+        monkeypatch.setenv('QGS_HIP_TGL_ASM', asm)
+        m = _lib.HipModel(ndim, coo, val, jcoo, jval)
+        m.set_kernel(2)
+        res = []
+        for d, ws, adj, inv in ((1, 1, False, 1.), (-1, 2, True, -1.), (1, 0, False, 1.), (1, 3, True, 1.)):
+            res.append(m.rk_tgls_integrate(t, x, tg, d, ws, b, c, a, adj, inv))
+            assert m.last_kernel_info()['name'] == (TGL_PAIR_ASM if asm == '1' else TGL_PAIR) % stages
+        out[asm] = res
         m.close()
     for (tr1, fm1), (tr0, fm0) in zip(out['1'], out['0']):
         assert np.array_equal(tr1, tr0) and np.array_equal(fm1, fm0)

@@ -606,9 +606,10 @@ def test_cabi_rejects_bad_arguments_and_stays_usable():
 
 def test_cache_miss_compiles_the_same_lds_stepper(tmp_path):
     """ndim 228 on an empty kernel cache: the LDS-resident stepper (requested with set_kernel(2)) is compiled by the
-    out-of-process helper and must come out as the pre-built one: 128 VGPRs (16 wavefronts per workgroup) and no more scratch
-    than the shipped kernel spills (420 B per lane since the statement order follows the magnitude classes, round 4; 412 B before)
-    plus a small margin -- a compiler change that spills more is caught here."""
+    out-of-process helper and must come out as the pre-built one: the hand-scheduled kernel of round 6 -- 256 registers (8 wavefronts
+    per workgroup), its stage body allocated by the generator, and nothing spilled inside it: what the compiler spills in the frame
+    code around the assembly statement is 32 - 36 B per lane (the compiler-scheduled kernel it replaces spilled 420 B); more than
+    64 B means the frame has started to spill into the hot loop."""
     import json
     import subprocess
     import sys
@@ -635,7 +636,7 @@ def test_cache_miss_compiles_the_same_lds_stepper(tmp_path):
     out = p.stdout.decode()
     info = json.loads([ln for ln in out.splitlines() if ln.startswith('INFO ')][0][5:])
     assert info['name'] == LDS_STEPPER, info
-    assert info['vgprs'] <= 128 and info['scratch_bytes'] <= 448, info
+    assert info['vgprs'] <= 256 and info['scratch_bytes'] <= 64, info
     assert 'FINITE 1' in out
 
 
