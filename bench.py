@@ -758,8 +758,9 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
                      'traffic_over_algorithmic': (traffic3 / (2.0 * 8 * nd3 * n * steps)) if traffic3 else None,
                      'hbm_algorithmic_frac': rate * 2 * 8 * nd3 / 1e9 / HBM_PEAK_GBS,
                      # executed view: the generator's count of fp64 instructions (an FMA = 2 flop) against the same peak
-                     'executed_fp64_instr_per_step': (instr * 4 / 64.0) if instr else None,
-                     'executed_fp64_frac': (rate * (instr * 4 / 64.0) * 2 / 1e12 / FP64_VALU_PEAK_TFLOPS) if instr else None,
+                     # (an instruction of a wavefront is one lane-operation per member: 4 stages x the count per workgroup-stage)
+                     'executed_fp64_instr_per_step': (instr * 4) if instr else None,
+                     'executed_fp64_frac': (rate * (instr * 4) * 2 / 1e12 / FP64_VALU_PEAK_TFLOPS) if instr else None,
                      'executed': executed_view(k3['name'], thr3, ms, steps),
                      # the instruction floor of THIS formulation: the generator's count at full issue rate, no waits
                      'floor_ms': floor_ms, 'frac_of_floor': (floor_ms / ms) if floor_ms else None,

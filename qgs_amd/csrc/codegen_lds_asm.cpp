@@ -347,7 +347,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
             auto it = last_valu_write.find(reg);
             if (it == last_valu_write.end()) return;
             const long between = slot_now() - it->second;
-            if (between < 2) { body.push_back("s_nop " + std::to_string(1 - between)); ++n_hazard_nops; }
+            if (between < 2 && opt.asm_dpp_spacing) { body.push_back("s_nop " + std::to_string(1 - between)); ++n_hazard_nops; }
         };
         auto acc_k = [&](int row, double c, int src) {        // k[row] += c * src
             const Coef cf = coef_operand(c);

@@ -229,7 +229,7 @@ void emit_tgl_asm_kernel(std::ostringstream &out, int ndim, const std::vector<st
             auto it = last_valu_write.find(reg);
             if (it == last_valu_write.end()) return;
             const long between = slot_now() - it->second;     // instructions issued since the write
-            if (between < 2) body.push_back("s_nop " + std::to_string(1 - between));
+            if (between < 2 && opt.asm_dpp_spacing) body.push_back("s_nop " + std::to_string(1 - between));
         };
         // coefficient ring: chunk k of a stage in slot k % NR (NC is a multiple of NR)
         std::vector<int> ring_op(NR, -1);
