@@ -670,10 +670,10 @@ def extra_configs(torch, dev, model, ndim, nnz, jnnz, tensors):
     flops_tgls = 4 * (2 * jnnz) + 4 * 2 * ndim ** 3 + 7 * 2 * ndim * ndim + flops36     # 4.02e5 at ndim 36
     rate = n * steps / (ms_call * 1e-3)
     # what the two kernels of a call EXECUTE: fp64 instructions of their step loops, counted in the ISA (tools/kisa.py ->
-    # profiles/r04_kernel_isa.json; the tangent kernel's loop holds the tangent and the adjoint branch: half of it runs)
+    # profiles/r06_kernel_isa.json; the tangent kernel's loop holds the tangent and the adjoint branch: half of it runs)
     executed = None
     try:
-        with open(os.path.join(HERE, 'profiles', 'r04_kernel_isa.json')) as f:
+        with open(os.path.join(HERE, 'profiles', 'r06_kernel_isa.json')) as f:
             isa = json.load(f)
         tg_i = isa['bench:' + kname['name']]['hot_loop']['fp64'] / 2.0
         st_i = isa['bench:qgs_spec_rkstagesp_s4']['hot_loop']['fp64']
@@ -984,11 +984,10 @@ print('COLD ' + json.dumps({'seconds': t1 - t0, 'second_call_seconds': t2 - t1, 
 def cold_start_228():
     """BASELINE configs[2] (MAOOAM 6x6, ndim 228) from the tensors to the first result of 65 536 members x 100 steps, each in a FRESH
     process (host tensor assembly excluded: 5 s of NumPy, not the GPU path's): on an empty kernel cache with the compiler's own
-    cache off (automatic mode: a call of this size does not pay for a compilation, the generic tiled kernel runs), the same with the
-    specialised kernel requested (qgs_model_set_kernel(m, 2): the hand-scheduled LDS stepper is generated and compiled -- the wait a
-    user chooses), the cache that run left (automatic mode now finds the code object), the cache that ships with the tree, and the
-    generic kernels on request.  `auto_small_run`: 4 096 members x 20 steps in automatic mode on an
-    empty cache -- whether a short first run waits for a compilation or takes the generic kernel."""
+    cache off (automatic mode: a call of this size pays for the one-second compilation of the hand-scheduled LDS stepper), the same
+    with the specialised kernel requested outright, the cache that run left, the cache that ships with the tree, and the generic
+    kernels on request (what a call too short to compile for gets).  `auto_small_run_empty_cache`: 4 096 members x 20 steps in
+    automatic mode on an empty cache -- a short first run takes the generic kernel instead of waiting."""
     import tempfile
     out = {}
     with tempfile.TemporaryDirectory(prefix='qgs_cold228_') as d, tempfile.TemporaryDirectory(prefix='qgs_cold228b_') as d2:
@@ -1245,6 +1244,14 @@ def main():
         tflops = alg_flops / (kern_ms * 1e-3) / 1e12
         alg_gbs = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = measured_traffic(kinfo['name'], launch_threads(kinfo['name'], n_traj), kern_ms)
+        # what the kernel executes per trajectory-step: fp64 instructions of its step loop, counted in the ISA (tools/kisa.py ->
+        # profiles/r06_kernel_isa.json, a committed constant), an FMA = 2 flop
+        fp64_instr = None
+        try:
+            with open(os.path.join(HERE, 'profiles', 'r06_kernel_isa.json')) as f:
+                fp64_instr = json.load(f)['bench:' + kinfo['name']]['hot_loop']['fp64']
+        except (OSError, KeyError, ValueError):
+            pass
         result = {
             'metric': 'ensemble trajectory-steps/sec fp64, MAOOAM-36',
             'value': value, 'unit': 'traj-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -1272,6 +1279,10 @@ def main():
                          'clock_probe_ms': clock[1] if clock else None, 'peak_clock_ghz': PEAK_CLOCK_GHZ,
                          'kernel': kinfo['name'], 'kernel_ms': kern_ms,
                          'algorithmic_flops_per_launch': alg_flops, 'flops_per_traj_step': flops_per_traj_step,
+                         # executed view: `frac` is on ALGORITHMIC flops; the kernel shares common factors and executes fewer
+                         'executed_fp64_instr_per_step': fp64_instr,
+                         'executed_fp64_frac': (fp64_instr * 2.0 * n_traj * rk_steps / (kern_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS) if fp64_instr else None,
+                         'executed': executed_view(kinfo['name'], launch_threads(kinfo['name'], n_traj), kern_ms, rk_steps),
                          'traffic': traffic,                                  # HBM bytes per launch from the PMC counters (profiles/)
                          'traffic_source': TRAFFIC_SOURCE,
                          'hbm_algorithmic_bytes_per_launch': alg_bytes,

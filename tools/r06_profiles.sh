@@ -17,7 +17,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o p -
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq1 -o p -- $B > $O/sq1.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_WAVES SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq2 -o p -- $B > $O/sq2.log 2>&1
 python3 - $O <<'PY'
-import csv, glob, collections, json, sys
+import csv, glob, collections, json, re, sys
 O = sys.argv[1]
 def rows(d):
     fs = glob.glob(O + '/' + d + '/**/*counter_collection.csv', recursive=True)
@@ -27,7 +27,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ('fetch', 'write', 'sq1', 'sq2'):
     per = collections.defaultdict(list)
     for r in rows(d):
-        k = r['Kernel_Name']
+        k = re.sub(r'^(\w+::)+', '', r['Kernel_Name'].split('(')[0])          # (generic kernels: without namespace and argument list)
         if k.startswith('qgs_') or 'batched_qr' in k:
             per[(k, int(r['Grid_Size']), r['Counter_Name'])].append((float(r['Counter_Value']), (float(r['End_Timestamp']) - float(r['Start_Timestamp'])) * 1e-6))
     for (k, g, c), v in per.items():
