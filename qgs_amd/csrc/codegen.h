@@ -187,6 +187,8 @@ struct QrPlan {
     int waves = 1;        // wavefronts per workgroup ((64 / members) * slots * waves >= n_cols)
     int chains = 1;       // partial sums per dot product (1 = one left-to-right chain)
     bool reload = false;  // read the reflector from LDS once for the dot products and again for the update (large n_rows)
+    int stagger = 0;      // row design: workgroups whose index has bit `stagger_bit` set start `stagger` x 8 128 cycles late (s_sleep), so that the
+    int stagger_bit = 8;  //     two workgroups of a CU are not in their load / store phases at the same time (0: off)
     bool one_wave_per_simd = false;   // row design beyond 256 registers per lane: one wavefront per SIMD, part of the matrices in AGPRs
     int row_groups = 0;   // > 0: grid design for tall matrices (rows > 64): a member over `waves` wavefronts = 4 * waves row groups,
                           //      `members` members per workgroup

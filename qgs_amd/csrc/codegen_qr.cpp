@@ -106,6 +106,7 @@ std::string qr_plan_signature(const QrPlan &p)
     s << "m" << p.members << "p" << p.slots << "w" << p.waves << "c" << p.chains << "r" << (p.reload ? 1 : 0);
     if (p.row_groups > 0) s << "g" << p.row_groups;
     if (p.one_wave_per_simd) s << "o1";
+    if (p.stagger > 0) s << "st" << p.stagger << "b" << p.stagger_bit;
     return s.str();
 }
 
@@ -467,6 +468,9 @@ static GeneratedKernel generate_qr_row_kernel(int n_rows, int n_cols, const QrPl
     o << "#define QGS_TID() ({ unsigned t_ = threadIdx.x; asm volatile(\"\" : \"+v\"(t_)); t_; })\n"
       << "#define QGS_CC() ((int)(QGS_TID() & 15u))\n";
     o << "    const i64 m0 = (i64)blockIdx.x * 16;\n    QGS_QR_MARK(0)\n";
+    if (plan.stagger > 0)
+        o << "    if ((blockIdx.x >> " << plan.stagger_bit << ") & 1u) {          // de-synchronise the workgroups that share a CU\n"
+          << "        for (int k = 0; k < " << plan.stagger << "; ++k) __builtin_amdgcn_s_sleep(127);\n    }\n";
     for (int s = 0; s < P; ++s) {
         o << "    f64";
         for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << q(s, i);

@@ -230,3 +230,93 @@ def test_compiled_model_kernels_have_no_inline_asm_hazard(tmp_path):
                 assert _regs(ins[n - 1][1], 's') == _regs(p[-1], 's')
             if p[0] == 'global_store_dwordx4':
                 assert ins[n - 1][0] == 's_mov_b64' and ins[n + 1][:2] == ['s_nop', '1']
+
+
+# ---- the hand-scheduled kernels (round 6): their bodies are assembly the generator writes, so the rules are checked on that text ----
+def _asm_statements(source):
+    """The instruction lists of the multi-line `asm volatile(` statements of a generated source (one list per statement)."""
+    out, cur = [], None
+    for line in source.splitlines():
+        t = line.strip()
+        if t == 'asm volatile(':
+            cur = []
+        elif cur is not None:
+            if t.startswith('"'):
+                txt = t.strip('"').replace('\\n', '')
+                if txt and not txt.startswith('.'):
+                    cur.append(txt.replace(',', ' ').split())
+            else:
+                out.append(cur)
+                cur = None
+    return out
+
+
+def _strict_dpp_and_lane_read_hazards(ins):
+    """(DPP instructions, lane reads, violations): the compiler's DPP rule -- no VGPR a VALU instruction wrote within two wait states
+    may be read by a DPP instruction, accumulator and second operand included -- and the rule found in round 6: a lane read
+    (v_readfirstlane_b32) must not follow the VALU instruction that produces its source within two wait states (a stale low word was
+    measured behind v_mul_f64)."""
+    n_dpp = n_lane = 0
+    bad = []
+    for n, p in enumerate(ins):
+        if any(x.startswith('row_newbcast') for x in p):
+            n_dpp += 1
+            regs = set()
+            for t in p[1:4]:
+                regs |= _regs(t.lstrip('-'), 'v')
+            q = _near(ins, n, -1, 2, lambda q: _valu_writes(q, regs))
+            if q:
+                bad.append(('dpp', ' '.join(q), ' '.join(p)))
+        if p[0] == 'v_readfirstlane_b32' and not p[2].startswith('%'):
+            n_lane += 1
+            src = _regs(p[2], 'v')
+            q = _near(ins, n, -1, 2, lambda q: q[0] != 'v_readfirstlane_b32' and _valu_writes(q, src))
+            if q:
+                bad.append(('lane read', ' '.join(q), ' '.join(p)))
+    return n_dpp, n_lane, bad
+
+
+def test_strict_scanner_sees_both_rules():
+    ok = [['v_mul_f64', 'v[4:5]', 'v[0:1]', 'v[2:3]'], ['s_nop', '1'], ['v_readfirstlane_b32', 's3', 'v4'],
+          ['v_fma_f64', 'v[8:9]', 'v[0:1]', 'v[2:3]', 'v[8:9]'], ['v_mov_b64', 'v[20:21]', '0'], ['v_mov_b64', 'v[22:23]', '0'],
+          ['v_fmac_f64_dpp', 'v[10:11]', 'v[12:13]', 'v[8:9]', 'row_newbcast:3', 'row_mask:0xf', 'bank_mask:0xf']]
+    assert _strict_dpp_and_lane_read_hazards(ok)[2] == []
+    stale = [['v_mul_f64', 'v[4:5]', 'v[0:1]', 'v[2:3]'], ['v_readfirstlane_b32', 's3', 'v4']]
+    assert _strict_dpp_and_lane_read_hazards(stale)[2][0][0] == 'lane read'
+    acc = [['v_fmac_f64_dpp', 'v[10:11]', 'v[12:13]', 'v[8:9]', 'row_newbcast:3'], ['v_mov_b64', 'v[20:21]', '0'],
+           ['v_fmac_f64_dpp', 'v[10:11]', 'v[14:15]', 'v[8:9]', 'row_newbcast:4']]
+    assert _strict_dpp_and_lane_read_hazards(acc)[2][0][0] == 'dpp'
+
+
+@pytest.mark.parametrize('tensor, knobs, kernel, min_dpp', [('t228', [], 'qgs_spec_rkldsa8', 15000), ('a36', ['tglasm=1'], 'qgs_spec_tglpa_s4', 1000),
+                                                            ('rp20', ['tglasm=1', 'stages=2'], 'qgs_spec_tglpa_s2', 200)])
+def test_hand_scheduled_bodies_keep_the_dpp_and_lane_read_rules(tmp_path, tensor, knobs, kernel, min_dpp):
+    """The stage body of the LDS-resident stepper (MAOOAM 6x6) and the hand-scheduled tangent kernel, as the generator writes them:
+    every DPP instruction two wait states behind the last VALU write of anything it reads, every lane read two wait states behind
+    the instruction that produced its source."""
+    import numpy as np
+    from conftest import GOLDEN_DIR
+    csrc = os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), 'csrc')
+    dump = str(tmp_path / 'codegen_dump')
+    subprocess.run(['g++', '-O1', '-std=c++17', '-o', dump, os.path.join(csrc, 'codegen_dump.cpp')] + [f for f in sorted(glob.glob(os.path.join(csrc, 'codegen*.cpp'))) if not f.endswith('codegen_dump.cpp')],
+                   check=True, timeout=600)
+    g = np.load(os.path.join(GOLDEN_DIR, tensor + '.npz'))
+    txt = tmp_path / 'tensor.txt'
+    with open(txt, 'w') as f:
+        for kind, coo, v in (('T', g['coo'], g['val']), ('J', g['jcoo'], g['jval'])):
+            for c, x in zip(coo, v):
+                f.write('%s %s %s\n' % (kind, ' '.join(str(int(q)) for q in c), float(x).hex()))
+    src = subprocess.run([dump, str(int(g['ndim'])), str(txt), 'tables'] + knobs, check=True, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                         timeout=600).stdout.decode()
+    chunks = ['#ifndef QGS_SPEC_PRELUDE' + c for c in src.split('#ifndef QGS_SPEC_PRELUDE')[1:]]
+    mine = [c for c in chunks if re.search(r'\b' + kernel + r'\(', c)]
+    assert mine, sorted(set(re.findall(r'(qgs_spec_\w+)\(', src)))
+    n_dpp = n_lane = 0
+    for ins in _asm_statements(mine[0]):
+        if len(ins) < 50:
+            continue                        # (the one-line statements of the prelude)
+        d, l, bad = _strict_dpp_and_lane_read_hazards(ins)
+        assert not bad, bad[:5]
+        n_dpp += d
+        n_lane += l
+    assert n_dpp >= min_dpp and (n_lane > 0 or 'rklds' in kernel), (n_dpp, n_lane)
