@@ -39,6 +39,7 @@ Extra objects on the JSON line (rank 0):
 import argparse
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -814,7 +815,9 @@ def f_row_configs(torch, dev, m3, g3, tableau, st):
     flops_pair_step = 12 * jnnz + 14 * nd                   # 3 flop per Jacobian-tensor term and stage + the 7 axpys, as SURVEY 8(d) counts the stepper
     pair_rate = n * nv * steps / (ms_t * 1e-3)
     alg_bytes_t = 2.0 * 8 * (nd + nd * nv) * n * steps
-    thr_t = (n + 15) // 16 * ((nv + 3) // 4) * 64 * 16     # workgroups of 16 members x 4 columns, 16 wavefronts each
+    mw = re.search(r'lds[a-z]*(\d+)$', k_t['name'])
+    waves_t = int(mw.group(1)) if mw else 16
+    thr_t = (n + 15) // 16 * ((nv + 3) // 4) * 64 * waves_t     # workgroups of 16 members x 4 columns; 16 wavefronts each, hand-scheduled: 8
     tr_t = measured_traffic(k_t['name'], thr_t, None)
     res['tgls228_full_basis'] = {
         'workload': 'MAOOAM 6x6 tangent model: 1 024 members x 228 tangent vectors (identity), 10 sub-steps of 0.01: one Benettin interval of the '

@@ -404,6 +404,12 @@ bool tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt)
     return rank3 && detail::tgl_asm_applies(ndim, 4, opt);
 }
 
+// (8 wavefronts x 256 registers: up to 32 rows per wavefront leave a factor cache of 45 values)
+bool lds_tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt)
+{
+    return rank3 && opt.lds_tgl_members == 16 && ndim <= 256 && (int64_t)opt.lds_asm_waves * 32 >= ndim;
+}
+
 bool kernel_uses_jacobian(Kernel k)
 {
     switch (k) {
@@ -425,8 +431,12 @@ std::string kernel_name(Kernel k, int S, const CodegenOptions &opt)
     case Kernel::TglPair: return (opt.tgl_asm && S >= 2 && S <= 4 ? "qgs_spec_tglpa_s" : "qgs_spec_tglp_s") + std::to_string(S);
     case Kernel::Tgl: return "qgs_spec_tgl_s" + std::to_string(S);
     case Kernel::RkLds: return opt.lds_asm ? "qgs_spec_rkldsa" + std::to_string(opt.lds_asm_waves) : "qgs_spec_rklds" + std::to_string(opt.lds_waves);
-    case Kernel::TglLds: return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
-    case Kernel::AdjLds: return "qgs_spec_adjlds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
+    case Kernel::TglLds:
+        if (opt.lds_tgl_asm) return "qgs_spec_tglldsa" + std::to_string(opt.lds_asm_waves);
+        return "qgs_spec_tgllds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
+    case Kernel::AdjLds:
+        if (opt.lds_tgl_asm) return "qgs_spec_adjldsa" + std::to_string(opt.lds_asm_waves);
+        return "qgs_spec_adjlds" + std::to_string(opt.lds_waves) + (opt.lds_tgl_members == 8 ? "m8" : "");
     case Kernel::TglX: return "qgs_spec_tglx" + std::to_string(opt.tgl_share_x) + "_s" + std::to_string(S);
     case Kernel::RkRec: return "qgs_spec_rkr_s" + std::to_string(S);
     case Kernel::TendLds: return "qgs_spec_tendlds" + std::to_string(opt.lds_waves);
@@ -458,7 +468,7 @@ std::string options_signature(const CodegenOptions &o)
       << ",lo" << o.lds_order << ",la" << o.lds_asm << ":" << o.lds_asm_waves << ":" << o.lds_asm_cap << ":" << o.lds_asm_pingpong << ":"
       << o.lds_asm_lanes << ":" << o.lds_asm_chunk << ":" << o.lds_asm_vfree << ":" << o.lds_asm_sfree << ":" << o.lds_asm_mincap << ":" << o.lds_asm_coef
       << ":" << o.lds_asm_ring << ":" << o.lds_asm_progressive << ":" << o.lds_asm_merge
-      << ":" << o.lds_asm_keep << ":" << o.lds_asm_fmac << ",ta" << o.tgl_asm << ":" << o.tgl_asm_ring << ",ds" << o.asm_dpp_spacing;
+      << ":" << o.lds_asm_keep << ":" << o.lds_asm_fmac << ":" << o.lds_asm_xprefetch << ",lt" << o.lds_tgl_asm << ",ta" << o.tgl_asm << ":" << o.tgl_asm_ring << ",ds" << o.asm_dpp_spacing;
     return s.str();
 }
 
@@ -517,8 +527,14 @@ GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const
         break;
     case Kernel::TendLds: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, true); break;
     case Kernel::RkLdsDense: emit_rk_lds_kernel(o, ndim, rows, opt, der.t, false, true); break;
-    case Kernel::TglLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, false), false, opt, der.j); break;
-    case Kernel::AdjLds: emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, true), true, opt, der.j); break;
+    case Kernel::TglLds: case Kernel::AdjLds: {
+        const bool adjoint = (k == Kernel::AdjLds);
+        if (opt.lds_tgl_asm && !lds_tgl_asm_supported(ndim, der.j.empty(), opt))
+            throw std::logic_error("codegen: the hand-scheduled LDS tangent kernels take rank-3 tensors and tiles of 16 members only");
+        if (opt.lds_tgl_asm) emit_tgl_lds_asm_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, adjoint), adjoint, opt);
+        else emit_tgl_lds_kernel(o, ndim, build_wx_rows(ndim, jac_tensor, adjoint), adjoint, opt, der.j);
+        break;
+    }
     }
     gen.source = o.str();
     return gen;

@@ -54,6 +54,8 @@ struct CodegenOptions {
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
+    bool lds_tgl_asm = false;  // the LDS-resident tangent / adjoint kernels (rank 3, tiles of 16 members) with the same hand-scheduled stage body:
+                               // qgs_spec_tglldsa<W> / qgs_spec_adjldsa<W>
     bool lds_asm = true;       // the LDS-resident stepper (rank 3) with a hand-scheduled stage body: qgs_spec_rkldsa<W> (codegen_lds_asm.cpp);
                                //     its own workgroup shape and phase size:
     int lds_asm_waves = 8;    //     wavefronts per 64 members (16: 128 registers per lane; 8: 256)
@@ -67,6 +69,8 @@ struct CodegenOptions {
                                //     for the LDS reads it needs (in-order returns, nothing else on the counter)
     bool asm_dpp_spacing = true;   // both hand-scheduled kernels: two wait states between a VALU write of ANY register and a DPP instruction that
                                //     reads it (the compiler's rule); false: only for the DPP-shuffled operand, which these kernels never write by VALU
+    bool lds_asm_xprefetch = true;  // tangent frame: the stage state of the NEXT stage is requested when a stage starts (into accumulation
+                               //     registers) and written to LDS behind the barrier at its end; else: loaded there by the frame code
     bool lds_asm_fmac = true;  //     t = fma(a, b, t) as the two-address v_fmac_f64 (4 bytes instead of 8)
     bool lds_asm_merge = true; //     consecutive phases whose modes fit the cache together are one phase (the greedy cover's tail of 2 - 4-mode phases)
     bool lds_asm_keep = true;  //     (one cache set) a mode the previous phase left in a slot stays there and is not read again
@@ -156,6 +160,7 @@ enum class Kernel { Tend, Jac, Rk, RkSplit, RkStages, Tgl, RkLds, TglLds, AdjLds
 std::string kernel_name(Kernel k, int S, const CodegenOptions &opt);
 // the hand-scheduled pair kernel of the tangent model exists for a model of this size (callers clear CodegenOptions::tgl_asm otherwise)
 bool tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt);
+bool lds_tgl_asm_supported(int ndim, bool rank3, const CodegenOptions &opt);
 bool kernel_uses_jacobian(Kernel k);     // its coefficients come from the Jacobian tensor (else: from the tendencies tensor)
 GeneratedKernel generate_kernel(int ndim, const std::vector<Term> &tensor, const std::vector<Term> &jac_tensor, Kernel k, int S,
                                 const CodegenOptions &opt, const Derived &der = Derived());

@@ -54,6 +54,8 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "tglasm=", 7)) opt.tgl_asm = std::atoi(argv[a] + 7) != 0;
         if (!std::strncmp(argv[a], "tglring=", 8)) opt.tgl_asm_ring = std::atoi(argv[a] + 8);
         if (!std::strncmp(argv[a], "asm=", 4)) opt.lds_asm = std::atoi(argv[a] + 4) != 0;
+        if (!std::strncmp(argv[a], "ldstglasm=", 10)) opt.lds_tgl_asm = std::atoi(argv[a] + 10) != 0;
+        if (!std::strncmp(argv[a], "asmxpre=", 8)) opt.lds_asm_xprefetch = std::atoi(argv[a] + 8) != 0;
         if (!std::strncmp(argv[a], "asmcoef=", 8)) opt.lds_asm_coef = std::atoi(argv[a] + 8);
         if (!std::strncmp(argv[a], "asmmerge=", 9)) opt.lds_asm_merge = std::atoi(argv[a] + 9) != 0;
         if (!std::strncmp(argv[a], "asmkeep=", 8)) opt.lds_asm_keep = std::atoi(argv[a] + 8) != 0;
@@ -73,6 +75,7 @@ int main(int argc, char **argv)
     if (rank == 5) opt.row_split = 1;
     if (!qgs::tgl_asm_supported(ndim, der.j.empty(), opt)) opt.tgl_asm = false;
     if (!der.t.empty()) opt.lds_asm = false;           // (as the library: the hand-scheduled LDS stepper takes rank-3 tensors only)
+    if (!qgs::lds_tgl_asm_supported(ndim, der.j.empty(), opt)) opt.lds_tgl_asm = false;
     std::fprintf(stderr, "ndim %d rank %d terms %zu jac terms %zu derived %zu / %zu tendency fp64 instr %lld\n", ndim, rank, T.size(),
                  J.size(), der.t.size(), der.j.size(), (long long)qgs::count_tendency_flops_instr(ndim, T, opt) + (long long)der.t.size());
     if (ndim <= 64) std::fputs(qgs::generate_source(ndim, T, J, stages, opt, der).c_str(), stdout);

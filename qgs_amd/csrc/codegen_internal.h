@@ -152,6 +152,7 @@ std::vector<std::vector<int>> lds_partition(int n_rows, int n_nodes, const RowTe
 void emit_rk_lds_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt,
                         const std::vector<std::pair<int, int>> &der, bool tend_kernel = false, bool dense = false);
 void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt);
+void emit_tgl_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &wx, bool adjoint, const CodegenOptions &opt);
 void emit_tgl_lds_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &wx, bool adjoint,
                          const CodegenOptions &opt, const std::vector<std::pair<int, int>> &der);
 

@@ -57,7 +57,7 @@ struct Statement { std::vector<AIns> ins; };
 // needs with the factor cache ITS row count leaves (cap_for), at most `max_rows` rows per block (the registers).  The sequence is
 // the one of lds_partition: rows in order, the cheap ones (MAOOAM: the ocean rows) spread evenly through it.  Optimal contiguous
 // split for the current cost estimate by dynamic programming, the estimate refined against the real counts a few times.
-std::vector<std::vector<int>> asm_partition(int n_rows, const RowTerms &rt, int W, const std::function<int(int)> &cap_for, int max_rows)
+std::vector<std::vector<int>> asm_partition(int n_rows, int n_nodes, const RowTerms &rt, int W, const std::function<int(int)> &cap_for, int max_rows)
 {
     std::vector<double> c(n_rows + 1, 0.0);
     double total = 0.0;
@@ -109,7 +109,7 @@ std::vector<std::vector<int>> asm_partition(int n_rows, const RowTerms &rt, int 
         std::vector<double> actual(W, 0.0), est(W, 0.0);
         for (int v = 0; v < W; ++v) {
             std::sort(cand[v].begin(), cand[v].end());
-            actual[v] = (double)lds_wave_instr(n_rows, rt, cand[v], cap_for((int)cand[v].size()), true);
+            actual[v] = (double)lds_wave_instr(n_nodes, rt, cand[v], cap_for((int)cand[v].size()), true);
             for (int i : cand[v]) est[v] += c[i];
             worst = std::max(worst, actual[v]);
         }
@@ -120,22 +120,28 @@ std::vector<std::vector<int>> asm_partition(int n_rows, const RowTerms &rt, int 
     return best;
 }
 
-}  // namespace
+// The two kernels that share the stage body below.  Stepper: nodes 1 .. ndim are the modes of the stage state, xs[mode][64].
+// Tangent / adjoint model (frame of emit_tgl_lds_kernel: 16 members x 4 columns per workgroup): nodes 1 .. ndim are the components
+// of the tangent stage vector, ws[mode][64] (what the wavefronts write at the end of a stage), nodes ndim + 1 .. 2 ndim the stage
+// state of the 16 members, xs[mode][16], which the whole workgroup loads between two stage bodies.
+struct AsmFrame {
+    bool tangent = false, adjoint = false;
+    int MT = 16;                                             // tangent: members per workgroup
+};
 
-void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const std::vector<double> &c0, const AsmFrame &fr, const CodegenOptions &opt)
 {
     const int W = opt.lds_asm_waves, cap = std::max(2, opt.lds_asm_cap), NL = std::max(1, opt.lds_asm_lanes);
-    const bool pp = opt.lds_asm_pingpong;
-    const bool dpp = opt.lds_asm_coef == 1;                  // coefficients through vector memory + DPP broadcast (else: SGPR chunks)
+    const bool pp = opt.lds_asm_pingpong && !fr.tangent;
+    const bool dpp = opt.lds_asm_coef == 1 || fr.tangent;    // coefficients through vector memory + DPP broadcast (else: SGPR chunks)
+    const int n_nodes = fr.tangent ? 2 * ndim : ndim;
+    const int MT = fr.MT, NC = 64 / MT;
     const int CE = dpp ? 16 : ((opt.lds_asm_chunk == 8 || opt.lds_asm_chunk == 12) ? opt.lds_asm_chunk : 16);     // coefficients per chunk
     const int NR = dpp ? std::max(2, opt.lds_asm_ring) : 0;  // coefficient chunks in registers (dpp): chunk c in ring slot c % NR
     const int VT = std::min(256, (512 / ((W + 3) / 4)) / 8 * 8);                                     // registers a lane may have
-    const std::string kname = "qgs_spec_rkldsa" + std::to_string(W);
-    RowTerms rt(ndim + 1);
-    for (int i = 1; i <= ndim; ++i) {
-        for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
-        for (const Bil &b : rows[i].bil) rt[i].push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
-    }
+    const std::string kname = (fr.tangent ? (fr.adjoint ? "qgs_spec_adjldsa" : "qgs_spec_tglldsa") : "qgs_spec_rkldsa") + std::to_string(W);
+    if (ndim > 256) throw std::logic_error("codegen: the hand-scheduled LDS kernels address at most 256 rows of 64 lanes");
+    auto is_x = [&](int n) { return fr.tangent && n > ndim; };                  // a stage-state node of the tangent frame
     // register plan of a wavefront with R rows: [0, VF) the compiler's, then acc, k, temporaries, address registers, (dpp: the
     // coefficient ring,) cache.  The cache is what the rows leave: wavefronts with few, long rows get the large cache their rows
     // profit from.
@@ -153,7 +159,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
     };
     int max_rows = 0;                                        // the most rows that still leave a phase of `lds_asm_mincap` modes
     while (plan_for(max_rows + 1).cap >= std::max(4, opt.lds_asm_mincap)) ++max_rows;
-    const std::vector<std::vector<int>> owns = asm_partition(ndim, rt, W, [&](int R) { return plan_for(R).cap; }, max_rows);
+    const std::vector<std::vector<int>> owns = asm_partition(ndim, n_nodes, rt, W, [&](int R) { return plan_for(R).cap; }, max_rows);
     std::vector<int> slot(ndim + 1, 0), slot0(W, 0);
     {
         int q = 0;
@@ -163,35 +169,75 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
     // VGPR and is moved to an SGPR of this plan by v_readfirstlane_b32: under the SGPR pressure this statement creates, the compiler
     // handed VGPRs to "s"-constrained operands in some of the wavefront branches.
     const int SF = std::max(16, opt.lds_asm_sfree) / 4 * 4;
-    const int BUF[2] = {SF, SF + 2 * CE}, YB = dpp ? SF : SF + 4 * CE, KT = YB + 2, YW = KT + 2, KB = dpp ? YW + 2 : YW, LAST = KB + 2;
-    if (LAST + 1 > 96) throw std::logic_error("codegen: the hand-scheduled LDS stepper does not fit its scalar plan");
+    const int BUF[2] = {SF, SF + 2 * CE}, YB = dpp ? SF : SF + 4 * CE, KT = YB + 2, YW = KT + 2, KB = dpp ? YW + 2 : YW, LAST = KB + 2, MORE = LAST + 1;
+    const bool xpre = fr.tangent && opt.lds_asm_xprefetch;   // the next stage state: requested at the start of the stage body, written at its end
+    const int NQ = (ndim * MT + 64 * W - 1) / (64 * W);      // ... in NQ elements per lane: element q of lane t = (mode t / MT + q 64 W / MT, member t % MT)
+    if (xpre && NL < 2) throw std::logic_error("codegen: the stage-state prefetch of the tangent frame needs two temporaries");
+    if (MORE + 1 > 96) throw std::logic_error("codegen: the hand-scheduled LDS stepper does not fit its scalar plan");
 
     std::ostringstream o;
     std::vector<KTable> tables(W);
     LdsStats stats;
     int64_t n_chunks = 0, n_extra_waits = 0, n_hazard_nops = 0;
     std::vector<int64_t> wave_instr(W, 0);
-    o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members, stage body\n"
-      << "// hand-scheduled: " << VT << " registers per lane = " << VF << " for the frame + 2 x 2 per own row (acc, k) + " << 2 * NL
-      << " temporaries + the factor cache in " << (pp ? "two halves" : "one set") << " (phases of <= " << cap << " modes); coefficients in chunks of "
-      << CE << (dpp ? " through vector memory, " + std::to_string(NR) + " chunks in registers, broadcast by DPP" : " in two SGPR buffers") << "\n";
-    o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
-      << "    const f64* __restrict__ y_in,\n"
-      << "    f64* __restrict__ y_out,        // final state, X[mode][member] (may be null)\n"
-      << "    f64* __restrict__ ywork,        // private [workgroup][mode][64]: state at the start of the current step\n"
-      << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
-      << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
-      << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S)\n{\n";
-    o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
-    o << "    const int lane = threadIdx.x & 63;\n"
-      << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
-      << "    const unsigned ldsaddr = (unsigned)(unsigned long long)(&xs[0][0]) + lane8;   // LDS byte address of xs[0][lane]\n"
-      << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
-      << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
-      << "    const bool live = m0 < n_traj;\n"
-      << "    const i64 m = live ? m0 : (n_traj - 1);\n"
-      << "    f64* const ywg = ywork + (i64)blockIdx.x * " << ndim * 64 << ";              // this workgroup's block (uniform)\n"
-      << "    QGS_CLOCK_MARK(0)\n";
+    if (!fr.tangent) {
+        o << "\n// run-time stage count RK stepper, stage state in LDS, rows split over " << W << " wavefronts per 64 members, stage body\n"
+          << "// hand-scheduled: " << VT << " registers per lane = " << VF << " for the frame + 2 x 2 per own row (acc, k) + " << 2 * NL
+          << " temporaries + the factor cache in " << (pp ? "two halves" : "one set") << " (phases of <= " << cap << " modes); coefficients in chunks of "
+          << CE << (dpp ? " through vector memory, " + std::to_string(NR) + " chunks in registers, broadcast by DPP" : " in two SGPR buffers") << "\n";
+        o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
+          << "    const f64* __restrict__ y_in,\n"
+          << "    f64* __restrict__ y_out,        // final state, X[mode][member] (may be null)\n"
+          << "    f64* __restrict__ ywork,        // private [workgroup][mode][64]: state at the start of the current step\n"
+          << "    f64* __restrict__ rec, f64* __restrict__ stages,\n"
+          << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+          << "    i64 n_traj, i64 ld, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records, int backward, int write_final, int S)\n{\n";
+        o << "    __shared__ f64 xs[" << ndim << "][QGS_WAVE];\n";
+        o << "    const int lane = threadIdx.x & 63;\n"
+          << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
+          << "    const unsigned ldsaddr = (unsigned)(unsigned long long)(&xs[0][0]) + lane8;   // LDS byte address of xs[0][lane]\n"
+          << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+          << "    const i64 m0 = (i64)blockIdx.x * QGS_WAVE + lane;\n"
+          << "    const bool live = m0 < n_traj;\n"
+          << "    const i64 m = live ? m0 : (n_traj - 1);\n"
+          << "    f64* const ywg = ywork + (i64)blockIdx.x * " << ndim * 64 << ";              // this workgroup's block (uniform)\n"
+          << "    QGS_CLOCK_MARK(0)\n";
+    } else {
+        const std::string sMT = std::to_string(MT), sMSK = std::to_string(MT - 1), sMSH = std::to_string(MT == 8 ? 3 : 4);
+        o << "\n// " << (fr.adjoint ? "adjoint" : "tangent") << " model, run-time stage count, " << MT << " members x " << NC << " columns per workgroup of " << W
+          << " wavefronts, stage state\n// and tangent stage vector in LDS, stage body hand-scheduled: " << VT << " registers per lane = " << VF
+          << " for the frame + 2 x 2 per own row (acc, k) + " << 2 * NL << " temporaries\n// + the factor cache (phases of <= " << cap
+          << " values); coefficients in chunks of 16 through vector memory, " << NR << " chunks in registers, broadcast by DPP\n";
+        o << "extern \"C\" __global__ void __launch_bounds__(" << 64 * W << ") " << kname << "(\n"
+          << "    const f64* __restrict__ w_in_p,  // F[mode][col][member] at step `step_begin`\n"
+          << "    f64* __restrict__ w_out_p,       // after step `step_end-1` (may be null)\n"
+          << "    f64* __restrict__ vwork,         // private [workgroup][mode][64]: tangent state at the start of the current step\n"
+          << "    f64* __restrict__ rec,           // F[record][mode][col][member]\n"
+          << "    const f64* __restrict__ stages,  // S[(step-step_begin)*S+stage][mode][member]\n"
+          << "    const f64* __restrict__ dtime, const f64* __restrict__ tab,\n"
+          << "    i64 n_traj, i64 ld, i64 n_tg, i64 step_begin, i64 step_end, i64 write_steps, i64 n_records,\n"
+          << "    int backward, int write_final, f64 inverse, int S)\n{\n";
+        o << "    __shared__ f64 lds_all[" << ndim * MT + ndim * 64 << "];\n"
+          << "    f64 (*xs)[" << MT << "] = (f64 (*)[" << MT << "])lds_all;                       // stage state of the " << MT << " members\n"
+          << "    f64 (*ws)[QGS_WAVE] = (f64 (*)[QGS_WAVE])(lds_all + " << ndim * MT << ");   // tangent stage vector of the 64 pairs\n";
+        o << "    const int lane = threadIdx.x & 63;\n"
+          << "    const unsigned lane8 = (unsigned)lane * 8u;\n"
+          << "    const unsigned ldsaddr = (unsigned)(unsigned long long)(&ws[0][0]) + lane8;                       // LDS byte address of ws[0][lane]\n"
+          << "    const unsigned xladdr = (unsigned)(unsigned long long)(&xs[0][0]) + (unsigned)(lane & " << sMSK << ") * 8u;   // of xs[0][member of this lane]\n"
+          << "    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+          << "    const i64 L = n_tg * ld;\n"
+          << "    const i64 mt = (i64)blockIdx.x * " << MT << ", m0 = mt + (lane & " << sMSK << "), c0 = (i64)blockIdx.y * " << NC << " + (lane >> " << sMSH << ");\n"
+          << "    const bool live = (m0 < n_traj) && (c0 < n_tg);\n"
+          << "    const i64 m = m0 < n_traj ? m0 : (n_traj - 1), col = c0 < n_tg ? c0 : (n_tg - 1);\n"
+          << "    const i64 l = col * ld + m;                                  // this pair's lane of F[mode][col][member]\n"
+          << "    f64* const ywg = vwork + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * " << ndim * 64 << ";      // this workgroup's block (uniform)\n"
+          << "    // stage-state tile of the " << MT << " members, loaded by the whole workgroup: element e -> (mode e / " << MT << ", member e % " << MT << ")\n"
+          << "    i64 xm = mt + (threadIdx.x & " << sMSK << "); if (xm >= n_traj) xm = n_traj - 1;\n"
+          << "    const unsigned trow = threadIdx.x >> " << sMSH << ", ld8 = (unsigned)(ld * 8);          // (ld < 2^29: checked by the launcher)\n"
+          << "    const unsigned xwaddr = (unsigned)(unsigned long long)(&xs[0][0]) + (threadIdx.x & " << sMSK << ") * 8u;\n"
+          << "#define QGS_LOAD_XS(sp) do { const f64* sp_ = (sp); \\\n"
+          << "        for (int e = threadIdx.x; e < " << ndim * MT << "; e += " << 64 * W << ") xs[e >> " << sMSH << "][e & " << sMSK << "] = sp_[(i64)(e >> " << sMSH << ") * ld + xm]; } while (0)\n";
+    }
     for (int w = 0; w < W; ++w) {
         const std::vector<int> &own = owns[w];
         const int R = (int)own.size();
@@ -205,9 +251,12 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         for (int i : own) o << " " << i;
         o << "\n";
         const char *I2 = "        ", *I3 = "            ", *I4 = "                ";
-        for (int d : own) o << I2 << "f64 acc" << d << " = y_in[" << (d - 1) << " * ld + m];\n";
+        // F: the array the records and final values of this kernel live in, row stride FL, this lane's element at Fl
+        const std::string FL = fr.tangent ? "L" : "ld", Fl = fr.tangent ? "l" : "m", FLr = fr.tangent ? "Lr" : "ldr";
+        for (int d : own) o << I2 << "f64 acc" << d << " = " << (fr.tangent ? "w_in_p" : "y_in") << "[" << (d - 1) << " * " << FL << " + " << Fl << "];\n";
         o << I2 << "f64* const yw = ywg + " << slot0[w] * 64 << ";      // rows of this wavefront: consecutive 512-byte lines\n";
-        for (int d : own) o << I2 << "xs[" << (d - 1) << "][lane] = acc" << d << "; yw[" << (slot[d] - slot0[w]) * 64 << " + lane] = acc" << d << ";\n";
+        for (int d : own) o << I2 << (fr.tangent ? "ws[" : "xs[") << (d - 1) << "][lane] = acc" << d << "; yw[" << (slot[d] - slot0[w]) * 64 << " + lane] = acc" << d << ";\n";
+        if (fr.tangent) o << I2 << "if (step_begin < step_end) QGS_LOAD_XS(stages);\n";
         o << I2 << "__syncthreads();\n";
         o << I2 << "const unsigned ywlo = (unsigned)(unsigned long long)yw, ywhi = (unsigned)((unsigned long long)yw >> 32);\n";
         o << I2 << "QGS_REC_INIT\n";
@@ -216,28 +265,37 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         o << I2 << "for (i64 ti = step_begin; ti < step_end; ++ti) {\n";
         o << I3 << "const f64 dt = dtime[ti + 1] - dtime[ti];\n";
         o << I3 << "if (ti == next_rec) {\n"
-          << I4 << "i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));   // keeps the row offsets out of the loop-invariant set\n"
-          << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * ldr + m;\n"
+          << I4 << "i64 " << FLr << " = " << FL << "; asm volatile(\"\" : \"+s\"(" << FLr << "));   // keeps the row offsets out of the loop-invariant set\n"
+          << I4 << "f64* p = rec + qgs_rec_index(iw, n_records, backward) * " << ndim << " * " << FLr << " + " << Fl << ";\n"
           << I4 << "++iw; next_rec += write_steps;\n"
           << I4 << "if (live) {\n";
-        for (int d : own) o << I4 << "    p[" << (d - 1) << " * ldr] = " << "acc" << d << ";\n";
+        for (int d : own) o << I4 << "    p[" << (d - 1) << " * " << FLr << "] = " << "acc" << d << ";\n";
         o << I4 << "}\n" << I3 << "}\n";
         o << "#pragma nounroll\n";
         o << I3 << "for (int st = 0; st < S; ++st) {\n";
         o << I4 << "const int last = (st == S - 1);\n";
-        o << I4 << "const f64 hb = dt * tab[st];\n";
-        o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
-        o << I4 << "if (stages && live) {\n"
-          << I4 << "    i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
-          << I4 << "    f64* sp = stages + ((ti - step_begin) * S + st) * " << ndim << " * ldr + m;\n";
-        for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
-        o << I4 << "}\n";
+        if (fr.tangent) {
+            o << I4 << "const f64 hb = dt * tab[st] * inverse;\n";                  // inverse = +-1: exact
+            o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st] * inverse;\n";
+            if (xpre)
+                o << I4 << "const i64 nxt = (ti - step_begin) * S + st + 1;\n"
+                  << I4 << "const int more = nxt < (step_end - step_begin) * S;\n"
+                  << I4 << "const unsigned long long xg = (unsigned long long)(stages + (more ? nxt : 0) * " << ndim << " * ld + xm);   // row 0 of this lane's column of the next tile\n";
+        } else {
+            o << I4 << "const f64 hb = dt * tab[st];\n";
+            o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
+            o << I4 << "if (stages && live) {\n"
+              << I4 << "    i64 ldr = ld; asm volatile(\"\" : \"+s\"(ldr));\n"
+              << I4 << "    f64* sp = stages + ((ti - step_begin) * S + st) * " << ndim << " * ldr + m;\n";
+            for (int d : own) o << I4 << "    sp[" << (d - 1) << " * ldr] = xs[" << (d - 1) << "][lane];\n";
+            o << I4 << "}\n";
+        }
 
         // ---- the stage body --------------------------------------------------------------------------------------------------
         std::vector<PTerm> terms;
         for (int i : own) terms.insert(terms.end(), rt[i].begin(), rt[i].end());
         std::vector<Phase> phases;
-        for (Phase &ph : build_phases(ndim, terms, pl.cap)) {
+        for (Phase &ph : build_phases(n_nodes, terms, pl.cap)) {
             // the greedy cover ends in a tail of phases of 2 - 4 modes (isolated factor pairs): consecutive phases whose modes fit the
             // cache together are one phase (one round of LDS reads and one wait instead of ten)
             if (!phases.empty() && opt.lds_asm_merge) {
@@ -399,6 +457,8 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                 if (r.m1)                                     // two rows per instruction: offsets in units of 64 doubles
                     body.push_back("ds_read2st64_b64 v[" + std::to_string(base + 2 * r.slot) + ":" + std::to_string(base + 2 * r.slot + 3) +
                                    "], %[lds] offset0:" + std::to_string(r.m0 - 1) + " offset1:" + std::to_string(r.m1 - 1));
+                else if (is_x(r.m0))                          // stage state of this lane's member (28.5 KB at most: one immediate)
+                    body.push_back("ds_read_b64 " + vreg(base + 2 * r.slot) + ", %[xl] offset:" + std::to_string((int64_t)(r.m0 - ndim - 1) * MT * 8));
                 else {
                     const int64_t off = (int64_t)(r.m0 - 1) * 512;
                     body.push_back("ds_read_b64 " + vreg(base + 2 * r.slot) + ", " + (off >= 65536 ? "v" + std::to_string(LB1) : std::string("%[lds]")) +
@@ -439,7 +499,25 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         body.push_back("v_readfirstlane_b32 s" + std::to_string(LAST) + ", %[last]");
         body.push_back("v_add_u32 v" + std::to_string(LB1) + ", 0x10000, %[lds]");
         if (dpp) body.push_back("v_and_b32 v" + std::to_string(L15) + ", 0x78, %[lane8]");
+        int x_last_op = -1;
+        if (xpre) body.push_back("v_readfirstlane_b32 s" + std::to_string(MORE) + ", %[more]");
         body.push_back("s_nop 4");                            // (an SGPR written by a VALU instruction is not an address at once)
+        // the rows of the tile a lane moves: min(row of element q, last row) -- the lanes past the end repeat the last row
+        auto x_row = [&](int q, int reg) {
+            body.push_back("v_add_u32 v" + std::to_string(reg) + ", " + std::to_string(q * (64 * W / MT)) + ", %[trow]");
+            body.push_back("v_min_u32 v" + std::to_string(reg) + ", " + std::to_string(ndim - 1) + ", v" + std::to_string(reg));
+        };
+        if (xpre) {                                           // first in the vector-memory queue of the stage: every later wait covers them
+            body.push_back("s_cmp_eq_u32 s" + std::to_string(MORE) + ", 0");
+            body.push_back("s_cbranch_scc1 .Lqgs_nx%=");
+            for (int q = 0; q < NQ; ++q) {
+                x_row(q, T0);
+                body.push_back("v_mad_u64_u32 " + vreg(T0 + 2) + ", vcc, v" + std::to_string(T0) + ", %[ld8], %[xg]");
+                body.push_back("global_load_dwordx2 a[" + std::to_string(2 * q) + ":" + std::to_string(2 * q + 1) + "], " + vreg(T0 + 2) + ", off");
+                x_last_op = vm_issue(false);
+            }
+            body.push_back(".Lqgs_nx%=:");
+        }
         if (dpp) {
             body.push_back("s_mov_b64 " + sreg(KB) + ", " + sreg(KT));
             for (int c = 0; c < NR; ++c) issue_ring(c);        // every slot: chunk c + NR follows into the slot chunk c leaves
@@ -557,7 +635,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                 // are all resident come first -- they run while the new factors are on their way -- the others in the order their last
                 // factor arrives; every instruction waits only for the reads it needs (LDS returns in order; DPP mode: nothing else on
                 // the counter).
-                std::vector<char> wanted(ndim + 1, 0);
+                std::vector<char> wanted(n_nodes + 1, 0);
                 for (int m : ph.modes) wanted[m] = 1;
                 std::vector<int> free_slots;
                 for (int q = 0; q < NS; ++q) {
@@ -572,9 +650,18 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                     for (const Statement &st : sts) for (int m : modes_of(st)) if (!slot_of.count(m) && !seen.count(m)) { seen[m] = 1; fresh.push_back(m); }
                 }
                 if (fresh.size() > free_slots.size()) throw std::logic_error("codegen: phase does not fit the factor cache");
+                if (fr.tangent) {                                // every product has one factor of each kind: two vector components
+                    std::vector<int> fw, fx, merged;             // (one instruction), then two state values, and so on
+                    for (int m : fresh) (is_x(m) ? fx : fw).push_back(m);
+                    for (size_t a = 0, b = 0; a < fw.size() || b < fx.size();) {
+                        for (int n = 0; n < 2 && a < fw.size(); ++n) merged.push_back(fw[a++]);
+                        for (int n = 0; n < 2 && b < fx.size(); ++n) merged.push_back(fx[b++]);
+                    }
+                    fresh.swap(merged);
+                }
                 size_t f = 0, q = 0;
                 while (f < fresh.size()) {                       // adjacent free slots take two modes per instruction
-                    if (f + 1 < fresh.size() && q + 1 < free_slots.size() && free_slots[q + 1] == free_slots[q] + 1) {
+                    if (f + 1 < fresh.size() && q + 1 < free_slots.size() && free_slots[q + 1] == free_slots[q] + 1 && !is_x(fresh[f]) && !is_x(fresh[f + 1])) {
                         reads.push_back({free_slots[q], fresh[f], fresh[f + 1]});
                         q += 2; f += 2;
                     } else {
@@ -602,8 +689,7 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
                 else { lds_wait(); issue_chunk(1); }
                 start_pending = false;
                 for (int i = 0; i < R; ++i) {
-                    const Row &r = rows[own[i]];
-                    if (r.has_c0 && r.c0 != 0.0) { AIns in; in.kind = AIns::MovK; in.row = i; in.coef = r.c0; place(in); }
+                    if (c0[own[i]] != 0.0) { AIns in; in.kind = AIns::MovK; in.row = i; in.coef = c0[own[i]]; place(in); }
                 }
             }
             const int base = cache_base(p);
@@ -706,7 +792,19 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         body.push_back(".Lqgs_join%=:");
         // nothing is left in flight (coefficient chunks requested ahead of the table's end included)
         body.push_back("s_waitcnt vmcnt(0) lgkmcnt(0)");
-        body.push_back("s_barrier");
+        if (xpre) {                                           // every wavefront is past the barrier above: nobody reads the old tile any more
+            (void)x_last_op;
+            body.push_back("s_cmp_eq_u32 s" + std::to_string(MORE) + ", 0");
+            body.push_back("s_cbranch_scc1 .Lqgs_nw%=");
+            for (int q = 0; q < NQ; ++q) {
+                x_row(q, T0);
+                body.push_back("v_lshl_add_u32 v" + std::to_string(T0 + 1) + ", v" + std::to_string(T0) + ", " + std::to_string(MT == 8 ? 6 : 7) + ", %[xw]");
+                body.push_back("ds_write_b64 v" + std::to_string(T0 + 1) + ", a[" + std::to_string(2 * q) + ":" + std::to_string(2 * q + 1) + "]");
+            }
+            body.push_back("s_waitcnt lgkmcnt(0)");
+            body.push_back(".Lqgs_nw%=:");
+        }
+        if (!fr.tangent || xpre) body.push_back("s_barrier"); // (tangent frame without the prefetch: the workgroup loads the next stage state first)
         tab.pad_to = ((size_t)chunk + (dpp ? NR + 1 : 2)) * CE;
 
         o << I4 << "// " << R << " rows, cache " << NS << " slots, phases of <= " << pl.cap << " modes: " << P << " phases, " << wave_instr[w]
@@ -716,23 +814,33 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
         o << I4 << "    :";
         for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << "\"+{" << vreg(ACC(i)) << "}\"(acc" << own[i] << ")";
         o << "\n" << I4 << "    : [lds] \"v\"(ldsaddr), [lane8] \"v\"(lane8), [hb] \"v\"(hb), [ha] \"v\"(ha), [ktlo] \"v\"(ktlo), [kthi] \"v\"(kthi), "
-          << "[ywlo] \"v\"(ywlo), [ywhi] \"v\"(ywhi), [last] \"v\"(last)\n";
+          << "[ywlo] \"v\"(ywlo), [ywhi] \"v\"(ywhi), [last] \"v\"(last)" << (fr.tangent ? ", [xl] \"v\"(xladdr)" : "")
+          << (xpre ? ", [more] \"v\"(more), [xg] \"v\"(xg), [ld8] \"v\"(ld8), [trow] \"v\"(trow), [xw] \"v\"(xwaddr)" : "") << "\n";
         o << I4 << "    :";
         bool first = true;
         for (int r = K0; r < VT; ++r) { o << (first ? " " : ", ") << "\"v" << r << "\""; first = false; }
-        for (int r = SF; r < LAST + 1; ++r) o << ", \"s" << r << "\"";
+        for (int r = SF; r < MORE + 1; ++r) o << ", \"s" << r << "\"";
+        if (xpre) { for (int r = 0; r < 2 * NQ; ++r) o << ", \"a" << r << "\""; o << ", \"vcc\""; }
         o << ", \"scc\", \"memory\");\n";
+        if (fr.tangent && !xpre)                                 // stage state of the next stage (or of the first stage of the next step)
+            o << I4 << "{\n"
+              << I4 << "    const i64 nxt = (ti - step_begin) * S + st + 1;\n"
+              << I4 << "    if (nxt < (step_end - step_begin) * S) QGS_LOAD_XS(stages + nxt * " << ndim << " * ld);\n"
+              << I4 << "}\n"
+              << I4 << "__syncthreads();\n";
         o << I3 << "}\n";
         o << I2 << "}\n";
-        o << I2 << "if (live) {\n" << I3 << "if (y_out) {\n";
-        for (int d : own) o << I4 << "y_out[" << (d - 1) << " * ld + m] = " << "acc" << d << ";\n";
+        const std::string Fout = fr.tangent ? "w_out_p" : "y_out";
+        o << I2 << "if (live) {\n" << I3 << "if (" << Fout << ") {\n";
+        for (int d : own) o << I4 << Fout << "[" << (d - 1) << " * " << FL << " + " << Fl << "] = " << "acc" << d << ";\n";
         o << I3 << "}\n" << I3 << "if (write_final) {\n"
-          << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * ld + m;\n";
-        for (int d : own) o << I4 << "p[" << (d - 1) << " * ld] = " << "acc" << d << ";\n";
+          << I4 << "f64* p = rec + qgs_rec_index(n_records - 1, n_records, backward) * " << ndim << " * " << FL << " + " << Fl << ";\n";
+        for (int d : own) o << I4 << "p[" << (d - 1) << " * " << FL << "] = " << "acc" << d << ";\n";
         o << I3 << "}\n" << I2 << "}\n    }\n";
     }
-    o << "    QGS_CLOCK_MARK(2)\n}\n";
-    out << "// per stage and 64 members: " << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
+    if (fr.tangent) o << "#undef QGS_LOAD_XS\n}\n";
+    else o << "    QGS_CLOCK_MARK(2)\n}\n";
+    out << "// per stage and 64 " << (fr.tangent ? "(member, column) pairs: " : "members: ") << stats.phases << " phases, " << stats.loads << " LDS reads, " << stats.instr
         << " fp64 instructions, " << stats.coef << " coefficient table entries in " << n_chunks + W << " chunks, "
         << n_extra_waits << " further waits for LDS reads, " << n_hazard_nops << " s_nop for the DPP read-after-write spacing\n";
     {
@@ -742,6 +850,35 @@ void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector
     }
     for (int w = 0; w < W; ++w) emit_ktable(out, kname + "_kt" + std::to_string(w), tables[w]);
     out << o.str();
+}
+
+}  // namespace
+
+void emit_rk_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<Row> &rows, const CodegenOptions &opt)
+{
+    RowTerms rt(ndim + 1);
+    std::vector<double> c0(ndim + 1, 0.0);
+    for (int i = 1; i <= ndim; ++i) {
+        for (const Lin &l : rows[i].lin) rt[i].push_back({i, 0, l.k, l.c});
+        for (const Bil &b : rows[i].bil) rt[i].push_back({i, std::min(b.j, b.k), std::max(b.j, b.k), b.c});
+        if (rows[i].has_c0) c0[i] = rows[i].c0;
+    }
+    emit_lds_asm(out, ndim, rt, c0, AsmFrame{}, opt);
+}
+
+// (J w)_i = sum_{j,k} Tj_ijk x_k w_j, or the transpose: the rows of `wx` (build_wx_rows), factors as nodes w_j < x_k
+void emit_tgl_lds_asm_kernel(std::ostringstream &out, int ndim, const std::vector<std::vector<WX>> &wx, bool adjoint, const CodegenOptions &opt)
+{
+    RowTerms rt(ndim + 1);
+    for (int i = 1; i <= ndim; ++i)
+        for (const WX &t : wx[i]) {
+            if (t.x == 0) rt[i].push_back({i, 0, t.w, t.c});                 // x_0 = 1: c * w_j
+            else rt[i].push_back({i, t.w, ndim + t.x, t.c});
+        }
+    AsmFrame fr;
+    fr.tangent = true;
+    fr.adjoint = adjoint;
+    emit_lds_asm(out, ndim, rt, std::vector<double>(ndim + 1, 0.0), fr, opt);
 }
 
 }  // namespace detail

@@ -11,7 +11,8 @@ import json
 import os
 
 import numpy as np
-from kernel_names import LDS_STEPPER, LDS_STEPPER_RANK5, TGL_PAIR, TGL_PAIR_ASM
+from kernel_names import (LDS_STEPPER, LDS_STEPPER_RANK5, TGL_PAIR, TGL_PAIR_ASM, LDS_TANGENT, LDS_ADJOINT, LDS_TANGENT_RANK5, LDS_ADJOINT_RANK5,
+                          LDS_TANGENT_ASM, LDS_ADJOINT_ASM, LDS_TANGENT_CC, LDS_ADJOINT_CC)
 import pytest
 
 from conftest import GOLDEN_DIR, REPO, RK4, load_golden, rel_err
@@ -133,7 +134,7 @@ def test_lds_resident_stepper_ndim228_vs_oracle(models, n_traj):
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:tg.shape[0]], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
         if kind == 2:
-            assert m.last_kernel_info()['name'] == 'qgs_spec_tgllds16'
+            assert m.last_kernel_info()['name'] == LDS_TANGENT
     m.set_kernel(0)
 
 
@@ -156,7 +157,7 @@ def test_lds_resident_tangent_ndim228_vs_oracle(models, n_traj, n_tg):
     for d, ws, b, c, a, adj, inv in cases:
         rtr, rfm = ora.integrate_runge_kutta_tgls_jit(t, ic, tg, d, ws, b, c, a, adj, inv)
         tr, fm = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
-        assert m.last_kernel_info()['name'] == ('qgs_spec_adjlds16' if adj else 'qgs_spec_tgllds16')
+        assert m.last_kernel_info()['name'] == (LDS_ADJOINT if adj else LDS_TANGENT)
         assert fm.shape == rfm.shape and rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (d, ws, adj, inv)
     m.set_kernel(0)
 
@@ -195,11 +196,11 @@ def test_rank5_models_vs_oracle(models, name, n_traj):
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, 1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.)
         assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else 'qgs_spec_tgllds16')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else LDS_TANGENT_RANK5)
         tr, fm = m.rk_tgls_integrate(t[:5], ic[:nt], tg, -1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.)
         assert rel_err(tr, atr) < 1e-12 and rel_err(fm, afm) < 1e-11, kind
         if kind == 'specialised':
-            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else 'qgs_spec_adjlds16')
+            assert m.last_kernel_info()['name'] == ('qgs_spec_tglp_s4' if name == 'd38' else LDS_ADJOINT_RANK5)
     m.set_kernel(0)
 
 
@@ -518,7 +519,7 @@ def test_lds_resident_kernels_on_a_second_tensor_ndim72():
     t = np.concatenate((np.arange(0., 1., 0.1), [1.]))
     ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = rng.randn(9, f.ndim, 6)
-    for kind, names in ((1, ('gen_rk_tiled_kernel', None)), (2, (LDS_STEPPER, 'qgs_spec_tgllds16'))):
+    for kind, names in ((1, ('gen_rk_tiled_kernel', None)), (2, (LDS_STEPPER, LDS_TANGENT))):
         m.set_kernel(kind)
         out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
         assert m.last_kernel_info()['name'] == names[0]
@@ -528,7 +529,7 @@ def test_lds_resident_kernels_on_a_second_tensor_ndim72():
             tr, fm = m.rk_tgls_integrate(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
             assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (kind, adj)
         if names[1]:
-            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16'
+            assert m.last_kernel_info()['name'] == LDS_ADJOINT
     f.operands.release()
 
 
@@ -557,7 +558,7 @@ def test_lds_resident_kernels_rank5_ndim106(monkeypatch, tile_members):
     ref = ora.integrate_runge_kutta_jit(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'], threads=4)
     tg = rng.randn(9, f.ndim, 6)
     sfx = 'm8' if tile_members == 8 else ''
-    for kind, names in ((1, ('gen_rk_kernel', None)), (2, (LDS_STEPPER_RANK5, 'qgs_spec_tgllds16' + sfx))):
+    for kind, names in ((1, ('gen_rk_kernel', None)), (2, (LDS_STEPPER_RANK5, LDS_TANGENT_RANK5 + sfx))):
         m.set_kernel(kind)
         assert rel_err(m.tendencies(ic), ora.f(0., ic)) < 1e-14, kind
         out = m.rk_integrate(t, ic, 1, 3, RK4['b'], RK4['c'], RK4['a'])
@@ -568,7 +569,7 @@ def test_lds_resident_kernels_rank5_ndim106(monkeypatch, tile_members):
             tr, fm = m.rk_tgls_integrate(t[:6], ic[:9], tg, 1, 1, RK4['b'], RK4['c'], RK4['a'], adj, 1.)
             assert rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (kind, adj)
         if names[1]:
-            assert m.last_kernel_info()['name'] == 'qgs_spec_adjlds16' + sfx
+            assert m.last_kernel_info()['name'] == LDS_ADJOINT_RANK5 + sfx
     f.operands.release()
 
 
@@ -741,6 +742,51 @@ def test_hand_scheduled_tangent_kernel_equals_the_compiler_scheduled_one(monkeyp
         m.close()
     for (tr1, fm1), (tr0, fm0) in zip(out['1'], out['0']):
         assert np.array_equal(tr1, tr0) and np.array_equal(fm1, fm0)
+
+
+@pytest.mark.parametrize('tensor,n_traj,n_tg', [('t228', 21, 6), ('t228', 1, 3), ('a72', 40, 9)])
+def test_hand_scheduled_lds_tangent_kernels_vs_oracle_and_their_twins(monkeypatch, tensor, n_traj, n_tg):
+    """`qgs_spec_tglldsa8` / `qgs_spec_adjldsa8` (codegen_lds_asm.cpp: the stage body of the hand-scheduled LDS stepper in the frame of
+    the LDS-resident tangent kernels) and the compiler-scheduled `qgs_spec_tgllds16` / `qgs_spec_adjlds16`, each selected by
+    QGS_HIP_LDS_TGL_ASM, against the oracle and against each other: tangent forward with records, adjoint backward with `inverse`,
+    a 2-stage scheme without records; ragged member and column tiles."""
+    from qgs_amd import _lib
+    from oracle.oracle import OracleModel
+    if tensor == 'a72':
+        import model_configs
+        from qgs_amd.functions.tendencies import create_tendencies
+        f, Df = create_tendencies(model_configs.params_a72())
+        ndim, coo, val, jcoo, jval = f.ndim, f.coo, f.val, Df.coo, Df.val
+        f.operands.release()
+    else:
+        g = load_golden(tensor)
+        ndim, coo, val, jcoo, jval = g.ndim, g['coo'], g['val'], g['jcoo'], g['jval']
+    ora = OracleModel(ndim, coo, val, jcoo, jval)
+    rng = np.random.RandomState(5 * n_traj + n_tg)
+    ic = rng.rand(n_traj, ndim) * 0.01
+    tg = rng.randn(n_traj, ndim, n_tg)
+    t = np.concatenate((np.arange(0., 0.6, 0.1), [0.6]))
+    b2, c2 = np.array([0., 1.]), np.array([0., .5])
+    a2 = np.zeros((2, 2)); a2[1, 0] = .5
+    cases = [(1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.), (-1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.),
+             (1, 0, b2, c2, a2, True, 1.), (1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)]
+    refs = [ora.integrate_runge_kutta_tgls_jit(t, ic, tg, d, ws, b, c, a, adj, inv) for d, ws, b, c, a, adj, inv in cases]
+    out = {}
+    for asm in ('1', '0'):
+        monkeypatch.setenv('QGS_HIP_LDS_TGL_ASM', asm)
+        m = _lib.HipModel(ndim, coo, val, jcoo, jval)
+        m.set_kernel(2)
+        res = []
+        for (d, ws, b, c, a, adj, inv), (rtr, rfm) in zip(cases, refs):
+            tr, fm = m.rk_tgls_integrate(t, ic, tg, d, ws, b, c, a, adj, inv)
+            names = (LDS_TANGENT_ASM, LDS_ADJOINT_ASM) if asm == '1' else (LDS_TANGENT_CC, LDS_ADJOINT_CC)
+            assert m.last_kernel_info()['name'] == names[1 if adj else 0]
+            assert fm.shape == rfm.shape and rel_err(tr, rtr) < 1e-12 and rel_err(fm, rfm) < 1e-11, (asm, d, ws, adj, inv)
+            res.append(fm)
+        out[asm] = res
+        m.close()
+    for fm1, fm0 in zip(out['1'], out['0']):
+        assert rel_err(fm1, fm0) < 1e-12
 
 
 def test_cache_miss_compiles_the_same_stepper(tmp_path):
