@@ -54,7 +54,7 @@ struct CodegenOptions {
                                //     25 % fewer coefficient fetches (needs the smaller factor cache above to stay spill-free)
     bool lds_coeff_dedupe = true; // ... a coefficient already present in the group of 16 being consumed is not fetched again
     int lds_yload_ahead = 2;   // ... and phases before the end of a stage at which the step-start state is re-read
-    bool lds_tgl_asm = false;  // the LDS-resident tangent / adjoint kernels (rank 3, tiles of 16 members) with the same hand-scheduled stage body:
+    bool lds_tgl_asm = true;   // the LDS-resident tangent / adjoint kernels (rank 3, tiles of 16 members) with the same hand-scheduled stage body:
                                // qgs_spec_tglldsa<W> / qgs_spec_adjldsa<W>
     bool lds_asm = true;       // the LDS-resident stepper (rank 3) with a hand-scheduled stage body: qgs_spec_rkldsa<W> (codegen_lds_asm.cpp);
                                //     its own workgroup shape and phase size:
@@ -69,8 +69,6 @@ struct CodegenOptions {
                                //     for the LDS reads it needs (in-order returns, nothing else on the counter)
     bool asm_dpp_spacing = true;   // both hand-scheduled kernels: two wait states between a VALU write of ANY register and a DPP instruction that
                                //     reads it (the compiler's rule); false: only for the DPP-shuffled operand, which these kernels never write by VALU
-    bool lds_asm_xprefetch = true;  // tangent frame: the stage state of the NEXT stage is requested when a stage starts (into accumulation
-                               //     registers) and written to LDS behind the barrier at its end; else: loaded there by the frame code
     bool lds_asm_fmac = true;  //     t = fma(a, b, t) as the two-address v_fmac_f64 (4 bytes instead of 8)
     bool lds_asm_merge = true; //     consecutive phases whose modes fit the cache together are one phase (the greedy cover's tail of 2 - 4-mode phases)
     bool lds_asm_keep = true;  //     (one cache set) a mode the previous phase left in a slot stays there and is not read again

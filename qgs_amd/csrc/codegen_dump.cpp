@@ -55,7 +55,6 @@ int main(int argc, char **argv)
         if (!std::strncmp(argv[a], "tglring=", 8)) opt.tgl_asm_ring = std::atoi(argv[a] + 8);
         if (!std::strncmp(argv[a], "asm=", 4)) opt.lds_asm = std::atoi(argv[a] + 4) != 0;
         if (!std::strncmp(argv[a], "ldstglasm=", 10)) opt.lds_tgl_asm = std::atoi(argv[a] + 10) != 0;
-        if (!std::strncmp(argv[a], "asmxpre=", 8)) opt.lds_asm_xprefetch = std::atoi(argv[a] + 8) != 0;
         if (!std::strncmp(argv[a], "asmcoef=", 8)) opt.lds_asm_coef = std::atoi(argv[a] + 8);
         if (!std::strncmp(argv[a], "asmmerge=", 9)) opt.lds_asm_merge = std::atoi(argv[a] + 9) != 0;
         if (!std::strncmp(argv[a], "asmkeep=", 8)) opt.lds_asm_keep = std::atoi(argv[a] + 8) != 0;

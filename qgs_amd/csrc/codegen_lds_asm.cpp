@@ -169,11 +169,8 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
     // VGPR and is moved to an SGPR of this plan by v_readfirstlane_b32: under the SGPR pressure this statement creates, the compiler
     // handed VGPRs to "s"-constrained operands in some of the wavefront branches.
     const int SF = std::max(16, opt.lds_asm_sfree) / 4 * 4;
-    const int BUF[2] = {SF, SF + 2 * CE}, YB = dpp ? SF : SF + 4 * CE, KT = YB + 2, YW = KT + 2, KB = dpp ? YW + 2 : YW, LAST = KB + 2, MORE = LAST + 1;
-    const bool xpre = fr.tangent && opt.lds_asm_xprefetch;   // the next stage state: requested at the start of the stage body, written at its end
-    const int NQ = (ndim * MT + 64 * W - 1) / (64 * W);      // ... in NQ elements per lane: element q of lane t = (mode t / MT + q 64 W / MT, member t % MT)
-    if (xpre && NL < 2) throw std::logic_error("codegen: the stage-state prefetch of the tangent frame needs two temporaries");
-    if (MORE + 1 > 96) throw std::logic_error("codegen: the hand-scheduled LDS stepper does not fit its scalar plan");
+    const int BUF[2] = {SF, SF + 2 * CE}, YB = dpp ? SF : SF + 4 * CE, KT = YB + 2, YW = KT + 2, KB = dpp ? YW + 2 : YW, LAST = KB + 2;
+    if (LAST + 1 > 96) throw std::logic_error("codegen: the hand-scheduled LDS stepper does not fit its scalar plan");
 
     std::ostringstream o;
     std::vector<KTable> tables(W);
@@ -233,8 +230,6 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
           << "    f64* const ywg = vwork + ((i64)blockIdx.y * gridDim.x + blockIdx.x) * " << ndim * 64 << ";      // this workgroup's block (uniform)\n"
           << "    // stage-state tile of the " << MT << " members, loaded by the whole workgroup: element e -> (mode e / " << MT << ", member e % " << MT << ")\n"
           << "    i64 xm = mt + (threadIdx.x & " << sMSK << "); if (xm >= n_traj) xm = n_traj - 1;\n"
-          << "    const unsigned trow = threadIdx.x >> " << sMSH << ", ld8 = (unsigned)(ld * 8);          // (ld < 2^29: checked by the launcher)\n"
-          << "    const unsigned xwaddr = (unsigned)(unsigned long long)(&xs[0][0]) + (threadIdx.x & " << sMSK << ") * 8u;\n"
           << "#define QGS_LOAD_XS(sp) do { const f64* sp_ = (sp); \\\n"
           << "        for (int e = threadIdx.x; e < " << ndim * MT << "; e += " << 64 * W << ") xs[e >> " << sMSH << "][e & " << sMSK << "] = sp_[(i64)(e >> " << sMSH << ") * ld + xm]; } while (0)\n";
     }
@@ -277,10 +272,6 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         if (fr.tangent) {
             o << I4 << "const f64 hb = dt * tab[st] * inverse;\n";                  // inverse = +-1: exact
             o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st] * inverse;\n";
-            if (xpre)
-                o << I4 << "const i64 nxt = (ti - step_begin) * S + st + 1;\n"
-                  << I4 << "const int more = nxt < (step_end - step_begin) * S;\n"
-                  << I4 << "const unsigned long long xg = (unsigned long long)(stages + (more ? nxt : 0) * " << ndim << " * ld + xm);   // row 0 of this lane's column of the next tile\n";
         } else {
             o << I4 << "const f64 hb = dt * tab[st];\n";
             o << I4 << "const f64 ha = last ? 0.0 : dt * tab[S + st];\n";
@@ -499,25 +490,7 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         body.push_back("v_readfirstlane_b32 s" + std::to_string(LAST) + ", %[last]");
         body.push_back("v_add_u32 v" + std::to_string(LB1) + ", 0x10000, %[lds]");
         if (dpp) body.push_back("v_and_b32 v" + std::to_string(L15) + ", 0x78, %[lane8]");
-        int x_last_op = -1;
-        if (xpre) body.push_back("v_readfirstlane_b32 s" + std::to_string(MORE) + ", %[more]");
         body.push_back("s_nop 4");                            // (an SGPR written by a VALU instruction is not an address at once)
-        // the rows of the tile a lane moves: min(row of element q, last row) -- the lanes past the end repeat the last row
-        auto x_row = [&](int q, int reg) {
-            body.push_back("v_add_u32 v" + std::to_string(reg) + ", " + std::to_string(q * (64 * W / MT)) + ", %[trow]");
-            body.push_back("v_min_u32 v" + std::to_string(reg) + ", " + std::to_string(ndim - 1) + ", v" + std::to_string(reg));
-        };
-        if (xpre) {                                           // first in the vector-memory queue of the stage: every later wait covers them
-            body.push_back("s_cmp_eq_u32 s" + std::to_string(MORE) + ", 0");
-            body.push_back("s_cbranch_scc1 .Lqgs_nx%=");
-            for (int q = 0; q < NQ; ++q) {
-                x_row(q, T0);
-                body.push_back("v_mad_u64_u32 " + vreg(T0 + 2) + ", vcc, v" + std::to_string(T0) + ", %[ld8], %[xg]");
-                body.push_back("global_load_dwordx2 a[" + std::to_string(2 * q) + ":" + std::to_string(2 * q + 1) + "], " + vreg(T0 + 2) + ", off");
-                x_last_op = vm_issue(false);
-            }
-            body.push_back(".Lqgs_nx%=:");
-        }
         if (dpp) {
             body.push_back("s_mov_b64 " + sreg(KB) + ", " + sreg(KT));
             for (int c = 0; c < NR; ++c) issue_ring(c);        // every slot: chunk c + NR follows into the slot chunk c leaves
@@ -792,19 +765,7 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         body.push_back(".Lqgs_join%=:");
         // nothing is left in flight (coefficient chunks requested ahead of the table's end included)
         body.push_back("s_waitcnt vmcnt(0) lgkmcnt(0)");
-        if (xpre) {                                           // every wavefront is past the barrier above: nobody reads the old tile any more
-            (void)x_last_op;
-            body.push_back("s_cmp_eq_u32 s" + std::to_string(MORE) + ", 0");
-            body.push_back("s_cbranch_scc1 .Lqgs_nw%=");
-            for (int q = 0; q < NQ; ++q) {
-                x_row(q, T0);
-                body.push_back("v_lshl_add_u32 v" + std::to_string(T0 + 1) + ", v" + std::to_string(T0) + ", " + std::to_string(MT == 8 ? 6 : 7) + ", %[xw]");
-                body.push_back("ds_write_b64 v" + std::to_string(T0 + 1) + ", a[" + std::to_string(2 * q) + ":" + std::to_string(2 * q + 1) + "]");
-            }
-            body.push_back("s_waitcnt lgkmcnt(0)");
-            body.push_back(".Lqgs_nw%=:");
-        }
-        if (!fr.tangent || xpre) body.push_back("s_barrier"); // (tangent frame without the prefetch: the workgroup loads the next stage state first)
+        if (!fr.tangent) body.push_back("s_barrier");         // (tangent frame: the workgroup loads the next stage state first)
         tab.pad_to = ((size_t)chunk + (dpp ? NR + 1 : 2)) * CE;
 
         o << I4 << "// " << R << " rows, cache " << NS << " slots, phases of <= " << pl.cap << " modes: " << P << " phases, " << wave_instr[w]
@@ -814,15 +775,13 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         o << I4 << "    :";
         for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << "\"+{" << vreg(ACC(i)) << "}\"(acc" << own[i] << ")";
         o << "\n" << I4 << "    : [lds] \"v\"(ldsaddr), [lane8] \"v\"(lane8), [hb] \"v\"(hb), [ha] \"v\"(ha), [ktlo] \"v\"(ktlo), [kthi] \"v\"(kthi), "
-          << "[ywlo] \"v\"(ywlo), [ywhi] \"v\"(ywhi), [last] \"v\"(last)" << (fr.tangent ? ", [xl] \"v\"(xladdr)" : "")
-          << (xpre ? ", [more] \"v\"(more), [xg] \"v\"(xg), [ld8] \"v\"(ld8), [trow] \"v\"(trow), [xw] \"v\"(xwaddr)" : "") << "\n";
+          << "[ywlo] \"v\"(ywlo), [ywhi] \"v\"(ywhi), [last] \"v\"(last)" << (fr.tangent ? ", [xl] \"v\"(xladdr)" : "") << "\n";
         o << I4 << "    :";
         bool first = true;
         for (int r = K0; r < VT; ++r) { o << (first ? " " : ", ") << "\"v" << r << "\""; first = false; }
-        for (int r = SF; r < MORE + 1; ++r) o << ", \"s" << r << "\"";
-        if (xpre) { for (int r = 0; r < 2 * NQ; ++r) o << ", \"a" << r << "\""; o << ", \"vcc\""; }
+        for (int r = SF; r < LAST + 1; ++r) o << ", \"s" << r << "\"";
         o << ", \"scc\", \"memory\");\n";
-        if (fr.tangent && !xpre)                                 // stage state of the next stage (or of the first stage of the next step)
+        if (fr.tangent)                                          // stage state of the next stage (or of the first stage of the next step)
             o << I4 << "{\n"
               << I4 << "    const i64 nxt = (ti - step_begin) * S + st + 1;\n"
               << I4 << "    if (nxt < (step_end - step_begin) * S) QGS_LOAD_XS(stages + nxt * " << ndim << " * ld);\n"
