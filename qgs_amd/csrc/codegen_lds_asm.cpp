@@ -1,24 +1,27 @@
-// codegen_lds_asm.cpp -- the LDS-resident stepper of large systems with a hand-scheduled stage body.  See codegen.h /
-// codegen_internal.h; the frame (workgroup shape, stage state in LDS, rows split over wavefronts, phases that cache a set of
-// modes in registers) is the one of emit_rk_lds_kernel in codegen_lds.cpp.
+// codegen_lds_asm.cpp -- the LDS-resident kernels of large rank-3 systems with a hand-scheduled stage body: the stepper
+// (qgs_spec_rkldsa<W>) and the tangent / adjoint model (qgs_spec_tglldsa<W> / qgs_spec_adjldsa<W>).  See codegen.h /
+// codegen_internal.h; the frames (workgroup shape, stage state in LDS, rows split over wavefronts, phases that cache a set of LDS
+// values in registers) are those of emit_rk_lds_kernel / emit_tgl_lds_kernel in codegen_lds.cpp.
 //
-// Why.  Left to the compiler, the straight-line stage body of that kernel spills at every workgroup shape (420 B per lane at 16
+// Why.  Left to the compiler, the straight-line stage body of those kernels spills at every workgroup shape (420 B per lane at 16
 // wavefronts, 700 - 1 100 B at 12 and 8: profiles/r06_lds228_variants.txt) -- the machine scheduler hoists LDS reads and
 // coefficient fetches across the phases the generator laid out, and every `s_waitcnt lgkmcnt(0)` (LDS reads and scalar loads share
-// one counter, scalar loads return out of order) waits for something that has only just been issued: 57 % of the wavefront-cycles
-// of qgs_spec_rklds16 are waits.  The generator knows every live range, so here it allocates the registers itself and emits the
-// stage body as ONE inline-assembly statement per wavefront:
+// one counter, scalar loads return out of order) waits for something that has only just been issued: 57 - 59 % of the
+// wavefront-cycles of qgs_spec_rklds16 / qgs_spec_tgllds16 are waits.  The generator knows every live range, so here it allocates the
+// registers itself and emits the stage body as ONE inline-assembly statement per wavefront (8 wavefronts x 256 registers):
 //   * registers: the running sums `acc` (tied to the C++ variables by physical-register constraints), the stage sums `k`, a few
-//     temporaries, and the factor cache in two halves -- phase p computes out of one half while the LDS reads of phase p + 1 land
-//     in the other;
-//   * coefficients: the wavefront's table is consumed in chunks of 16 entries held in two SGPR buffers; the scalar loads of chunk
-//     c + 1 leave at the moment chunk c starts being consumed, so the one `s_waitcnt lgkmcnt(0)` per chunk waits for loads that
-//     have been in flight for a whole chunk (~50 fp64 instructions) -- and it is also the wait that covers the LDS reads issued a
-//     phase ahead;
-//   * the step-start state y is read back from the private global buffer into the idle cache half during the last phase
-//     (vector-memory counter: in order, separate from the LDS / scalar counter), and not at all in the last stage;
-//   * nothing is spilled, no lane moves, no scratch.
-// Everything outside the stage body (prologue, record stores, stage-state store for the tangent pass, final stores) stays C++.
+//     temporaries, the coefficient ring, and the factor cache -- one set: a value a phase shares with its predecessor stays in its
+//     slot, the statements of a phase are ordered by the last LDS read they need and wait for exactly that read (developer
+//     variant: two halves, phase p + 1 prefetched while phase p computes);
+//   * coefficients: the wavefront's table in chunks of 16 doubles through vector memory, lane l of every row of 16 lanes loading
+//     entry l into a ring of register pairs two chunks ahead, picked by `v_fmac_f64_dpp ... row_newbcast` (vector loads return in
+//     order: the wait is precise; nothing but LDS reads is left on the LDS / scalar counter).  Developer variant: two SGPR buffers;
+//   * the step-start state y is read back from the private global buffer into cache slots the last phase does not use, requested
+//     when that phase starts, and not at all in the last stage;
+//   * rows per wavefront: contiguous blocks found by dynamic programming over the instructions a block really needs;
+//   * nothing is spilled, no lane moves, no scratch in the stage body.
+// Everything outside the stage body (prologue, record stores, stage-state store / load for the tangent model, final stores) stays C++.
+// profiles/r06_lds228.md and profiles/r06_tgllds.md have the measurements.
 #include "codegen_internal.h"
 
 #include <algorithm>
