@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from qgs_amd import _lib  # noqa: E402
+if os.environ.get('RK_AB_LIB'):                    # another build of the library (developer knobs)
+    _lib.LIB_PATH = os.path.abspath(os.environ['RK_AB_LIB'])
 
 RK4 = dict(c=np.array([0., 0.5, 0.5, 1.]), b=np.array([1. / 6, 1. / 3, 1. / 3, 1. / 6]),
            a=np.array([[0., 0, 0, 0], [0.5, 0, 0, 0], [0, 0.5, 0, 0], [0, 0, 1., 0]]))
