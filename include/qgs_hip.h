@@ -81,8 +81,9 @@ int64_t qgs_model_info(const qgs_model *m, int which);
  * stepper serves the trajectory integrations and f, and (ndim <= 243) LDS-resident tangent / adjoint kernels the
  * tangent pass; Df stays generic.  In automatic mode the LDS-resident kernels are used when their code objects are
  * already cached (the cache that ships with the tree, or a previous run) or when one call is long enough to pay for the
- * compilation: about a second for the rank-3 stepper (hand-scheduled stage body, from 5e11 term-stages per call), 10 - 40 s for
- * the tangent / adjoint, rank-5 and general-tableau flavours (from 2e12).  bench.py's cold_start entries quantify each case.
+ * compilation: one to four seconds for the rank-3 stepper and tangent / adjoint kernels (hand-scheduled stage body, from 5e11
+ * term-stages per call), 10 - 40 s for the rank-5 and general-tableau flavours (from 2e12).  bench.py's cold_start entries
+ * quantify each case.
  * The call also re-reads the kernel-selection knobs of INTEGRATION.md from the environment (they are read
  * when a model is created and here, never inside a launch). */
 int qgs_model_set_kernel(qgs_model *m, int kind);

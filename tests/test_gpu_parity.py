@@ -749,7 +749,7 @@ def test_hand_scheduled_lds_tangent_kernels_vs_oracle_and_their_twins(monkeypatc
     """`qgs_spec_tglldsa8` / `qgs_spec_adjldsa8` (codegen_lds_asm.cpp: the stage body of the hand-scheduled LDS stepper in the frame of
     the LDS-resident tangent kernels) and the compiler-scheduled `qgs_spec_tgllds16` / `qgs_spec_adjlds16`, each selected by
     QGS_HIP_LDS_TGL_ASM, against the oracle and against each other: tangent forward with records, adjoint backward with `inverse`,
-    a 2-stage scheme without records; ragged member and column tiles."""
+    a 2-stage scheme without records, a 3-stage scheme with a record every third step; ragged member and column tiles."""
     from qgs_amd import _lib
     from oracle.oracle import OracleModel
     if tensor == 'a72':
@@ -768,8 +768,10 @@ def test_hand_scheduled_lds_tangent_kernels_vs_oracle_and_their_twins(monkeypatc
     t = np.concatenate((np.arange(0., 0.6, 0.1), [0.6]))
     b2, c2 = np.array([0., 1.]), np.array([0., .5])
     a2 = np.zeros((2, 2)); a2[1, 0] = .5
+    b3, c3 = np.array([1. / 6, 2. / 3, 1. / 6]), np.array([0., .5, 1.])
+    a3 = np.zeros((3, 3)); a3[1, 0] = .5; a3[2, 1] = 1.
     cases = [(1, 2, RK4['b'], RK4['c'], RK4['a'], False, 1.), (-1, 1, RK4['b'], RK4['c'], RK4['a'], True, -1.),
-             (1, 0, b2, c2, a2, True, 1.), (1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.)]
+             (1, 0, b2, c2, a2, True, 1.), (1, 0, RK4['b'], RK4['c'], RK4['a'], False, 1.), (1, 3, b3, c3, a3, False, 1.)]
     refs = [ora.integrate_runge_kutta_tgls_jit(t, ic, tg, d, ws, b, c, a, adj, inv) for d, ws, b, c, a, adj, inv in cases]
     out = {}
     for asm in ('1', '0'):
