@@ -468,7 +468,7 @@ std::string options_signature(const CodegenOptions &o)
       << ",lo" << o.lds_order << ",la" << o.lds_asm << ":" << o.lds_asm_waves << ":" << o.lds_asm_cap << ":" << o.lds_asm_pingpong << ":"
       << o.lds_asm_lanes << ":" << o.lds_asm_chunk << ":" << o.lds_asm_vfree << ":" << o.lds_asm_sfree << ":" << o.lds_asm_mincap << ":" << o.lds_asm_coef
       << ":" << o.lds_asm_ring << ":" << o.lds_asm_progressive << ":" << o.lds_asm_merge
-      << ":" << o.lds_asm_keep << ":" << o.lds_asm_fmac << ",lt" << o.lds_tgl_asm << ",ta" << o.tgl_asm << ":" << o.tgl_asm_ring << ",ds" << o.asm_dpp_spacing;
+      << ":" << o.lds_asm_keep << ":" << o.lds_asm_fmac << ":" << o.lds_asm_skip << ",lt" << o.lds_tgl_asm << ",ta" << o.tgl_asm << ":" << o.tgl_asm_ring << ",ds" << o.asm_dpp_spacing;
     return s.str();
 }
 

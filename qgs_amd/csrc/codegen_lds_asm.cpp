@@ -774,7 +774,13 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         o << I4 << "// " << R << " rows, cache " << NS << " slots, phases of <= " << pl.cap << " modes: " << P << " phases, " << wave_instr[w]
           << " fp64 instructions\n";
         o << I4 << "asm volatile(\n";
-        for (const std::string &ln : body) o << I4 << "    \"" << ln << "\\n\"\n";
+        for (const std::string &ln : body) {
+            // (timing experiments of the developer build: the body without its barriers / LDS waits / vector-memory waits -- wrong results)
+            if ((opt.lds_asm_skip & 1) && ln == "s_barrier") continue;
+            if ((opt.lds_asm_skip & 2) && ln.compare(0, 18, "s_waitcnt lgkmcnt(") == 0) continue;
+            if ((opt.lds_asm_skip & 4) && ln.compare(0, 16, "s_waitcnt vmcnt(") == 0 && ln.find("lgkmcnt") == std::string::npos) continue;
+            o << I4 << "    \"" << ln << "\\n\"\n";
+        }
         o << I4 << "    :";
         for (int i = 0; i < R; ++i) o << (i ? ", " : " ") << "\"+{" << vreg(ACC(i)) << "}\"(acc" << own[i] << ")";
         o << "\n" << I4 << "    : [lds] \"v\"(ldsaddr), [lane8] \"v\"(lane8), [hb] \"v\"(hb), [ha] \"v\"(ha), [ktlo] \"v\"(ktlo), [kthi] \"v\"(kthi), "
