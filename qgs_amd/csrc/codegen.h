@@ -69,7 +69,7 @@ struct CodegenOptions {
                                //     for the LDS reads it needs (in-order returns, nothing else on the counter)
     bool asm_dpp_spacing = true;   // both hand-scheduled kernels: two wait states between a VALU write of ANY register and a DPP instruction that
                                //     reads it (the compiler's rule); false: only for the DPP-shuffled operand, which these kernels never write by VALU
-    int lds_asm_skip = 0;      //     developer timing experiments: 1 = no barriers, 2 = no LDS waits, 4 = no vector-memory waits (wrong results)
+    int lds_asm_skip = 0;      //     developer timing experiments (wrong results): 1 = no barriers, 2 = no LDS waits, 4 = no vector-memory waits, 8 = no loads, 16 = no spacing s_nop, 32 = plain FMA for the DPP form
     bool lds_asm_fmac = true;  //     t = fma(a, b, t) as the two-address v_fmac_f64 (4 bytes instead of 8)
     bool lds_asm_merge = true; //     consecutive phases whose modes fit the cache together are one phase (the greedy cover's tail of 2 - 4-mode phases)
     bool lds_asm_keep = true;  //     (one cache set) a mode the previous phase left in a slot stays there and is not read again

@@ -779,6 +779,14 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
             if ((opt.lds_asm_skip & 1) && ln == "s_barrier") continue;
             if ((opt.lds_asm_skip & 2) && ln.compare(0, 18, "s_waitcnt lgkmcnt(") == 0) continue;
             if ((opt.lds_asm_skip & 4) && ln.compare(0, 16, "s_waitcnt vmcnt(") == 0 && ln.find("lgkmcnt") == std::string::npos) continue;
+            if ((opt.lds_asm_skip & 8) && (ln.compare(0, 7, "ds_read") == 0 || ln.compare(0, 11, "global_load") == 0)) continue;      // no loads at all
+            if ((opt.lds_asm_skip & 16) && ln.compare(0, 6, "s_nop ") == 0 && ln != "s_nop 4") continue;                                // no spacing
+            if ((opt.lds_asm_skip & 32) && ln.find("_dpp ") != std::string::npos) {                                                     // plain FMA instead of the DPP form
+                std::string t = ln.substr(0, ln.find(" row_newbcast"));
+                t.replace(t.find("v_fmac_f64_dpp"), 14, "v_fmac_f64");
+                o << I4 << "    \"" << t << "\\n\"\n";
+                continue;
+            }
             o << I4 << "    \"" << ln << "\\n\"\n";
         }
         o << I4 << "    :";

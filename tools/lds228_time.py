@@ -20,6 +20,7 @@ for _ in range(3):
     m.rk_integrate_device(n, n, ic.data_ptr(), t, 1, 0, b, c, a, rec.data_ptr(), st)
     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
 info = m.last_kernel_info()
+clk = m.kernel_clock()                     # (shader GHz, ms) of the last launch: in-kernel probe
 # numerics of the kernel just timed: 200 members x 12 steps (records every 4) against the generic tiled kernel
 nc, sc = 200, 12
 tc = np.concatenate((np.arange(0., sc * 0.1, 0.1), [sc * 0.1]))[:sc + 1]
@@ -27,4 +28,4 @@ icc = np.random.RandomState(5).rand(nc, ndim) * 0.01
 a_spec = m.rk_integrate(tc, icc, 1, 4, b, c, a)
 m.set_kernel(1)
 a_gen = m.rk_integrate(tc, icc, 1, 4, b, c, a)
-print('%.2f ms %s  max rel diff vs %s: %.1e' % (min(ts[1:]) * 1e3, info, m.last_kernel_info()['name'], float(np.abs(a_spec - a_gen).max() / np.abs(a_gen).max())), flush=True)
+print('%.2f ms at %.2f GHz %s  max rel diff vs %s: %.1e' % (min(ts[1:]) * 1e3, clk[0] if clk else 0., info, m.last_kernel_info()['name'], float(np.abs(a_spec - a_gen).max() / np.abs(a_gen).max())), flush=True)
