@@ -351,6 +351,7 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
             body.push_back("global_load_dwordx2 " + vreg(RING + 2 * (c % NR)) + ", v" + std::to_string(L15) + ", " + sreg(KB) + " offset:" + std::to_string((c % 32) * 128));
             ring_op[c % NR] = vm_issue(false);
         };
+        int reads_done = 0, reads_total = 0;                  // LDS read instructions of the current phase: known to have returned / issued
         auto boundary = [&]() {                              // chunk `chunk` is used up
             ++chunk;
             ++n_chunks;
@@ -358,8 +359,9 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
                 issue_ring(chunk + NR - 1);                   // into the slot of the chunk just finished (chunks chunk .. chunk + NR - 2 are there or on their way)
                 vm_wait(ring_op[chunk % NR], false);
             } else {
-                body.push_back("s_waitcnt lgkmcnt(0)");
+                body.push_back("s_waitcnt lgkmcnt(0)");          // (scalar loads share the counter with the LDS reads: both have landed)
                 lds_pending = false;
+                reads_done = reads_total;
                 issue_chunk(chunk + 1);
             }
         };
@@ -470,7 +472,7 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
             if (i < modes.size()) reads.push_back({(int)i, modes[i], 0});
             emit_reads(cache_base(p), reads);
         };
-        auto lds_wait = [&]() { body.push_back("s_waitcnt lgkmcnt(0)"); lds_pending = false; };
+        auto lds_wait = [&]() { body.push_back("s_waitcnt lgkmcnt(0)"); lds_pending = false; reads_done = reads_total; };
         // global address of own row i: YB pair = yw + 4096 * (i / 8), immediate offset 512 * (i % 8)
         int yb_block = -1;
         auto ybase = [&](int i) {
@@ -596,7 +598,7 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
         for (int p = 0; p < P; ++p) {
             const Phase &ph = phases[p];
             std::vector<Statement> sts = statements_of(ph);
-            const bool progressive = dpp && !pp && opt.lds_asm_progressive;
+            const bool progressive = !pp && opt.lds_asm_progressive;
             std::map<int, int> slot_of, read_of;                // mode -> cache slot; mode -> index of the read instruction that brings it (-1: resident)
             std::vector<ReadIns> reads;
             if (pp) {
@@ -654,6 +656,8 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
                     std::stable_sort(sts.begin(), sts.end(), [&](const Statement &x, const Statement &y) { return last_read(x) < last_read(y); });
                 }
                 emit_reads(C0, reads);
+                reads_total = n_read_instr;
+                reads_done = 0;
                 if (!progressive && !reads.empty()) { lds_wait(); ++n_extra_waits; }
                 if (p == P - 1) {                               // the step-start state: into the slots this last phase does not use
                     for (int q2 = 0; q2 < NS; ++q2) (resident[q2] && wanted[resident[q2]] ? late_regs : early_regs).push_back(C0 + 2 * q2);
@@ -686,12 +690,13 @@ void emit_lds_asm(std::ostringstream &out, int ndim, const RowTerms &rt, const s
                 body.push_back(".Lqgs_ny%=:");
             }
             // NL statements in flight, their instructions round-robin (independent fp64 dependency chains)
-            int reads_done = progressive ? 0 : n_read_instr;   // LDS read instructions known to have returned
-            const int reads_total = n_read_instr;
+            if (pp) { reads_total = n_read_instr; reads_done = n_read_instr; }
             auto need = [&](int read) {                        // read instruction `read` of this phase has returned (-1: resident)
                 const int q = read + 1;                        // read instructions needed
                 if (q <= reads_done) return;
-                const int allow = std::min(15, reads_total - q);          // 4-bit counter: at most 15 may stay outstanding
+                // (4-bit counter: at most 15 may stay outstanding; SGPR mode: scalar loads may be on the counter too, and they return
+                // out of order: everything)
+                const int allow = dpp ? std::min(15, reads_total - q) : 0;
                 body.push_back("s_waitcnt lgkmcnt(" + std::to_string(allow) + ")");
                 reads_done = reads_total - allow;
                 if (reads_done >= reads_total) lds_pending = false;
