@@ -1226,6 +1226,12 @@ def main():
         clock = model.kernel_clock()                     # of the last timed pass's stepper launch (in-kernel probe, qgs_kernel_clock)
     except Exception:
         clock = None
+    fma_rate = None
+    if rank == 0 and world == 1:                          # (behind the timed region; ~30 ms)
+        try:
+            fma_rate = _lib.fp64_fma_rate(dev.index or 0, 30.0)
+        except Exception:
+            fma_rate = None
     # --busy-fill (off by default): a short timed region (the driver's --steps 20 is 90 ms) is invisible to an smi sampler; with the
     # flag the same passes are run on, untimed and outside every statistic above, until this process has kept the GPU busy for ~1.2 s.
     busy_fill_passes = 0
@@ -1275,6 +1281,12 @@ def main():
             'gather_ms': gather_ms,        # one RCCL gather of the final states onto rank 0, start to completion (None without a process group)
             'roofline': {'bound': 'fp64_valu', 'achieved': tflops, 'peak': FP64_VALU_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': tflops / FP64_VALU_PEAK_TFLOPS,
+                         # what THIS box sustains on independent fp64 FMAs alone (qgs_fp64_fma_rate, ~30 ms behind the timed region: the
+                         # board lowers the clock under fp64 load, so the nominal peak is not reachable by any instruction stream) and the
+                         # EXECUTED flops of the kernel as a fraction of it
+                         'sustained_fma_tflops': fma_rate[0] if fma_rate else None, 'sustained_fma_ms': fma_rate[1] if fma_rate else None,
+                         'executed_frac_of_sustained_fma': (fp64_instr * 2.0 * n_traj * rk_steps / (kern_ms * 1e-3) / 1e12 / fma_rate[0])
+                                                           if (fp64_instr and fma_rate) else None,
                          # the clock the timed launch ran at (in-kernel probe: shader-clock counter over the 100 MHz counter of
                          # workgroup 0, which lives for the whole launch) and the fraction of the FP64 peak AT that clock
                          'effective_clock_ghz': clock[0] if clock else None,
@@ -1329,6 +1341,11 @@ def main():
                 for k, v in result['configs'].items():
                     entries = v.items() if k == 'f_rows' else [(k, v)]
                     failures += [kk for kk, vv in entries if not (isinstance(vv, dict) and vv.get('parity_check', {}).get('ok', False))]
+                    for kk, vv in entries:                                   # fp64-bound entries also against what this box sustains on FMAs alone
+                        rf = vv.get('roofline') if isinstance(vv, dict) else None
+                        if fma_rate and isinstance(rf, dict) and rf.get('bound') == 'fp64_valu' and rf.get('achieved'):
+                            rf['sustained_fma_tflops'] = fma_rate[0]
+                            rf['frac_of_sustained_fma'] = rf['achieved'] / fma_rate[0]
             except Exception as e:                                           # never lose the headline line to a side measurement
                 result['configs'] = {'error': repr(e)}
         if world == 1 and not args.no_cold_start:

@@ -303,6 +303,11 @@ int qgs_clv_backstep_device(qgs_model *m, int64_t n_traj, int64_t ld, int n_vec,
 int qgs_last_kernel_info(const qgs_model *m, char *name_buf, int buflen,
                          int *vgprs, int *sgprs, int *lds_bytes, int *scratch_bytes);
 
+/* What the device sustains on independent fp64 FMAs and nothing else (eight chains per lane, eight wavefronts per SIMD), timed over
+ * about `target_ms` milliseconds with HIP events on the default stream: *tflops, *elapsed_ms.  A measurement aid of bench.py (the
+ * practical ceiling next to the nominal FP64 peak: the board lowers the clock under this load); no counterpart in the reference. */
+int qgs_fp64_fma_rate(int device, double target_ms, double *tflops, double *elapsed_ms);
+
 /* Effective shader clock of the LAST generated kernel this model launched (blocks until the device is idle): lane 0 of
  * workgroup 0 notes the shader-clock counter and the constant 100 MHz counter when it starts and when it has issued its last
  * store.  *shader_ghz = shader cycles per nanosecond over that interval, *elapsed_ms = the interval (one workgroup's life: the

@@ -71,6 +71,7 @@ SIGNATURES = {
                                             _f64p, _int, _dbl, _vp, _vp, _vp]),
     'qgs_batched_qr_device': (_int, [_vp, _i64, _i64, _int, _int, _vp, _vp, _vp]),
     'qgs_kernel_clock': (_int, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    'qgs_fp64_fma_rate': (_int, [_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     'qgs_ensemble_moments_device': (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     'qgs_batched_matmul_device': (_int, [_vp, _i64, _i64, _int, _int, _int, _int, _int, _vp, _vp, _vp, _vp]),
     'qgs_clv_backstep_device': (_int, [_vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _vp]),
@@ -141,6 +142,13 @@ def backend_info():
     buf = ctypes.create_string_buffer(256)
     _check(lib().qgs_backend_info(ctypes.byref(n), buf, 256))
     return n.value, buf.value.decode()
+
+
+def fp64_fma_rate(device=0, target_ms=30.0):
+    """(TFLOP/s, milliseconds): what the device sustains on independent fp64 FMAs alone (qgs_fp64_fma_rate)."""
+    tf, ms = ctypes.c_double(0.), ctypes.c_double(0.)
+    _check(lib().qgs_fp64_fma_rate(int(device), float(target_ms), ctypes.byref(tf), ctypes.byref(ms)))
+    return tf.value, ms.value
 
 
 def n_records(time, write_steps):

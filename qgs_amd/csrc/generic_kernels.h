@@ -149,6 +149,7 @@ const char *launch_batched_qr_global(int n_rows, int n_cols, int64_t n_traj, int
                               hipStream_t st);
 // mean / variance over the members of every row of X[row][member]; `part` holds 2 * n_rows * moments_splits() doubles
 int moments_splits(int64_t n_rows, int64_t n_traj);
+void launch_fma_rate(int blocks, int iters, double *out, hipStream_t st);      // blocks x 256 lanes x iters x 8 independent fp64 FMAs
 void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x, double *part, double *mean, double *var,
                     hipStream_t st);
 

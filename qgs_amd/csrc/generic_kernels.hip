@@ -1124,6 +1124,25 @@ int moments_splits(int64_t n_rows, int64_t n_traj)
     return (int)(s < 1 ? 1 : (s > 1024 ? 1024 : s));
 }
 
+// What this chip sustains on nothing but independent fp64 FMAs (eight chains per lane, eight wavefronts per SIMD): the practical
+// ceiling bench.py sets its fp64 kernels against next to the nominal peak (the board lowers the clock under this load).
+__global__ void __launch_bounds__(256) fma_rate_kernel(double *out, int iters)
+{
+    double x = 1.0000001 + threadIdx.x * 1e-9, y = 0.9999999;
+    double a0 = 0, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
+#pragma nounroll
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_fma(x, y, a0); a1 = __builtin_fma(x, y, a1); a2 = __builtin_fma(x, y, a2); a3 = __builtin_fma(x, y, a3);
+        a4 = __builtin_fma(x, y, a4); a5 = __builtin_fma(x, y, a5); a6 = __builtin_fma(x, y, a6); a7 = __builtin_fma(x, y, a7);
+    }
+    out[(size_t)blockIdx.x * 256 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+}
+
+void launch_fma_rate(int blocks, int iters, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(fma_rate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, out, iters);
+}
+
 void launch_moments(int64_t n_rows, int64_t n_traj, int64_t ld, const double *x, double *part, double *mean, double *var,
                     hipStream_t st)
 {
