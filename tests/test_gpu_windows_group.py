@@ -764,3 +764,12 @@ def test_kernel_clock_probe():
     torch.cuda.synchronize()
     assert m.kernel_clock() is None
     m.close()
+
+
+def test_fp64_fma_rate_is_below_the_nominal_peak_and_plausible():
+    """`qgs_fp64_fma_rate`: independent fp64 FMAs, eight wavefronts per SIMD, over ~ 20 ms: between a third of the nominal 78.6 TFLOP/s
+    and the nominal peak itself (the board lowers the clock under this load; bench.py quotes its fp64 kernels against both)."""
+    from qgs_amd import _lib
+    tf, ms = _lib.fp64_fma_rate(0, 20.0)
+    assert 25.0 < tf <= 78.6 * 1.02, tf
+    assert 5.0 < ms < 200.0, ms
